@@ -1,0 +1,1029 @@
+// TEST INFRASTRUCTURE ONLY — fp64 CPU oracle for the DiffCloth hot path. See orc_sim.h.
+// Reference paths are relative to /root/reference/src/code/simulation/ ("Sim.cpp" = Simulation.cpp).
+#include "orc_sim.h"
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <queue>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace orc {
+
+// ------------------------------------------------------------------------------------------------
+// Mesh / constraint construction
+// ------------------------------------------------------------------------------------------------
+
+// Triangle rest data: Triangle.cpp:587-645.  Bending flaps: Sim.cpp:2096-2131 + TriangleBending.cpp:186-239.
+// Vertex areas: Sim.cpp:2894-2930.  Collision radii: Sim.cpp:2407-2431.  Connectivity table: Sim.cpp:2236-2239.
+void Sim::setMesh(int n, const double *pos, int T, const int *tri) {
+  N = n;
+  rest.assign(pos, pos + 3 * n);
+  tris_in.clear();
+  tris.clear();
+  bends.clear();
+  connected.assign(n, std::set<int>());
+  std::vector<std::vector<int>> particleTriangleMap(n);
+  for (int t = 0; t < T; t++) {
+    TriRest tr;
+    for (int k = 0; k < 3; k++) tr.v[k] = tri[3 * t + k];
+    tris_in.push_back({tr.v[0], tr.v[1], tr.v[2]});
+    V3 p0 = seg3(rest, tr.v[0]), p1 = seg3(rest, tr.v[1]), p2 = seg3(rest, tr.v[2]);
+    V3 e0 = p1 - p0, e1 = p2 - p0;
+    V3 P0 = e0.normalized();
+    V3 P1 = (e1 - P0 * e1.dot(P0)).normalized();
+    // deltaUV = P^T * edgeVec (2x2), inv_deltaUV = deltaUV^{-1}
+    double a = P0.dot(e0), b = P0.dot(e1), c = P1.dot(e0), d = P1.dot(e1);
+    double det = a * d - b * c;
+    tr.D[0] = d / det; tr.D[1] = -b / det; tr.D[2] = -c / det; tr.D[3] = a / det;
+    tr.area = std::fabs(det * 0.5);
+    tr.w = 0;
+    tris.push_back(tr);
+    for (int i = 0; i < 3; i++) {
+      particleTriangleMap[tr.v[i]].push_back(t);
+      for (int j = 0; j < 3; j++) connected[tr.v[i]].insert(tr.v[j]);
+    }
+  }
+  // bending flaps, ordered by (min,max) edge key with opposite vertices in triangle-iteration order
+  std::map<std::pair<int, int>, std::vector<int>> edgeTriangleMap;
+  for (int t = 0; t < T; t++) {
+    const int *idx = tris[t].v;
+    for (int v1 = 0; v1 < 3; v1++)
+      for (int v2 = v1 + 1; v2 < 3; v2++) {
+        int mn = std::min(idx[v1], idx[v2]), mx = std::max(idx[v1], idx[v2]);
+        int other = idx[(0 + 1 + 2) - (v1 + v2)];
+        edgeTriangleMap[std::make_pair(mn, mx)].push_back(other);
+      }
+  }
+  for (auto const &kv : edgeTriangleMap) {
+    if (kv.second.size() > 1) {
+      if (kv.second.size() > 2) { std::fprintf(stderr, "oracle: non-manifold edge\n"); std::abort(); }
+      BendRest b;
+      b.v[0] = kv.first.first; b.v[1] = kv.first.second; b.v[2] = kv.second[0]; b.v[3] = kv.second[1];
+      V3 p[4];
+      for (int i = 0; i < 4; i++) p[i] = seg3(rest, b.v[i]);
+      double l01 = (p[1] - p[0]).norm(), l02 = (p[2] - p[0]).norm(), l03 = (p[3] - p[0]).norm();
+      double l12 = (p[1] - p[2]).norm(), l13 = (p[1] - p[3]).norm();
+      double r0 = 0.5 * (l01 + l02 + l12);
+      b.A0 = std::sqrt(r0 * (r0 - l01) * (r0 - l02) * (r0 - l12));
+      double r1 = 0.5 * (l01 + l13 + l03);
+      b.A1 = std::sqrt(r1 * (r1 - l01) * (r1 - l03) * (r1 - l13));
+      double cot02 = ((l01 * l01) - (l02 * l02) + (l12 * l12)) / (4.0 * b.A0);
+      double cot12 = ((l01 * l01) + (l02 * l02) - (l12 * l12)) / (4.0 * b.A0);
+      double cot03 = ((l01 * l01) - (l03 * l03) + (l13 * l13)) / (4.0 * b.A1);
+      double cot13 = ((l01 * l01) + (l03 * l03) - (l13 * l13)) / (4.0 * b.A1);
+      b.wv[0] = cot02 + cot03; b.wv[1] = cot12 + cot13; b.wv[2] = -(cot02 + cot12); b.wv[3] = -(cot03 + cot13);
+      V3 e;
+      for (int i = 0; i < 4; i++) e += p[i] * b.wv[i];
+      b.n = e.norm();
+      b.w = 0;
+      bends.push_back(b);
+    }
+  }
+  // lumped areas
+  area.assign(n, 0.0);
+  for (const TriRest &t : tris)
+    for (int k = 0; k < 3; k++) area[t.v[k]] += t.area / 3.0;
+  // radii: min incident edge / 2 - 0.01
+  radii.assign(n, 0.0);
+  for (int i = 0; i < n; i++) {
+    V3 pos_i = seg3(rest, i);
+    double minEdge = 100;
+    for (int ti : particleTriangleMap[i]) {
+      const TriRest &t = tris[ti];
+      int p2 = t.v[0], p3 = t.v[1];
+      if (p2 == i) p2 = t.v[2];
+      if (p3 == i) p3 = t.v[2];
+      minEdge = std::min(minEdge, (seg3(rest, p2) - pos_i).norm());
+      minEdge = std::min(minEdge, (seg3(rest, p3) - pos_i).norm());
+    }
+    radii[i] = minEdge / 2.0 - 0.01;
+  }
+}
+
+// Sim.cpp:2969-3059 (initializePrefactoredMatrices), row coefficients Triangle.cpp:296-304,
+// TriangleBending.cpp:20-24, AttachmentSpring.cpp:61-63; masses Sim.cpp:2932-2937.
+void Sim::build() {
+  mass.assign(N, 0.0);
+  for (int i = 0; i < N; i++) mass[i] = area[i] * P.density;
+  for (TriRest &t : tris) t.w = std::sqrt(t.area * P.k_stretch);
+  for (BendRest &b : bends) b.w = std::sqrt(P.k_bend * 3.0 / (b.A0 + b.A1));
+  double w_att = std::sqrt(P.k_att);
+
+  rows.clear();
+  for (const TriRest &t : tris)
+    for (int i = 0; i < 2; i++) {
+      Row r; r.nv = 3; r.type = 0;
+      r.v[0] = t.v[0]; r.c[0] = -t.w * (t.D[0 * 2 + i] + t.D[1 * 2 + i]);
+      r.v[1] = t.v[1]; r.c[1] = t.w * t.D[0 * 2 + i];
+      r.v[2] = t.v[2]; r.c[2] = t.w * t.D[1 * 2 + i];
+      r.v[3] = -1; r.c[3] = 0;
+      rows.push_back(r);
+    }
+  for (const BendRest &b : bends) {
+    Row r; r.nv = 4; r.type = 1;
+    for (int i = 0; i < 4; i++) { r.v[i] = b.v[i]; r.c[i] = b.w * b.wv[i]; }
+    rows.push_back(r);
+  }
+  for (int a : att) {
+    Row r; r.nv = 1; r.type = 2;
+    r.v[0] = a; r.c[0] = w_att; r.v[1] = r.v[2] = r.v[3] = -1; r.c[1] = r.c[2] = r.c[3] = 0;
+    rows.push_back(r);
+  }
+  // weightless coefficient per row: coefficient / sqrt(k_type)  (addConstraint(withWeight=false))
+  double sqrtk[3] = {std::sqrt(P.k_stretch), std::sqrt(P.k_bend), std::sqrt(P.k_att)};
+
+  std::vector<std::map<int, double>> Cm(N);
+  std::vector<std::map<int, double>> Lm[3];
+  for (int t = 0; t < 3; t++) Lm[t].assign(N, std::map<int, double>());
+  double h2 = P.h * P.h;
+  for (const Row &r : rows)
+    for (int a = 0; a < r.nv; a++)
+      for (int b = 0; b < r.nv; b++) {
+        Cm[r.v[a]][r.v[b]] += h2 * r.c[a] * r.c[b];
+        if (sqrtk[r.type] > 0) Lm[r.type][r.v[a]][r.v[b]] += (r.c[a] / sqrtk[r.type]) * (r.c[b] / sqrtk[r.type]);
+      }
+  Pptr.assign(N + 1, 0); Pcol.clear(); Pval.clear(); Cval.clear();
+  for (int t = 0; t < 3; t++) Lval[t].clear();
+  for (int i = 0; i < N; i++) {
+    Cm[i][i] += 0.0;
+    for (auto &kv : Cm[i]) {
+      Pcol.push_back(kv.first);
+      Cval.push_back(kv.second);
+      Pval.push_back(kv.second + (kv.first == i ? mass[i] : 0.0));
+      for (int t = 0; t < 3; t++) {
+        auto it = Lm[t][i].find(kv.first);
+        Lval[t].push_back(it == Lm[t][i].end() ? 0.0 : it->second);
+      }
+    }
+    Pptr[i + 1] = (int) Pcol.size();
+  }
+
+  // --- reverse Cuthill-McKee ordering + skyline Cholesky (stand-in for SimplicialLLT) ---
+  perm.clear();
+  std::vector<char> visited(N, 0);
+  std::vector<int> deg(N);
+  for (int i = 0; i < N; i++) deg[i] = Pptr[i + 1] - Pptr[i];
+  for (int s0 = 0; s0 < N; s0++) {
+    if (visited[s0]) continue;
+    // pick a low-degree start inside this component via two BFS sweeps (pseudo-peripheral node)
+    int start = s0;
+    for (int sweep = 0; sweep < 2; sweep++) {
+      std::vector<int> dist(N, -1);
+      std::queue<int> q; q.push(start); dist[start] = 0; int last = start;
+      while (!q.empty()) {
+        int u = q.front(); q.pop(); last = u;
+        for (int k = Pptr[u]; k < Pptr[u + 1]; k++) { int w = Pcol[k]; if (dist[w] < 0 && !visited[w]) { dist[w] = dist[u] + 1; q.push(w); } }
+      }
+      start = last;
+    }
+    std::queue<int> q; q.push(start); visited[start] = 1;
+    while (!q.empty()) {
+      int u = q.front(); q.pop(); perm.push_back(u);
+      std::vector<int> nb;
+      for (int k = Pptr[u]; k < Pptr[u + 1]; k++) { int w = Pcol[k]; if (!visited[w]) { visited[w] = 1; nb.push_back(w); } }
+      std::sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+      for (int w : nb) q.push(w);
+    }
+  }
+  std::reverse(perm.begin(), perm.end());
+  iperm.assign(N, 0);
+  for (int i = 0; i < N; i++) iperm[perm[i]] = i;
+  skyFirst.assign(N, 0);
+  for (int i = 0; i < N; i++) {
+    int u = perm[i], first = i;
+    for (int k = Pptr[u]; k < Pptr[u + 1]; k++) first = std::min(first, iperm[Pcol[k]]);
+    skyFirst[i] = first;
+  }
+  skyPtr.assign(N + 1, 0);
+  for (int i = 0; i < N; i++) skyPtr[i + 1] = skyPtr[i] + (size_t) (i - skyFirst[i] + 1);
+  skyL.assign(skyPtr[N], 0.0);
+  for (int i = 0; i < N; i++) {
+    int u = perm[i];
+    for (int k = Pptr[u]; k < Pptr[u + 1]; k++) {
+      int j = iperm[Pcol[k]];
+      if (j <= i) skyL[skyPtr[i] + (j - skyFirst[i])] = Pval[k];
+    }
+  }
+  for (int i = 0; i < N; i++) {
+    double *Li = &skyL[skyPtr[i]];
+    int fi = skyFirst[i];
+    for (int j = fi; j <= i; j++) {
+      const double *Lj = &skyL[skyPtr[j]];
+      int fj = skyFirst[j];
+      int k0 = std::max(fi, fj);
+      double sum = Li[j - fi];
+      for (int k = k0; k < j; k++) sum -= Li[k - fi] * Lj[k - fj];
+      if (j < i) Li[j - fi] = sum / Lj[j - fj];
+      else {
+        if (sum <= 0) { std::fprintf(stderr, "oracle: P not SPD at row %d (%g)\n", i, sum); std::abort(); }
+        Li[j - fi] = std::sqrt(sum);
+      }
+    }
+  }
+}
+
+// v = P^{-1} rhs (Sim.cpp:1267, :1577) for an xyz-interleaved 3N vector; P = P_s (x) I3.
+void Sim::solveP(const std::vector<double> &rhs, std::vector<double> &out) const {
+  std::vector<double> y(3 * (size_t) N);
+  for (int i = 0; i < N; i++) {
+    const double *Li = &skyL[skyPtr[i]];
+    int fi = skyFirst[i], u = perm[i];
+    double s0 = rhs[3 * u], s1 = rhs[3 * u + 1], s2 = rhs[3 * u + 2];
+    for (int k = fi; k < i; k++) { double l = Li[k - fi]; s0 -= l * y[3 * k]; s1 -= l * y[3 * k + 1]; s2 -= l * y[3 * k + 2]; }
+    double d = Li[i - fi];
+    y[3 * i] = s0 / d; y[3 * i + 1] = s1 / d; y[3 * i + 2] = s2 / d;
+  }
+  for (int i = N - 1; i >= 0; i--) {
+    const double *Li = &skyL[skyPtr[i]];
+    int fi = skyFirst[i];
+    double d = Li[i - fi];
+    y[3 * i] /= d; y[3 * i + 1] /= d; y[3 * i + 2] /= d;
+    for (int k = fi; k < i; k++) { double l = Li[k - fi]; y[3 * k] -= l * y[3 * i]; y[3 * k + 1] -= l * y[3 * i + 1]; y[3 * k + 2] -= l * y[3 * i + 2]; }
+  }
+  out.resize(3 * (size_t) N);
+  for (int i = 0; i < N; i++) { int u = perm[i]; out[3 * u] = y[3 * i]; out[3 * u + 1] = y[3 * i + 1]; out[3 * u + 2] = y[3 * i + 2]; }
+}
+
+// y = (S (x) I3) x for a scalar matrix S given by `val` on P's CSR pattern.
+void Sim::mulS(const std::vector<double> &val, const std::vector<double> &x, std::vector<double> &y) const {
+  y.assign(3 * (size_t) N, 0.0);
+  for (int i = 0; i < N; i++) {
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int k = Pptr[i]; k < Pptr[i + 1]; k++) {
+      double a = val[k]; int j = Pcol[k];
+      s0 += a * x[3 * j]; s1 += a * x[3 * j + 1]; s2 += a * x[3 * j + 2];
+    }
+    y[3 * i] = s0; y[3 * i + 1] = s1; y[3 * i + 2] = s2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Local projections
+// ------------------------------------------------------------------------------------------------
+
+// Triangle::project -> projectToManifold (Triangle.cpp:310-351): F = [x1-x0, x2-x0] inv_deltaUV; Gram-Schmidt
+// frame Q from F's columns; R = U V^T of the 2x2 Q^T F; returns vec(Q R) (unweighted).
+void Sim::triProject(const TriRest &t, const double *x, double out[6]) const {
+  V3 x0 = seg3(x, t.v[0]), x1 = seg3(x, t.v[1]), x2 = seg3(x, t.v[2]);
+  V3 e0 = x1 - x0, e1 = x2 - x0;
+  V3 F0 = e0 * t.D[0] + e1 * t.D[2], F1 = e0 * t.D[1] + e1 * t.D[3];
+  V3 q0 = F0.normalized();
+  V3 q1 = (F1 - q0 * F1.dot(q0)).normalized();
+  double F2[4] = {q0.dot(F0), q0.dot(F1), q1.dot(F0), q1.dot(F1)};
+  double U[4], s[2], V[4];
+  svd2x2(F2, U, s, V);
+  // R = U V^T
+  double R[4] = {U[0] * V[0] + U[1] * V[1], U[0] * V[2] + U[1] * V[3], U[2] * V[0] + U[3] * V[1], U[2] * V[2] + U[3] * V[3]};
+  V3 n0 = q0 * R[0] + q1 * R[2], n1 = q0 * R[1] + q1 * R[3];
+  out[0] = n0.x; out[1] = n0.y; out[2] = n0.z; out[3] = n1.x; out[4] = n1.y; out[5] = n1.z;
+}
+
+// Triangle::projectToManifoldBackward (Triangle.cpp:354-451): analytic 6x9 Jacobian of vec(QR) w.r.t.
+// (x0,x1,x2).  Note the frame here is built from the raw edges (a,b), not from F's columns, as in the reference.
+Mat Sim::triProjectBackward(const TriRest &t, const double *x) const {
+  Mat I3 = Mat::identity(3), I2 = Mat::identity(2);
+  V3 x0 = seg3(x, t.v[0]), x1 = seg3(x, t.v[1]), x2 = seg3(x, t.v[2]);
+  V3 a = x1 - x0, b = x2 - x0;
+  V3 aN = a.normalized();
+  Mat dpv(2, 3);
+  dpv(0, 0) = -1; dpv(0, 1) = 1; dpv(1, 0) = -1; dpv(1, 2) = 1;
+  Mat dp_dx = kron(dpv, I3);             // 6x9
+  Mat db_dx = dp_dx.block(3, 0, 3, 9), da_dx = dp_dx.block(0, 0, 3, 9);
+  Mat daN_da = (I3 - outer(aN, aN)) * (1.0 / a.norm());
+  Mat daN_dx = daN_da * da_dx;
+  V3 f = b - aN * b.dot(aN);
+  V3 fN = f.normalized();
+  Mat dcol1_df = (I3 - outer(fN, fN)) * (1.0 / f.norm());
+  Mat df_db = I3 - outer(aN, aN);
+  Mat df_daN = (outer(aN, b) + I3 * aN.dot(b)) * (-1.0);
+  Mat df_dx = df_db * db_dx + df_daN * daN_dx;
+  Mat dQ_dx(6, 9);
+  dQ_dx.setBlock(0, 0, daN_dx);
+  dQ_dx.setBlock(3, 0, dcol1_df * df_dx);
+  // F1 = Q^T p (2x2), row-major vec order (F1_00, F1_10, F1_01, F1_11) as in the reference's 4-vectors
+  Mat dF1_dQ(4, 6), dF1_dp(4, 6);
+  for (int k = 0; k < 3; k++) {
+    dF1_dQ(0, k) = a[k]; dF1_dQ(2, k) = b[k]; dF1_dQ(1, 3 + k) = a[k]; dF1_dQ(3, 3 + k) = b[k];
+    dF1_dp(0, k) = aN[k]; dF1_dp(1, k) = fN[k]; dF1_dp(2, 3 + k) = aN[k]; dF1_dp(3, 3 + k) = fN[k];
+  }
+  Mat dF1_dx = dF1_dQ * dQ_dx + dF1_dp * dp_dx;  // 4x9
+  Mat D(2, 2); D(0, 0) = t.D[0]; D(0, 1) = t.D[1]; D(1, 0) = t.D[2]; D(1, 1) = t.D[3];
+  Mat F1(2, 2);
+  F1(0, 0) = aN.dot(a); F1(0, 1) = aN.dot(b); F1(1, 0) = fN.dot(a); F1(1, 1) = fN.dot(b);
+  Mat F = F1 * D;
+  Mat dF_dF1 = kron(D.T(), I2);
+  Mat dF_dx = dF_dF1 * dF1_dx;
+  double Fa[4] = {F(0, 0), F(0, 1), F(1, 0), F(1, 1)}, U[4], s[2], V[4];
+  svd2x2(Fa, U, s, V);
+  double R[4] = {U[0] * V[0] + U[1] * V[1], U[0] * V[2] + U[1] * V[3], U[2] * V[0] + U[3] * V[1], U[2] * V[2] + U[3] * V[3]};
+  double traceS = s[0] + s[1];           // trace(V diag(s) V^T)
+  Mat lhs(4, 1);
+  lhs(0, 0) = -R[1]; lhs(1, 0) = -R[3]; lhs(2, 0) = R[0]; lhs(3, 0) = R[2];
+  Mat dR_dF = lhs * (lhs.T() * (1.0 / traceS));
+  Mat dR_dx = dR_dF * dF_dx;
+  Mat Rm(2, 2); Rm(0, 0) = R[0]; Rm(0, 1) = R[1]; Rm(1, 0) = R[2]; Rm(1, 1) = R[3];
+  Mat dF2_dQ = kron(Rm.T(), I3);         // 6x6
+  Mat dF2_dR(6, 4);
+  for (int k = 0; k < 3; k++) {
+    dF2_dR(k, 0) = aN[k]; dF2_dR(k, 1) = fN[k]; dF2_dR(3 + k, 2) = aN[k]; dF2_dR(3 + k, 3) = fN[k];
+  }
+  return dF2_dQ * dQ_dx + dF2_dR * dR_dx;
+}
+
+// TriangleBending::project (TriangleBending.cpp:138-151), unweighted.
+void Sim::bendProject(const BendRest &b, const double *x, double out[3]) const {
+  V3 e;
+  if (b.n > 1e-6) {
+    for (int i = 0; i < 4; i++) e += seg3(x, b.v[i]) * b.wv[i];
+    e = e.normalized() * b.n;
+  }
+  out[0] = e.x; out[1] = e.y; out[2] = e.z;
+}
+
+// TriangleBending::backwardGradient (TriangleBending.cpp:154-172), weighted (3x12).
+Mat Sim::bendBackward(const BendRest &b, const double *x) const {
+  Mat J(3, 12);
+  if (b.n <= 1e-6) return J;
+  V3 e;
+  Mat de(3, 12);
+  for (int i = 0; i < 4; i++) {
+    e += seg3(x, b.v[i]) * b.wv[i];
+    for (int d = 0; d < 3; d++) de(d, 3 * i + d) += b.wv[i];
+  }
+  double en = e.norm();
+  V3 eh = e / en;
+  Mat dn = (Mat::identity(3) - outer(eh, eh)) * (1.0 / en) * de;
+  return dn * (b.w * b.n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Contact
+// ------------------------------------------------------------------------------------------------
+
+static std::pair<V3, double> projectionOnLine(const V3 &a, const V3 &b, const V3 &p) {  // Primitive.h:198-211
+  V3 AP = p - a, AB = b - a;
+  V3 proj = AB * (AP.dot(AB) / AB.dot(AB));
+  V3 Pp = a + proj;
+  double AB_l = (b - a).norm(), AP_l = (Pp - a).norm(), PB_l = (Pp - b).norm();
+  double t = AP_l / AB_l;
+  if (PB_l > AB_l) t *= -1;
+  return std::make_pair(Pp, t);
+}
+
+// Sphere::isInContact Primitive.cpp:221-261 (eps 0.1; discretized branch not used by shipped demos' hot path),
+// Capsule::isInContact Primitive.cpp:570-604, LowerLeg::isInContact Primitive.cpp:410-418.
+bool Sim::primInContact(const Primitive &p, const V3 &center_prim, const V3 &pos, const V3 &vel, V3 &normal,
+                        double &dist, V3 &v_out) const {
+  switch (p.kind) {
+    case PRIM_SPHERE: {
+      double eps = 0.1;
+      dist = (pos - center_prim).norm() - p.radius;
+      normal = (pos - center_prim).normalized();
+      bool collides = dist < eps;
+      v_out = p.velocity;
+      if (p.rotates) v_out += V3(0, 1, 0).cross(normal) * 8;
+      return collides;
+    }
+    case PRIM_CAPSULE: {
+      double delta = 0.1;
+      V3 posLocal = pos - center_prim;
+      v_out = p.velocity;
+      V3 bottom(0, 0, 0), top = p.topOffset;
+      std::pair<V3, double> pr = projectionOnLine(bottom, top, posLocal);
+      double t = pr.second;
+      if ((t < 0 - p.radius / p.length) || (t > 1 + p.radius / p.length)) return false;
+      if (t < 0) { dist = posLocal.norm() - p.radius; normal = posLocal.normalized(); }
+      else if (t > 1) { dist = (posLocal - top).norm() - (p.radius + 0.1); normal = (posLocal - top).normalized(); }
+      else { dist = (posLocal - pr.first).norm() - (p.radius + 0.1); normal = (posLocal - pr.first).normalized(); }
+      return dist < delta;
+    }
+    case PRIM_LOWER_LEG: {
+      for (const Primitive &c : p.children)
+        if (primInContact(c, center_prim + c.centerInit, pos, vel, normal, dist, v_out)) return true;
+      return false;
+    }
+  }
+  return false;
+}
+
+// Simulation::isInContactWithObstacle Sim.cpp:153-191: test t=0, h/2, h; first hit of the first primitive wins.
+PrimContact Sim::isInContactWithObstacle(const V3 &pos, const V3 &v_in) const {
+  PrimContact info;
+  for (int i = 0; i < (int) prims.size(); i++) {
+    const Primitive &p = prims[i];
+    const double ts[3] = {0.0, 0.5, 1.0};
+    for (int k = 0; k < 3; k++) {
+      if (primInContact(p, p.center, pos + v_in * (P.h * ts[k]), v_in, info.normal, info.dist, info.v_out)) {
+        info.primitiveId = i;
+        return info;
+      }
+    }
+  }
+  info.primitiveId = -1;
+  return info;
+}
+
+// Simulation::isSelfCollision Sim.cpp:194-220 (note tMid's factor 2, kept as in the reference).
+bool Sim::isSelfCollision(int a, int b, const V3 &xa, const V3 &xb, const V3 &va, const V3 &vb, SelfContact &info) const {
+  double thresh = radii[a] + radii[b];
+  V3 posDiff = xa - xb, v0 = posDiff, v = va - vb;
+  V3 p0 = v0, p1 = v0 + v * P.h;
+  double minDist = std::min(p0.norm(), p1.norm());
+  double tMid = -2 * (v.dot(v0)) / v.sqnorm();
+  if ((tMid >= 0) && (tMid <= P.h)) minDist = std::min(minDist, (v0 + v * tMid).norm());
+  if (minDist < thresh) {
+    info.particleId1 = std::min(a, b);
+    info.particleId2 = std::max(a, b);
+    info.normal = posDiff.normalized() * ((info.particleId1 == a) ? 1.0 : -1.0);
+    return true;
+  }
+  return false;
+}
+
+// Simulation::collisionDetection Sim.cpp:225-373.  Serial, hence deterministic (the reference's OpenMP
+// version appends under `omp critical`; only the order inside a layer differs, which does not change r).
+void Sim::collisionDetection(const std::vector<double> &x_n, const std::vector<double> &v, const V3 &particle0_pos,
+                             std::vector<PrimContact> &prim, std::vector<std::vector<SelfContact>> &layers) const {
+  prim.clear();
+  layers.clear();
+  std::vector<SelfContact> selfinfos;
+  if (P.contactEnabled) {
+    for (int i = 0; i < N; i++) {
+      PrimContact c = isInContactWithObstacle(seg3(x_n, i), seg3(v, i));
+      if (c.primitiveId != -1) { c.particleId = i; prim.push_back(c); }
+    }
+    if (P.selfcollisionEnabled) {
+      V3 maxDim = particle0_pos, minDim = particle0_pos;   // Sim.cpp:283 uses particles[0].pos (== s_n[0] here)
+      double maxRadii = radii[0];
+      for (int id = 0; id < N; id++) {
+        V3 pos = seg3(x_n, id);
+        maxRadii = std::max(maxRadii, radii[id]);
+        for (int i = 0; i < 3; i++) { maxDim[i] = std::max(maxDim[i], pos[i]); minDim[i] = std::min(minDim[i], pos[i]); }
+      }
+      V3 dim = maxDim - minDim;
+      int axis = 0;
+      for (int i = 1; i < 3; i++) if (dim[i] > dim[axis]) axis = i;
+      int cellNum = std::max(std::min(512, (int) (dim[axis] / (maxRadii * 2))), 1);
+      double cellDim = dim[axis] / cellNum;
+      int sweepCellRadius = (int) std::ceil(maxRadii * 2 / cellDim) + 2;
+      std::vector<std::set<int>> cells(cellNum);
+      for (int i = 0; i < N; i++) {
+        int cellIdx = std::min((int) ((x_n[3 * i + axis] - minDim[axis]) / cellDim), cellNum - 1);
+        cells[cellIdx].insert(i);
+      }
+      for (int c1 = 0; c1 < cellNum; c1++)
+        for (int c2 = c1; c2 < std::min(c1 + sweepCellRadius + 2, cellNum); c2++)
+          for (int p1 : cells[c1])
+            for (int p2 : cells[c2]) {
+              if ((c1 == c2) && (p1 < p2)) continue;
+              if (connected[p1].count(p2)) continue;
+              V3 xi = seg3(x_n, p1), xj = seg3(x_n, p2);
+              if ((xi - xj).norm() > 1.0) continue;
+              SelfContact info;
+              if (isSelfCollision(p1, p2, xi, xj, seg3(v, p1), seg3(v, p2), info)) selfinfos.push_back(info);
+            }
+      // deterministic order for reproducibility (the reference order depends on thread timing)
+      std::sort(selfinfos.begin(), selfinfos.end(), [](const SelfContact &a, const SelfContact &b) {
+        return std::make_pair(a.particleId1, a.particleId2) < std::make_pair(b.particleId1, b.particleId2);
+      });
+      layers = contactSorting(prim, selfinfos);
+    }
+  }
+}
+
+// Simulation::contactSorting Sim.cpp:422-624: greedy layering so that no vertex appears twice in a layer.
+std::vector<std::vector<SelfContact>> Sim::contactSorting(const std::vector<PrimContact> &primitiveCollisions,
+                                                          std::vector<SelfContact> &selfCollisions) {
+  std::map<int, std::set<int>> cmap;
+  std::map<std::pair<int, int>, int> table;
+  for (int i = 0; i < (int) selfCollisions.size(); i++) {
+    SelfContact &c = selfCollisions[i];
+    cmap[c.particleId1].insert(c.particleId2);
+    cmap[c.particleId2].insert(c.particleId1);
+    table[std::make_pair(c.particleId1, c.particleId2)] = i;
+    table[std::make_pair(c.particleId2, c.particleId1)] = i;
+  }
+  auto removeInfo = [&](int a, int b) {
+    table[std::make_pair(a, b)] = -1; table[std::make_pair(b, a)] = -1;
+    cmap[b].erase(a); cmap[a].erase(b);
+  };
+  std::vector<int> layerNumbers(selfCollisions.size(), -1);
+  int processed = 0, maxLayerIdx = 0;
+  std::set<int> frontier, newFrontier, involved;
+  for (const PrimContact &info : primitiveCollisions) {
+    if (!cmap[info.particleId].empty()) frontier.insert(info.particleId);
+    involved.insert(info.particleId);
+  }
+  for (auto it = cmap.begin(); it != cmap.end(); it++) {
+    int pid = it->first;
+    if (cmap[pid].size() != 1) continue;
+    int other = *(it->second.begin());
+    if (cmap[other].size() != 1) continue;
+    if (frontier.count(pid)) continue;
+    if (frontier.count(other)) continue;
+    int infoIdx = table[std::make_pair(pid, other)];
+    removeInfo(pid, other);
+    processed++;
+    layerNumbers[infoIdx] = 0;
+    involved.insert(pid); involved.insert(other);
+  }
+  int currentLayer = 1;
+  while (processed != (int) selfCollisions.size()) {
+    while (!frontier.empty()) {
+      newFrontier.clear();
+      involved.clear();
+      maxLayerIdx = std::max(currentLayer, maxLayerIdx);
+      for (int pid : frontier) {
+        if (cmap[pid].empty()) continue;
+        if (involved.count(pid)) continue;
+        for (int other : cmap[pid]) {
+          if (involved.count(other)) continue;
+          int infoIdx = table[std::make_pair(pid, other)];
+          removeInfo(pid, other);
+          processed++;
+          involved.insert(pid); involved.insert(other);
+          layerNumbers[infoIdx] = currentLayer;
+          if (!cmap[other].empty()) newFrontier.insert(other);
+          break;
+        }
+      }
+      currentLayer++;
+      frontier = newFrontier;
+    }
+    if (processed != (int) selfCollisions.size()) {
+      for (auto it = cmap.begin(); it != cmap.end();) { if (it->second.empty()) it = cmap.erase(it); else ++it; }
+      for (auto it = cmap.begin(); it != cmap.end(); it++)
+        if (it->second.size() == 1) { frontier.insert(it->first); break; }
+      if (frontier.empty() && !cmap.empty()) frontier.insert(cmap.begin()->first);
+      if (frontier.empty()) { std::fprintf(stderr, "oracle: contactSorting stuck\n"); std::abort(); }
+    }
+  }
+  std::vector<std::vector<SelfContact>> layers(maxLayerIdx + 1);
+  for (int i = 0; i < (int) selfCollisions.size(); i++) {
+    selfCollisions[i].layerId = layerNumbers[i];
+    layers[layerNumbers[i]].push_back(selfCollisions[i]);
+  }
+  return layers;
+}
+
+// Simulation::calcualteDryFrictionForce Sim.cpp:829-862.
+V3 Sim::dryFrictionForce(const V3 &n, const V3 &f_i, double mu, int &type) {
+  V3 r_i;
+  double sd = f_i.dot(n);
+  V3 f_N = n * sd, f_T = f_i - f_N;
+  double dT = f_T.norm();
+  if (sd >= 0.0) type = TAKE_OFF;
+  else {
+    r_i += -f_N;
+    if (dT <= mu * std::fabs(sd)) { r_i += -f_T; type = STICK; }
+    else { r_i += f_T.normalized() * (-mu * std::fabs(sd)); type = SLIDE; }
+  }
+  return r_i;
+}
+
+// Simulation::calculatedri_dmu Sim.cpp:865-879.
+V3 Sim::dri_dmu(const V3 &n, const V3 &f_i, double mu) {
+  V3 out;
+  double sd = f_i.dot(n);
+  V3 f_N = n * sd, f_T = f_i - f_N;
+  if (sd < 0.0 && f_T.norm() > mu * std::fabs(sd)) out += f_T.normalized() * (-std::fabs(sd));
+  return out;
+}
+
+// Simulation::calculatedri_dfi Sim.cpp:881-919.
+M3 Sim::dri_dfi(const V3 &n, const V3 &f_i, double mu) {
+  Mat I3 = Mat::identity(3), J(3, 3);
+  double sd = f_i.dot(n);
+  V3 f_N = n * sd, f_T = f_i - f_N;
+  double dT = f_T.norm();
+  Mat dfN = outer(n, n), dfT = I3 - dfN;
+  if (sd >= 0.0) {
+  } else {
+    J = J + dfN * (-1.0);
+    if (dT <= mu * std::fabs(sd)) J = J + dfT * (-1.0);
+    else {
+      V3 a = f_T.normalized();
+      double b = sd;
+      Mat da_dfT = (I3 - outer(a, a)) * (1.0 / f_T.norm());
+      Mat da_df = da_dfT * dfT;
+      J = J + (da_df * b + outer(a, n)) * mu;
+    }
+  }
+  M3 out;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[3 * i + j] = J(i, j);
+  return out;
+}
+
+// Simulation::calculateDryFrictionVector Sim.cpp:627-682.
+void Sim::dryFrictionVector(const std::vector<double> &f, std::vector<PrimContact> &prim,
+                            std::vector<std::vector<SelfContact>> &layers, std::vector<double> &r) const {
+  r.assign(3 * (size_t) N, 0.0);
+  if (!P.contactEnabled) return;
+  for (PrimContact &info : prim) {
+    if (info.primitiveId == -1) continue;
+    int p = info.particleId;
+    V3 d = seg3(f, p) - info.v_out * mass[p];
+    info.d = d;
+    V3 r_i = dryFrictionForce(info.normal, d, prims[info.primitiveId].mu, info.type);
+    addseg3(r, p, r_i);
+    info.r = r_i;
+  }
+  if (P.selfcollisionEnabled) {
+    for (auto &layer : layers)
+      for (SelfContact &info : layer) {
+        int A = info.particleId1, B = info.particleId2;
+        V3 fA = seg3(f, A) + seg3(r, A), fB = seg3(f, B) + seg3(r, B);
+        double mA = mass[A], mB = mass[B];
+        V3 d = fA / mA - fB / mB;
+        info.d = d;
+        double k = (mA * mB) / (mA + mB);
+        V3 r_i = dryFrictionForce(info.normal, d, 0.1, info.type) * k;
+        info.r = r_i;
+        addseg3(r, A, r_i);
+        addseg3(r, B, -r_i);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward step
+// ------------------------------------------------------------------------------------------------
+
+// Simulation::fillForces Sim.cpp:55-116 (gravity + uniform wind; fall-off / per-step / force-field variants omitted).
+double Sim::fillForces(std::vector<double> &f_ext, double t_now) const {
+  f_ext.assign(3 * (size_t) N, 0.0);
+  double windFactor = 1.0;
+  switch (P.windConfig) {
+    case 2: windFactor = (std::sin(P.windFrequency * t_now + P.windPhase) + 1.0) / 2.0; break;
+    case 0: windFactor = 0.0; break;
+    default: windFactor = 1.0; break;
+  }
+  for (int i = 0; i < N; i++) {
+    V3 f_i;
+    if (P.gravityEnabled) f_i += P.gravity * mass[i];
+    if (P.windEnabled) f_i += P.wind * (P.windNorm * windFactor);
+    addseg3(f_ext, i, f_i);
+  }
+  return windFactor;
+}
+
+// Simulation::step Sim.cpp:1043-1428 (VELOCITY_BASED branch).  Returns the index of the new record.
+int Sim::step(const double *x_n_in, const double *v_n_in, const double *x_fixed_in, double t_prev, int frozenContactsFrom) {
+#ifdef _OPENMP
+  omp_set_num_threads(P.threads);
+#endif
+  const double h = P.h;
+  const size_t n3 = 3 * (size_t) N;
+  std::vector<double> x_n(x_n_in, x_n_in + n3), v_n(v_n_in, v_n_in + n3);
+  Record rec;
+  rec.t = t_prev + h;
+  std::vector<double> f_ext;
+  rec.windFactor = fillForces(f_ext, rec.t);
+  std::vector<double> s_n(n3);
+  for (int i = 0; i < N; i++)
+    for (int d = 0; d < 3; d++)
+      s_n[3 * i + d] = x_n[3 * i + d] + h * v_n[3 * i + d] + h * h * f_ext[3 * i + d] / mass[i];
+  rec.x_prev = x_n; rec.v_prev = v_n; rec.s_n = s_n;
+  rec.x_fixed.assign(x_fixed_in, x_fixed_in + 3 * att.size());
+
+  // initial guess (Sim.cpp:1154-1160)
+  std::vector<double> x_now = s_n, v_now(n3);
+  for (size_t k = 0; k < n3; k++) v_now[k] = (s_n[k] - x_n[k]) / h;
+
+  double min_xdiff = 0;
+  for (size_t k = 0; k < n3; k++) min_xdiff += (s_n[k] - x_n[k]) * (s_n[k] - x_n[k]);
+  min_xdiff = std::sqrt(min_xdiff) * (1.0 / N);
+  std::vector<double> M_times_sn(n3), P_times_xn;
+  for (int i = 0; i < N; i++) for (int d = 0; d < 3; d++) M_times_sn[3 * i + d] = mass[i] * s_n[3 * i + d];
+  mulS(Pval, x_n, P_times_xn);
+  std::vector<double> x_best = x_n, v_best = v_n;
+
+  int PD_TOTAL_ITER = P.pd_iter_cap >= 0 ? P.pd_iter_cap : (int) ((-std::log10(P.fwd_tol)) * 150);
+  const int T = (int) tris.size(), E = (int) bends.size(), Af = (int) att.size();
+  const double w_att = std::sqrt(P.k_att);
+  std::vector<double> proj(3 * rows.size());    // p as 3-vectors per scalar row
+  std::vector<double> b(n3), b_tilde(n3), f(n3), r(n3, 0.0), Cv, rhs(n3), v_new(n3), x_new(n3);
+  const V3 particle0_pos = seg3(s_n, 0);
+  x_new = x_n; v_new = v_n;
+
+  for (int iter = 0; iter < PD_TOTAL_ITER; iter++) {
+    // local step (Sim.cpp:1198-1206)
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < T; t++) {
+      double o[6];
+      triProject(tris[t], x_now.data(), o);
+      for (int k = 0; k < 6; k++) proj[6 * (size_t) t + k] = o[k] * tris[t].w;
+    }
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < E; e++) {
+      double o[3];
+      bendProject(bends[e], x_now.data(), o);
+      for (int k = 0; k < 3; k++) proj[6 * (size_t) T + 3 * (size_t) e + k] = o[k] * bends[e].w;
+    }
+    for (int a = 0; a < Af; a++)   // AttachmentSpring::project AttachmentSpring.cpp:25-29
+      for (int k = 0; k < 3; k++) proj[6 * (size_t) T + 3 * (size_t) E + 3 * a + k] = w_att * rec.x_fixed[3 * a + k];
+
+    if (P.calcSeparateAtp) {       // Sim.cpp:1212-1218
+      double sk[3] = {std::sqrt(P.k_stretch), std::sqrt(P.k_bend), std::sqrt(P.k_att)};
+      for (int ty = 0; ty < 3; ty++) rec.Atp_weightless[ty].assign(n3, 0.0);
+      for (size_t ri = 0; ri < rows.size(); ri++) {
+        const Row &rw = rows[ri];
+        if (sk[rw.type] <= 0) continue;
+        for (int a = 0; a < rw.nv; a++)
+          for (int d = 0; d < 3; d++)
+            rec.Atp_weightless[rw.type][3 * rw.v[a] + d] += (rw.c[a] / sk[rw.type]) * proj[3 * ri + d] / sk[rw.type];
+      }
+    }
+    // b = h^2 A^T p + M s_n (Sim.cpp:1222)
+    b = M_times_sn;
+    for (size_t ri = 0; ri < rows.size(); ri++) {
+      const Row &rw = rows[ri];
+      for (int a = 0; a < rw.nv; a++)
+        for (int d = 0; d < 3; d++) b[3 * rw.v[a] + d] += h * h * rw.c[a] * proj[3 * ri + d];
+    }
+    // b_tilde, f (Sim.cpp:1248-1249)
+    mulS(Cval, v_now, Cv);
+    for (size_t k = 0; k < n3; k++) { b_tilde[k] = (b[k] - P_times_xn[k]) / h; f[k] = b_tilde[k] - Cv[k]; }
+    if (P.contactEnabled) {
+      if (iter == 0) {
+        if (frozenContactsFrom >= 0) {   // test hook: reuse the contact set (normals included) of an earlier record
+          rec.prim = records[frozenContactsFrom].prim;
+          rec.layers = records[frozenContactsFrom].layers;
+        } else collisionDetection(x_n, v_now, particle0_pos, rec.prim, rec.layers);   // Sim.cpp:1254-1256
+      }
+      dryFrictionVector(f, rec.prim, rec.layers, r);
+    } else std::fill(r.begin(), r.end(), 0.0);
+    // global step (Sim.cpp:1267-1268)
+    for (size_t k = 0; k < n3; k++) rhs[k] = b_tilde[k] + r[k];
+    solveP(rhs, v_new);
+    for (size_t k = 0; k < n3; k++) x_new[k] = v_new[k] * h + x_n[k];
+    // convergence (Sim.cpp:1324-1373)
+    double x_diff = 0;
+    for (size_t k = 0; k < n3; k++) x_diff += (x_new[k] - x_now[k]) * (x_new[k] - x_now[k]);
+    x_diff = std::sqrt(x_diff) * (1.0 / N);
+    if (x_diff < min_xdiff) { min_xdiff = x_diff; x_best = x_new; v_best = v_new; }
+    bool converged = x_diff < P.fwd_tol;
+    x_now = x_new; v_now = v_new;   // particles updated (Sim.cpp:1310-1314)
+    if (converged) { rec.converged = true; rec.convergeIter = iter + 1; break; }
+    if (iter == PD_TOTAL_ITER - 1) {
+      rec.converged = false; rec.convergeIter = PD_TOTAL_ITER;
+      x_new = x_best; v_new = v_best;   // revertToLastConverging
+    }
+  }
+  rec.x = x_new; rec.v = v_new; rec.f = f; rec.r = r;
+  records.push_back(std::move(rec));
+  return (int) records.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward step
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+struct BlockRows {                       // sparse 3N x 3N matrix of 3x3 blocks
+  std::vector<std::map<int, M3>> rows;
+  explicit BlockRows(int n) : rows(n) {}
+  void add(int i, int j, const M3 &m, double s = 1.0) {
+    auto it = rows[i].find(j);
+    if (it == rows[i].end()) { M3 z; for (int k = 0; k < 9; k++) z[k] = s * m[k]; rows[i][j] = z; }
+    else for (int k = 0; k < 9; k++) it->second[k] += s * m[k];
+  }
+  void mul(const std::vector<double> &x, std::vector<double> &y) const {        // y = A x
+    y.assign(x.size(), 0.0);
+    for (size_t i = 0; i < rows.size(); i++)
+      for (auto &kv : rows[i]) {
+        const M3 &m = kv.second; int j = kv.first;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) y[3 * i + a] += m[3 * a + b] * x[3 * j + b];
+      }
+  }
+  void mulT(const std::vector<double> &x, std::vector<double> &y) const {       // y = A^T x
+    y.assign(x.size(), 0.0);
+    for (size_t i = 0; i < rows.size(); i++)
+      for (auto &kv : rows[i]) {
+        const M3 &m = kv.second; int j = kv.first;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) y[3 * j + b] += m[3 * a + b] * x[3 * i + a];
+      }
+  }
+};
+M3 mul33(const M3 &a, const M3 &b) {
+  M3 c; c.fill(0);
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) for (int j = 0; j < 3; j++) c[3 * i + j] += a[3 * i + k] * b[3 * k + j];
+  return c;
+}
+}  // namespace
+
+// Simulation::stepBackward Sim.cpp:1455-1780 (+ calculatedr_df Sim.cpp:686-768, calculatedr_dmu :770-804,
+// solveDirect :1431-1440).  The SparseLU fallback is replaced by GMRES on (P - dP^T) preconditioned with the
+// Cholesky factor of P, run to 1e-13 — same linear system, same solution.
+BackwardOut Sim::stepBackward(const Record &rec, const double *dL_dxnew_in, const double *dL_dvnew_in,
+                              const double *dL_dxinit, const double *dL_dvinit, bool isStart, bool forceDirect,
+                              int numMu) const {
+  const double h = P.h, t2 = h * h;
+  const size_t n3 = 3 * (size_t) N;
+  BackwardOut out;
+  std::vector<double> g(dL_dxnew_in, dL_dxnew_in + n3), dL_dvnew(dL_dvnew_in, dL_dvnew_in + n3);
+  if (P.gradientClipping) {     // Sim.cpp:1460-1466
+    double nrm = 0;
+    for (double v : g) nrm += v * v;
+    nrm = std::sqrt(nrm);
+    if (nrm > P.gradientClippingThreshold * N) for (double &v : g) v = v * P.gradientClippingThreshold * N / nrm;
+  }
+  // --- dr_df (Sim.cpp:686-768) ---
+  BlockRows dr_df(N);
+  if (P.contactEnabled) {
+    for (const PrimContact &info : rec.prim)
+      if (info.primitiveId != -1) dr_df.add(info.particleId, info.particleId, dri_dfi(info.normal, info.d, prims[info.primitiveId].mu));
+    if (P.selfcollisionEnabled)
+      for (const auto &layer : rec.layers) {
+        BlockRows last = dr_df;
+        for (const SelfContact &info : layer) {
+          int nA = info.particleId1, nB = info.particleId2;
+          double mA = mass[nA], mB = mass[nB], k = (mA * mB) / (mA + mB);
+          M3 dr_dd = dri_dfi(info.normal, info.d, 0.1);
+          M3 dA, dB;
+          for (int q = 0; q < 9; q++) { dA[q] = k * dr_dd[q] / mA; dB[q] = -k * dr_dd[q] / mB; }
+          dr_df.add(nA, nA, dA); dr_df.add(nA, nB, dB);
+          dr_df.add(nB, nA, dA, -1.0); dr_df.add(nB, nB, dB, -1.0);
+          for (auto &kv : last.rows[nA]) { M3 m = mul33(dA, kv.second); dr_df.add(nA, kv.first, m); dr_df.add(nB, kv.first, m, -1.0); }
+          for (auto &kv : last.rows[nB]) { M3 m = mul33(dB, kv.second); dr_df.add(nA, kv.first, m); dr_df.add(nB, kv.first, m, -1.0); }
+        }
+      }
+  }
+  // --- projection Jacobians at x_new (Sim.cpp:1540-1551) ---
+  const int T = (int) tris.size(), E = (int) bends.size();
+  std::vector<Mat> Jtri(T), Jbend(E);
+#pragma omp parallel for schedule(static)
+  for (int t = 0; t < T; t++) Jtri[t] = triProjectBackward(tris[t], rec.x.data()) * tris[t].w;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < E; e++) Jbend[e] = bendBackward(bends[e], rec.x.data());
+
+  // deltaU(u) = t2 * dproj^T * A * (dr_df^T u + u) - C^T (dr_df^T u)   (Sim.cpp:1573-1575)
+  auto applyDeltaPT = [&](const std::vector<double> &u, std::vector<double> &dU) {
+    std::vector<double> w, y(n3), Cw;
+    dr_df.mulT(u, w);
+    for (size_t k = 0; k < n3; k++) y[k] = w[k] + u[k];
+    dU.assign(n3, 0.0);
+    for (int t = 0; t < T; t++) {
+      double q[6];
+      for (int i = 0; i < 2; i++) {
+        const Row &rw = rows[2 * (size_t) t + i];
+        for (int d = 0; d < 3; d++) { double s = 0; for (int a = 0; a < 3; a++) s += rw.c[a] * y[3 * rw.v[a] + d]; q[3 * i + d] = s; }
+      }
+      const Mat &J = Jtri[t];
+      for (int a = 0; a < 3; a++) for (int d = 0; d < 3; d++) {
+        double s = 0; for (int k = 0; k < 6; k++) s += J(k, 3 * a + d) * q[k];
+        dU[3 * tris[t].v[a] + d] += t2 * s;
+      }
+    }
+    for (int e = 0; e < E; e++) {
+      const Row &rw = rows[2 * (size_t) T + e];
+      double q[3];
+      for (int d = 0; d < 3; d++) { double s = 0; for (int a = 0; a < 4; a++) s += rw.c[a] * y[3 * rw.v[a] + d]; q[d] = s; }
+      const Mat &J = Jbend[e];
+      for (int a = 0; a < 4; a++) for (int d = 0; d < 3; d++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += J(k, 3 * a + d) * q[k];
+        dU[3 * bends[e].v[a] + d] += t2 * s;
+      }
+    }
+    mulS(Cval, w, Cw);
+    for (size_t k = 0; k < n3; k++) dU[k] -= Cw[k];
+  };
+
+  std::vector<double> u(n3, 0.0), u_prev(n3, 0.0), dU, rhs(n3);
+  auto solveDirect = [&]() {   // (P - dP^T) u = g  via right-preconditioned restarted GMRES
+    const int m = 80;
+    std::vector<double> x(n3, 0.0);
+    auto applyOp = [&](const std::vector<double> &z, std::vector<double> &Az) {   // Az = (P - dP^T) P^{-1} z
+      std::vector<double> pz, Ppz, d;
+      solveP(z, pz); mulS(Pval, pz, Ppz); applyDeltaPT(pz, d);
+      Az.resize(n3);
+      for (size_t k = 0; k < n3; k++) Az[k] = Ppz[k] - d[k];
+    };
+    double bnorm = 0; for (double v : g) bnorm += v * v; bnorm = std::sqrt(bnorm);
+    if (bnorm == 0) { u.assign(n3, 0.0); return; }
+    for (int restart = 0; restart < 40; restart++) {
+      std::vector<double> Ax, r0(n3);
+      applyOp(x, Ax);
+      double beta = 0;
+      for (size_t k = 0; k < n3; k++) { r0[k] = g[k] - Ax[k]; beta += r0[k] * r0[k]; }
+      beta = std::sqrt(beta);
+      if (beta <= 1e-13 * bnorm) break;
+      std::vector<std::vector<double>> V(1, r0);
+      for (double &v : V[0]) v /= beta;
+      std::vector<std::vector<double>> H(m + 1, std::vector<double>(m, 0.0));
+      std::vector<double> cs(m), sn(m), gvec(m + 1, 0.0);
+      gvec[0] = beta;
+      int kdone = 0;
+      for (int k = 0; k < m; k++) {
+        std::vector<double> wv;
+        applyOp(V[k], wv);
+        for (int j = 0; j <= k; j++) {
+          double hj = 0; for (size_t q = 0; q < n3; q++) hj += wv[q] * V[j][q];
+          H[j][k] = hj;
+          for (size_t q = 0; q < n3; q++) wv[q] -= hj * V[j][q];
+        }
+        double hn = 0; for (double v : wv) hn += v * v; hn = std::sqrt(hn);
+        H[k + 1][k] = hn;
+        for (int j = 0; j < k; j++) { double tmp = cs[j] * H[j][k] + sn[j] * H[j + 1][k]; H[j + 1][k] = -sn[j] * H[j][k] + cs[j] * H[j + 1][k]; H[j][k] = tmp; }
+        double den = std::sqrt(H[k][k] * H[k][k] + hn * hn);
+        cs[k] = H[k][k] / den; sn[k] = hn / den;
+        H[k][k] = den; H[k + 1][k] = 0;
+        gvec[k + 1] = -sn[k] * gvec[k]; gvec[k] = cs[k] * gvec[k];
+        kdone = k + 1;
+        if (std::fabs(gvec[k + 1]) <= 1e-14 * bnorm || hn == 0) break;
+        for (double &v : wv) v /= hn;
+        V.push_back(wv);
+      }
+      std::vector<double> yv(kdone);
+      for (int i = kdone - 1; i >= 0; i--) { double s = gvec[i]; for (int j = i + 1; j < kdone; j++) s -= H[i][j] * yv[j]; yv[i] = s / H[i][i]; }
+      for (int j = 0; j < kdone; j++) for (size_t q = 0; q < n3; q++) x[q] += yv[j] * V[j][q];
+    }
+    solveP(x, u);
+  };
+
+  if (forceDirect) { solveDirect(); out.usedDirect = true; out.converged = true; }
+  else {
+    const int MAX_ITER_NUM = 400;       // Sim.cpp:1562
+    for (int it = 0; it < MAX_ITER_NUM; it++) {
+      applyDeltaPT(u_prev, dU);
+      for (size_t k = 0; k < n3; k++) rhs[k] = g[k] + dU[k];
+      solveP(rhs, u);
+      double diff = 0;
+      for (size_t k = 0; k < n3; k++) diff += (u[k] - u_prev[k]) * (u[k] - u_prev[k]);
+      bool converged = std::fabs(std::sqrt(diff) / (N * 1.0)) < P.bwd_tol;
+      bool isLast = (it + 1 == MAX_ITER_NUM);
+      if (converged || isLast) {
+        out.backwardIters = it + 1;
+        out.converged = converged;
+        if (!converged) { solveDirect(); out.usedDirect = true; }
+        break;
+      }
+      u_prev = u;
+    }
+  }
+  // --- state gradients (Sim.cpp:1534, 1608-1616) ---
+  out.dL_dx.assign(dL_dxinit, dL_dxinit + n3);
+  out.dL_dv.assign(dL_dvinit, dL_dvinit + n3);
+  for (size_t k = 0; k < n3; k++) out.dL_dx[k] += dL_dvnew[k] * (-1.0 / h);
+  std::vector<double> w;
+  dr_df.mulT(u, w);                                  // (I + dr_df)^T u = u + w
+  for (int i = 0; i < N; i++)
+    for (int d = 0; d < 3; d++) {
+      out.dL_dx[3 * i + d] += mass[i] * u[3 * i + d];
+      out.dL_dv[3 * i + d] += h * mass[i] * (u[3 * i + d] + w[3 * i + d]);
+    }
+  if (!isStart) for (size_t k = 0; k < n3; k++) out.dL_dx[k] += out.dL_dv[k] * 1.0 / h;
+  // --- dL/dmu (Sim.cpp:1622-1632, 770-804) ---
+  out.dL_dmu.assign(numMu, 0.0);
+  for (const PrimContact &info : rec.prim)
+    if (info.primitiveId != -1 && info.primitiveId < numMu) {
+      V3 dm = dri_dmu(info.normal, info.d, prims[info.primitiveId].mu);
+      out.dL_dmu[info.primitiveId] += dm.dot(seg3(u, info.particleId)) * h;
+    }
+  // --- dL/dx_fixed (Sim.cpp:1642-1650; A_t_dp_dxfixed Sim.cpp:3035-3048) ---
+  out.dL_dxfixed.assign(3 * att.size(), 0.0);
+  for (size_t a = 0; a < att.size(); a++)
+    for (int d = 0; d < 3; d++) out.dL_dxfixed[3 * a + d] = t2 * P.k_att * (u[3 * att[a] + d] + w[3 * att[a] + d]);
+  // --- dL/dk per type (Sim.cpp:1681-1699); needs Record::Atp_weightless (calcSeparateAtp) ---
+  if (!rec.Atp_weightless[0].empty()) {
+    for (int ty = 0; ty < 3; ty++) {
+      std::vector<double> Lx, df_dk(n3), dr;
+      mulS(Lval[ty], rec.x, Lx);
+      for (size_t k = 0; k < n3; k++) df_dk[k] = h * rec.Atp_weightless[ty][k] - h * Lx[k];
+      dr_df.mul(df_dk, dr);
+      double s = 0;
+      for (size_t k = 0; k < n3; k++) s += u[k] * (t2 * rec.Atp_weightless[ty][k] + h * dr[k] - t2 * Lx[k]);
+      out.dL_dk[ty] = s;
+    }
+  }
+  // --- dL/ddensity (Sim.cpp:1672-1679), adddr_dd = false ---
+  {
+    std::vector<double> df_dd(n3), dr, rhsd(n3);
+    V3 gn = P.gravityEnabled ? P.gravity : V3(0, 0, 0);
+    for (int i = 0; i < N; i++)
+      for (int d = 0; d < 3; d++) df_dd[3 * i + d] = area[i] * (rec.v_prev[3 * i + d] + h * gn[d]);
+    dr_df.mul(df_dd, dr);
+    double s = 0;
+    for (int i = 0; i < N; i++)
+      for (int d = 0; d < 3; d++) {
+        double dMy = area[i] * (rec.x_prev[3 * i + d] + h * rec.v_prev[3 * i + d] + t2 * gn[d]);
+        s += u[3 * i + d] * (dMy + h * dr[3 * i + d] - area[i] * rec.x[3 * i + d]);
+      }
+    out.dL_ddensity = s;
+  }
+  // --- dL/dwind (Sim.cpp:1730-1764), WIND_SIN without fall-off ---
+  if (P.windEnabled) {
+    V3 tot;
+    for (int i = 0; i < N; i++) tot += (seg3(u, i) + seg3(w, i)) * t2;
+    V3 windForce = P.wind * P.windNorm;
+    double c = std::cos(P.windFrequency * rec.t + P.windPhase);
+    for (int d = 0; d < 3; d++) out.dL_dwind[d] = tot[d] * rec.windFactor;
+    out.dL_dwind[3] = tot.dot(windForce) * c * 0.5 * rec.t;
+    out.dL_dwind[4] = tot.dot(windForce) * c * 0.5;
+  }
+  return out;
+}
+
+}  // namespace orc

@@ -1,0 +1,157 @@
+"""Oracle self-checks: known-answer tests and finite-difference checks of every local Jacobian.
+
+The reference ships no tests; these are the closed-form KATs of SURVEY.md §8(c)(4):
+rest pose => zero constraint force, rigid-motion equivariance, FD of d(project)/dx (Triangle.cpp:354-451,
+TriangleBending.cpp:154-172) and of calculatedri_dfi / calculatedri_dmu (Simulation.cpp:865-919).
+"""
+import numpy as np
+import pytest
+
+import meshes
+import orc
+
+
+@pytest.fixture(scope="module")
+def small():
+    V, F = meshes.grid_cloth(6, 5, 3.0, 2.5, "DOWN")
+    o = orc.Oracle(V, F, h=1 / 90, density=0.3, k_stretch=150.0, k_bend=0.05, attachments=[0, 5]).build()
+    return V, F, o
+
+
+def test_counts_and_mass(small):
+    V, F, o = small
+    assert o.N == 30 and o.T == 2 * 5 * 4
+    # interior edges of a (nx-1)x(ny-1) quad grid split into triangles: 3*qx*qy - qx - qy
+    assert o.E == 3 * 5 * 4 - 5 - 4
+    m, a, r = o.vertex_data()
+    np.testing.assert_allclose(a.sum(), 3.0 * 2.5, rtol=1e-12)
+    np.testing.assert_allclose(m, 0.3 * a, rtol=1e-14)
+    assert (r > 0).all()
+
+
+def test_P_is_spd_and_solve(small):
+    V, F, o = small
+    import scipy.sparse as sp
+    ptr, col, val = o.P_csr()
+    P = sp.csr_matrix((val, col, ptr), shape=(o.N, o.N))
+    assert abs(P - P.T).max() < 1e-12
+    w = np.linalg.eigvalsh(P.toarray())
+    assert w.min() > 0
+    rng = np.random.default_rng(0)
+    rhs = rng.standard_normal(3 * o.N)
+    sol = o.solveP(rhs)
+    res = sp.kron(P, sp.identity(3)) @ sol - rhs
+    assert np.abs(res).max() < 1e-10
+
+
+def test_rest_pose_is_force_free(small):
+    V, F, o = small
+    x = V.reshape(-1).copy()
+    # at rest F = [P, P_perp] is already an isometry: project(x) = w * vec(F), so A^T (p - A x) = 0
+    for t in range(o.T):
+        p = o.tri_project(t, x)
+        J = o.tri_project_backward(t, x)
+        assert np.isfinite(p).all() and np.isfinite(J).all()
+        # |column| of an isometry is 1  ->  |p[:3]| = |p[3:]| = w
+        np.testing.assert_allclose(np.linalg.norm(p[:3]), np.linalg.norm(p[3:]), rtol=1e-12)
+        assert abs(p[:3] @ p[3:]) < 1e-10 * (p[:3] @ p[:3])
+    idx, wv, n = o.bends()
+    for e in range(o.E):
+        p = o.bend_project(e, x)
+        ee = (wv[e][:, None] * V[idx[e]]).sum(axis=0)
+        # flat rest state: weighted sum has norm n (both ~0 for a planar grid)
+        np.testing.assert_allclose(np.linalg.norm(ee), n[e], atol=1e-12)
+
+
+def test_rigid_motion_equivariance(small):
+    V, F, o = small
+    rng = np.random.default_rng(1)
+    x = (V + 0.05 * rng.standard_normal(V.shape))
+    Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    xr = x @ Q.T + np.array([0.3, -2.0, 1.0])
+    for t in range(0, o.T, 3):
+        p = o.tri_project(t, x.reshape(-1)).reshape(2, 3)
+        pr = o.tri_project(t, xr.reshape(-1)).reshape(2, 3)
+        np.testing.assert_allclose(pr, p @ Q.T, atol=1e-10)
+    for e in range(0, o.E, 3):
+        p = o.bend_project(e, x.reshape(-1))
+        pr = o.bend_project(e, xr.reshape(-1))
+        np.testing.assert_allclose(pr, Q @ p, atol=1e-10)
+
+
+def _fd_jac(fun, x, idx, eps=1e-6):
+    cols = []
+    for k in idx:
+        xp = x.copy(); xp[k] += eps
+        xm = x.copy(); xm[k] -= eps
+        cols.append((fun(xp) - fun(xm)) / (2 * eps))
+    return np.stack(cols, axis=1)
+
+
+def test_triangle_jacobian_fd(small):
+    V, F, o = small
+    rng = np.random.default_rng(2)
+    x = (V + 0.08 * rng.standard_normal(V.shape)).reshape(-1)
+    for t in [0, 7, 19, 33]:
+        vid = F[t]
+        cols = [3 * v + d for v in vid for d in range(3)]
+        Jfd = _fd_jac(lambda y: o.tri_project(t, y), x, cols)
+        J = o.tri_project_backward(t, x)
+        np.testing.assert_allclose(J, Jfd, atol=2e-6 * np.abs(Jfd).max())
+
+
+def test_bending_jacobian_fd():
+    # a non-flat rest shape so that the rest norm n is > 1e-6 and the constraint is active
+    V, F = meshes.grid_cloth(5, 5, 2.0, 2.0, "DOWN")
+    V = V.copy()
+    V[:, 1] += 0.15 * np.sin(2.0 * V[:, 0]) * np.cos(1.5 * V[:, 2])
+    o = orc.Oracle(V, F, k_bend=0.7).build()
+    idx, wv, n = o.bends()
+    assert (n > 1e-6).any()
+    rng = np.random.default_rng(3)
+    x = (V + 0.05 * rng.standard_normal(V.shape)).reshape(-1)
+    checked = 0
+    for e in range(o.E):
+        if n[e] <= 1e-6:
+            continue
+        cols = [3 * v + d for v in idx[e] for d in range(3)]
+        Jfd = _fd_jac(lambda y: o.bend_project(e, y), x, cols)
+        J = o.bend_backward(e, x)
+        np.testing.assert_allclose(J, Jfd, atol=2e-6 * max(np.abs(Jfd).max(), 1e-3))
+        checked += 1
+    assert checked > 5
+
+
+@pytest.mark.parametrize("case", ["takeoff", "stick", "slide"])
+def test_friction_branches_and_jacobian(case):
+    n = np.array([0.2, 0.9, -0.3]); n /= np.linalg.norm(n)
+    t1 = np.cross(n, [1.0, 0, 0]); t1 /= np.linalg.norm(t1)
+    mu = 0.4
+    if case == "takeoff":
+        f = 2.0 * n + 0.5 * t1
+    elif case == "stick":
+        f = -2.0 * n + 0.5 * t1          # |f_T| = 0.5 <= mu*2 = 0.8
+    else:
+        f = -2.0 * n + 1.5 * t1          # |f_T| = 1.5 > 0.8
+    r, ty, J, dmu = orc.friction(n, f, mu)
+    if case == "takeoff":
+        assert ty == 0 and np.allclose(r, 0) and np.allclose(J, 0)
+    elif case == "stick":
+        assert ty == 1
+        np.testing.assert_allclose(r, -f, atol=1e-14)
+        np.testing.assert_allclose(J, -np.eye(3), atol=1e-14)
+        assert np.allclose(dmu, 0)
+    else:
+        assert ty == 2
+        np.testing.assert_allclose(r, 2.0 * n - mu * 2.0 * t1, atol=1e-14)
+    eps = 1e-6
+    Jfd = np.zeros((3, 3))
+    for k in range(3):
+        fp = f.copy(); fp[k] += eps
+        fm = f.copy(); fm[k] -= eps
+        Jfd[:, k] = (orc.friction(n, fp, mu)[0] - orc.friction(n, fm, mu)[0]) / (2 * eps)
+    np.testing.assert_allclose(J, Jfd, atol=1e-8)
+    dfd = (orc.friction(n, f, mu + eps)[0] - orc.friction(n, f, mu - eps)[0]) / (2 * eps)
+    np.testing.assert_allclose(dmu, dfd, atol=1e-8)
