@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — forward+backward steps/s of the MI355X DiffCloth stepper on BASELINE.json's headline workload.
+
+Workload: synthetic 100x100 grid cloth (N = 10 000 vertices, T = 19 602 triangles,
+E = 29 205 bending flaps) of the reference's `sphereFabric` (k_stretch 150, k_bend 1e-5, density 0.3, 4.5 x 4.5)
+dropped on the `rotatingSphereScene` sphere (r = 2, Signorini–Coulomb contact), h = 1/180, 256 independent
+rollouts per GPU (per-rollout start offset and friction coefficient, seed = global rollout id).
+One "step" = one forward time step (Simulation::step) + one backward step (Simulation::stepBackward) of all
+rollouts of the job; `value` = rollout-steps per second over the whole job = B_total * K / t.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+One process per GPU; rollouts are independent, so ranks share nothing on the data path ("weak" scaling: 256
+rollouts per GPU). The only collective is the barrier / MAX-reduce of the timing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def grid_cloth(nx, dim):
+    """Reference grid builder (Simulation.cpp:2611-2757), orientation DOWN — same numbering as tests/meshes.py."""
+    import meshes
+    return meshes.grid_cloth(nx, nx, dim, dim, "DOWN")
+
+
+def make_engine(device, args, V, F, center):
+    from diffcloth_amd import capi
+    e = capi.Engine(device)
+    e.set_mesh(V, F)
+    e.set_params(time_step=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_tol=args.fwd_tol,
+                 backward_tol=args.bwd_tol, cg_rel_tol=args.cg_tol, cg_max_iter=args.cg_max,
+                 gradient_clipping=1, selfcollision_enabled=0)
+    e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=center, radius=2.0, mu=0.9)])
+    e.build()
+    return e
+
+
+def rollout_inputs(V, ids):
+    """Per-rollout start state and friction coefficient, seeded by the global rollout id."""
+    X = np.empty((len(ids), V.size)); MU = np.empty((len(ids), 1))
+    for k, gid in enumerate(ids):
+        rng = np.random.default_rng(1000 + int(gid))
+        shift = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.09, -0.02), rng.uniform(-0.5, 0.5)])
+        X[k] = (V + shift).astype(np.float32).reshape(-1)
+        MU[k, 0] = rng.uniform(0.1, 0.9)
+    return X, MU
+
+
+def cpu_baseline(args, V, F, center, x0, mu, steps):
+    """Reference algorithm (fp64 oracle port, OpenMP at the reference's sites) on the host cores, one rollout."""
+    import orc
+    threads = os.cpu_count() or 1
+    o = orc.Oracle(V, F, h=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, fwd_tol=args.fwd_tol,
+                   bwd_tol=args.bwd_tol, selfcollision=False, gradient_clipping=True, threads=threads)
+    o.add_sphere(center, 2.0, float(mu))
+    o.build()
+    x = x0.copy(); v = np.zeros_like(x)
+    t0 = time.perf_counter()
+    recs = []
+    for s in range(steps):
+        out = o.step(x, v)
+        recs.append(out)
+        x, v = out["x"], out["v"]
+    gx = x - V.reshape(-1); gv = np.zeros_like(gx)
+    for s in reversed(range(steps)):
+        b = o.step_backward(recs[s]["id"], gx, gv, is_start=(s == 0), direct=False)
+        gx, gv = b["dL_dx"], b["dL_dv"]
+    dt = time.perf_counter() - t0
+    return dict(value=steps / dt, unit="rollout-steps/s", cores=threads, kind="port",
+                sample=f"1 rollout x {steps} fwd+bwd steps of the same workload, fp64 oracle (oracle/), "
+                       f"mean PD iters {np.mean([r['iters'] for r in recs]):.0f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="rollouts per GPU")
+    ap.add_argument("--grid", type=int, default=100, help="grid cloth resolution (grid x grid vertices)")
+    ap.add_argument("--h", type=float, default=1.0 / 180)
+    ap.add_argument("--fwd-tol", dest="fwd_tol", type=float, default=1e-8)   # hatController.py:83 / tshirtScene
+    ap.add_argument("--bwd-tol", dest="bwd_tol", type=float, default=5e-4)   # every scene table
+    ap.add_argument("--cg-tol", dest="cg_tol", type=float, default=1e-4)
+    ap.add_argument("--cg-max", dest="cg_max", type=int, default=500)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="steps of the CPU baseline sample (0 disables)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the stepper has no CPU path")
+
+    V, F = grid_cloth(args.grid, 4.5)
+    V = V.astype(np.float32).astype(np.float64)
+    import meshes
+    center = meshes.sphere_scene_center(V, 2.0).astype(np.float32).astype(np.float64)
+    B, K, W = args.batch, args.steps, args.warmup
+    e = make_engine(local_rank, args, V, F, center)
+    e.alloc_batch(B, W + K)
+    ids = np.arange(rank * B, (rank + 1) * B)
+    X0, MU = rollout_inputs(V, ids)
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: W untimed forward steps (contact onset) + one untimed backward step
+    e.rollout_forward(0, W)
+    e.seed_gradient(W, None, 1.0)
+    if W > 0:
+        e.rollout_backward(W, 1)
+    e.sync()
+    e.kernel_times(reset=True)
+
+    barrier()
+    t0 = time.perf_counter()
+    e.rollout_forward(W, K)                 # K forward steps, tape on the device
+    e.seed_gradient(W + K, None, 1.0)       # dL/dx_K of the match-shape loss, on the device
+    e.rollout_backward(W + K, K)            # K backward steps
+    e.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kt = e.kernel_times()
+    # iteration statistics of the timed steps (needed for the algorithmic-byte count)
+    pd = cg_f = adj = cg_b = 0.0
+    conv = 0
+    for s in range(W + 1, W + K + 1):
+        fs, bs = e.get_stats(s)
+        pd += fs["pd_iters"].sum(); cg_f += fs["cg_iters"].sum(); conv += int((fs["converged"] > 0).sum())
+        adj += bs["adjoint_iters"].sum(); cg_b += bs["cg_iters"].sum()
+    N = e.N
+    # bytes_fwd_step = (108 * I_pd + 132 * I_cg) * N per rollout (fp32)
+    bytes_fwd = (108.0 * pd + 132.0 * cg_f) * N
+    bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b) * N
+    fwd_s = kt["fwd_ms"] * 1e-3
+    achieved = bytes_fwd / max(fwd_s, 1e-12) / 1e9
+    dx, dv, dmu = e.get_gradient()
+    finite = bool(np.isfinite(dx).all() and np.isfinite(dv).all())
+
+    if rank == 0:
+        out = {
+            "metric": "fwd+bwd steps/sec (node), 10k-vtx cloth+contact, batch=256",
+            "value": world * B * K / dt,
+            "unit": "rollout-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4 grid {args.grid}x{args.grid} cloth (N={N}, T={e.T}, E={e.E}) on sphere r=2, "
+                                   f"h=1/{round(1 / args.h)}, primitive Signorini-Coulomb contact",
+                       "rollouts_per_gpu": B, "rollouts_total": world * B, "fwd_tol": args.fwd_tol,
+                       "bwd_tol": args.bwd_tol, "cg_rel_tol": args.cg_tol,
+                       "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
+                       "mean_adjoint_iters_per_step": adj / (B * K), "converged_fraction": conv / (B * K),
+                       "batch_steps_per_s": world * K / dt, "gradients_finite": finite,
+                       "parallelism": f"rollout-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_pd_step", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_fwd / K, "avg_launch_ms": kt["fwd_ms"] / max(kt["fwd_launches"], 1),
+                         "bwd_kernel": "k_adjoint_step", "bwd_avg_launch_ms": kt["bwd_ms"] / max(kt["bwd_launches"], 1),
+                         "bwd_achieved": bytes_bwd / max(kt["bwd_ms"] * 1e-3, 1e-12) / 1e9},
+        }
+        if world == 1 and args.cpu_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(args, V, F, center, X0[0], MU[0, 0], args.cpu_steps)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

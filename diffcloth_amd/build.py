@@ -1,0 +1,46 @@
+"""Builds the native libraries of diffcloth_amd in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+  libdiffcloth_hip.so   C-ABI engine (include/diffcloth_hip.h): host system builder + HIP kernels
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "diffcloth_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "diffcloth_amd", "lib")
+LIB = os.path.join(LIBDIR, "libdiffcloth_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+ENGINE_SOURCES = ["dc_kernels.hip", "dc_engine.hip", "dc_system.cpp"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_engine(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in ENGINE_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("dc_device.h", "dc_system.h")] + [os.path.join(ROOT, "include", "diffcloth_hip.h")]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
+           "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-o", LIB]
+    for s in srcs:
+        if s.endswith(".cpp"):
+            cmd += ["-x", "hip", s]
+        else:
+            cmd += [s]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_engine(force="--force" in sys.argv, verbose=True))

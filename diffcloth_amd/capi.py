@@ -1,0 +1,279 @@
+"""ctypes binding of libdiffcloth_hip.so (include/diffcloth_hip.h).
+
+This is the thinnest possible Python view of the C-ABI: numpy float64 arrays in the reference's layout
+(xyz-interleaved, length 3N per rollout) go straight to the `dc_*` entry points. There is no CPU fallback:
+if the library is missing, or no HIP device is present, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiffcloth_hip.so")
+
+DC_PRIM_SPHERE, DC_PRIM_CAPSULE = 0, 1
+
+
+class DcError(RuntimeError):
+    pass
+
+
+class dc_primitive(C.Structure):
+    _fields_ = [("kind", C.c_int), ("group", C.c_int), ("center", C.c_double * 3), ("top_offset", C.c_double * 3),
+                ("radius", C.c_double), ("length", C.c_double), ("mu", C.c_double), ("rotates", C.c_int)]
+
+
+class dc_params(C.Structure):
+    _fields_ = [("time_step", C.c_double), ("density", C.c_double), ("k_stretch", C.c_double), ("k_bend", C.c_double),
+                ("k_att", C.c_double), ("gravity", C.c_double * 3), ("forward_tol", C.c_double),
+                ("backward_tol", C.c_double), ("gravity_enabled", C.c_int), ("contact_enabled", C.c_int),
+                ("selfcollision_enabled", C.c_int), ("gradient_clipping", C.c_int),
+                ("gradient_clipping_threshold", C.c_double), ("pd_iter_cap", C.c_int), ("adjoint_iter_cap", C.c_int),
+                ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int)]
+
+
+class dc_step_stats(C.Structure):
+    _fields_ = [("converged", C.c_int), ("pd_iters", C.c_int), ("cg_iters", C.c_int), ("prim_contacts", C.c_int),
+                ("self_contacts", C.c_int), ("last_xdiff", C.c_float)]
+
+
+class dc_bwd_stats(C.Structure):
+    _fields_ = [("converged", C.c_int), ("adjoint_iters", C.c_int), ("cg_iters", C.c_int), ("clipped", C.c_int),
+                ("last_udiff", C.c_float)]
+
+
+EXPORTED_SYMBOLS = [
+    "dc_create", "dc_destroy", "dc_last_error", "dc_version", "dc_set_mesh", "dc_set_attachments", "dc_set_params",
+    "dc_set_primitives", "dc_build", "dc_default_params", "dc_get_counts", "dc_get_system_matrix",
+    "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force",
+    "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_step_backward", "dc_rollout_forward",
+    "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_stats", "dc_sync", "dc_timer_start",
+    "dc_timer_stop", "dc_kernel_times",
+]
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def load_library():
+    """Loads libdiffcloth_hip.so; raises if it has not been built (see diffcloth_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DcError(f"{LIB_PATH} not found: run `python -m diffcloth_amd.build` (hipcc, gfx950)")
+        lib = C.CDLL(LIB_PATH)
+        lib.dc_last_error.restype = C.c_char_p
+        lib.dc_version.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _stats_to_dict(arr, fields):
+    return {f: np.array([getattr(s, f) for s in arr]) for f in fields}
+
+
+class Engine:
+    """One dc_ctx. Mirrors the call sequence of include/diffcloth_hip.h one to one."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.dc_create(C.c_int(device), C.byref(h))
+        if rc != 0:
+            raise DcError(f"dc_create failed with code {rc}: no HIP device available (there is no CPU fallback)")
+        self.h = h
+        self.params = dc_params()
+        self.lib.dc_default_params(C.byref(self.params))
+        self.N = self.T = self.E = self.Af = 0
+        self.B = 0
+        self.ngroups = 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DcError(f"code {rc}: {self.lib.dc_last_error(self.h).decode()}")
+
+    # ---- system ----
+    def set_mesh(self, verts, tris):
+        v = _f64(verts).reshape(-1)
+        t = _i32(tris).reshape(-1)
+        self._chk(self.lib.dc_set_mesh(self.h, C.c_int(v.size // 3), _d(v), C.c_int(t.size // 3), _i(t)))
+
+    def set_attachments(self, vertices):
+        a = _i32(vertices).reshape(-1)
+        self._chk(self.lib.dc_set_attachments(self.h, C.c_int(a.size), _i(a)))
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            if k == "gravity":
+                for d in range(3):
+                    self.params.gravity[d] = float(v[d])
+            elif hasattr(self.params, k):
+                setattr(self.params, k, v)
+            else:
+                raise KeyError(k)
+        self._chk(self.lib.dc_set_params(self.h, C.byref(self.params)))
+
+    def set_primitives(self, prims):
+        """prims: list of dicts(kind, group, center, top_offset, radius, length, mu, rotates)."""
+        arr = (dc_primitive * max(len(prims), 1))()
+        groups = []
+        for k, p in enumerate(prims):
+            arr[k].kind = p.get("kind", DC_PRIM_SPHERE)
+            arr[k].group = p.get("group", k)
+            for d in range(3):
+                arr[k].center[d] = float(p["center"][d])
+                arr[k].top_offset[d] = float(p.get("top_offset", (0, 0, 0))[d])
+            arr[k].radius = float(p["radius"])
+            arr[k].length = float(p.get("length", 0.0))
+            arr[k].mu = float(p.get("mu", 0.0))
+            arr[k].rotates = int(p.get("rotates", 0))
+            if arr[k].group not in groups:
+                groups.append(arr[k].group)
+        self.ngroups = max(len(groups), 1)
+        self._chk(self.lib.dc_set_primitives(self.h, C.c_int(len(prims)), arr))
+
+    def build(self):
+        self._chk(self.lib.dc_build(self.h))
+        c = _i32(np.zeros(6))
+        self._chk(self.lib.dc_get_counts(self.h, _i(c)))
+        self.N, self.T, self.E, self.Af, self.nnz, self.rows = [int(x) for x in c]
+        return self
+
+    def system_matrix(self):
+        ptr = _i32(np.zeros(self.N + 1)); col = _i32(np.zeros(self.nnz)); val = _f64(np.zeros(self.nnz))
+        self._chk(self.lib.dc_get_system_matrix(self.h, _i(ptr), _i(col), _d(val)))
+        return ptr, col, val
+
+    def vertex_data(self):
+        m = _f64(np.zeros(self.N)); a = _f64(np.zeros(self.N)); r = _f64(np.zeros(self.N))
+        self._chk(self.lib.dc_get_vertex_data(self.h, _d(m), _d(a), _d(r)))
+        return m, a, r
+
+    # ---- batch ----
+    def alloc_batch(self, batch, tape_steps):
+        self._chk(self.lib.dc_alloc_batch(self.h, C.c_int(batch), C.c_int(tape_steps)))
+        self.B = batch
+        self.tape = tape_steps
+
+    def _vec(self, a, per):
+        a = _f64(a).reshape(-1)
+        if a.size != self.B * per:
+            raise ValueError(f"expected {self.B}x{per} values, got {a.size}")
+        return a
+
+    def set_state(self, slot, x, v):
+        x = self._vec(x, 3 * self.N); v = self._vec(v, 3 * self.N)
+        self._chk(self.lib.dc_set_state(self.h, C.c_int(slot), _d(x), _d(v)))
+
+    def get_state(self, slot):
+        x = np.zeros((self.B, 3 * self.N)); v = np.zeros((self.B, 3 * self.N))
+        self._chk(self.lib.dc_get_state(self.h, C.c_int(slot), _d(x), _d(v)))
+        return x, v
+
+    def set_mu(self, mu):
+        m = None if mu is None else self._vec(mu, self.ngroups)
+        self._chk(self.lib.dc_set_mu(self.h, _d(m)))
+
+    def set_uniform_force(self, f):
+        a = None if f is None else self._vec(f, 3)
+        self._chk(self.lib.dc_set_uniform_force(self.h, _d(a)))
+
+    # ---- hot path ----
+    def step_forward(self, slot, fixed_pts=None, want_stats=True):
+        fp = None if fixed_pts is None else self._vec(fixed_pts, 3 * self.Af)
+        st = (dc_step_stats * self.B)() if want_stats else None
+        self._chk(self.lib.dc_step_forward(self.h, C.c_int(slot), _d(fp), st))
+        if want_stats:
+            return _stats_to_dict(st, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff"])
+        return None
+
+    def get_record(self, slot):
+        f = np.zeros((self.B, 3 * self.N)); r = np.zeros((self.B, 3 * self.N))
+        self._chk(self.lib.dc_get_record(self.h, C.c_int(slot), _d(f), _d(r)))
+        return f, r
+
+    def get_contacts(self, slot):
+        g = np.zeros((self.B, self.N), dtype=np.int32); n = np.zeros((self.B, 3 * self.N))
+        self._chk(self.lib.dc_get_contacts(self.h, C.c_int(slot), _i(g), _d(n)))
+        return g, n
+
+    def step_backward(self, slot, dL_dxnew, dL_dvnew, dL_dxinit=None, dL_dvinit=None, is_start=False):
+        n3 = 3 * self.N
+        gx = self._vec(dL_dxnew, n3); gv = self._vec(dL_dvnew, n3)
+        ix = None if dL_dxinit is None else self._vec(dL_dxinit, n3)
+        iv = None if dL_dvinit is None else self._vec(dL_dvinit, n3)
+        dx = np.zeros((self.B, n3)); dv = np.zeros((self.B, n3))
+        dxf = np.zeros((self.B, max(3 * self.Af, 1))); dmu = np.zeros((self.B, self.ngroups))
+        st = (dc_bwd_stats * self.B)()
+        self._chk(self.lib.dc_step_backward(self.h, C.c_int(slot), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
+                                            _d(dx), _d(dv), _d(dxf), _d(dmu), st))
+        out = dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:, :3 * self.Af], dL_dmu=dmu)
+        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "last_udiff"]))
+        return out
+
+    # ---- device-resident rollouts ----
+    def rollout_forward(self, slot, nsteps):
+        self._chk(self.lib.dc_rollout_forward(self.h, C.c_int(slot), C.c_int(nsteps)))
+
+    def seed_gradient(self, slot, target=None, scale=1.0):
+        t = None if target is None else _f64(target).reshape(-1)
+        self._chk(self.lib.dc_seed_gradient(self.h, C.c_int(slot), _d(t), C.c_double(scale)))
+
+    def rollout_backward(self, slot, nsteps):
+        self._chk(self.lib.dc_rollout_backward(self.h, C.c_int(slot), C.c_int(nsteps)))
+
+    def get_gradient(self):
+        dx = np.zeros((self.B, 3 * self.N)); dv = np.zeros((self.B, 3 * self.N)); dmu = np.zeros((self.B, self.ngroups))
+        self._chk(self.lib.dc_get_gradient(self.h, _d(dx), _d(dv), _d(dmu)))
+        return dx, dv, dmu
+
+    def get_stats(self, slot):
+        f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()
+        self._chk(self.lib.dc_get_stats(self.h, C.c_int(slot), f, b))
+        return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff"]),
+                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "last_udiff"]))
+
+    def sync(self):
+        self._chk(self.lib.dc_sync(self.h))
+
+    def timer_start(self):
+        self._chk(self.lib.dc_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.dc_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def kernel_times(self, reset=False):
+        a = C.c_float(); b = C.c_float(); na = C.c_int(); nb = C.c_int()
+        self._chk(self.lib.dc_kernel_times(self.h, C.byref(a), C.byref(na), C.byref(b), C.byref(nb), C.c_int(int(reset))))
+        return dict(fwd_ms=a.value, fwd_launches=na.value, bwd_ms=b.value, bwd_launches=nb.value)

@@ -1,0 +1,83 @@
+// Device-side data descriptors shared by the C-ABI layer (dc_engine.hip) and the kernels (dc_kernels.hip).
+// All device vectors are fp32, component-planar per rollout: v[b][c][i] at ((b*3 + c)*N + i).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/diffcloth_hip.h"
+
+namespace dc {
+
+constexpr int kMaxPrims = 8;
+
+struct DevPrim {
+  int kind, group, rotates, pad;
+  float cx, cy, cz, radius;
+  float tx, ty, tz, length;
+};
+
+// Shared (per-context) tables: topology + matrices, identical for every rollout of the batch.
+struct DevSystem {
+  int N, T, E, Af, NC;          // NC = 3T + 4E constraint corners
+  int nprim, ngroups, pad0;
+  const int *tri_v;             // [3][T]
+  const float4 *tri_D;          // [T]  inv_deltaUV (d00,d01,d10,d11)
+  const float *tri_w2;          // [T]  area * k_stretch
+  const int *bend_v;            // [4][E]
+  const float4 *bend_w;         // [E]  cotan weights
+  const float2 *bend_nw;        // [E]  (rest norm n, weight^2)
+  const int *att_vertex;        // [Af]
+  const int *att_of_vertex;     // [N]  fixed-point index or -1
+  const float *mass;            // [N]
+  const float *dinv;            // [N]  1 / P_ii  (block-Jacobi preconditioner; blocks are scalar * I3)
+  const int *P_ptr;             // [N+1]
+  const int *P_col;             // [nnz]
+  const float *P_val;           // [nnz]
+  const int *inc_ptr;           // [N+1] vertex -> constraint corners
+  const int *inc_idx;
+  float h, k_att, gx, gy, gz;
+  int contact_enabled, self_enabled, pad1;
+  DevPrim prims[kMaxPrims];
+};
+
+// Per-batch work buffers (one set, reused by forward and backward kernels).
+struct DevWork {
+  float *g;        // [B][3][N]  M (s_n - x_n) / h                    | backward: carried-in gradient copy
+  float *vnow;     // [B][3][N]  current velocity iterate             | backward: u
+  float *vbest;    // [B][3][N]  best iterate                          | backward: y = u + dr_df^T u
+  float *cg_r, *cg_p, *cg_ap, *cg_x;   // [B][3][N] each
+  float *corner;   // [B][3][NC] per-constraint-corner contributions
+};
+
+struct FwdArgs {
+  const float *x_in, *v_in;     // slot k   [B][3][N]
+  float *x_out, *v_out;         // slot k+1
+  float *rec_f, *rec_r, *rec_n; // record k+1 [B][3][N]
+  int *rec_prim;                // record k+1 [B][N]   flattened primitive index or -1
+  const float *x_fixed;         // [B][3][Af] fixed-point targets for this step
+  const float *mu;              // [B][ngroups]
+  const float *fu;              // [B][3] uniform extra force or nullptr
+  dc_step_stats *stats;         // [B]
+  float fwd_tol, cg_tol;
+  int pd_cap, cg_max, stall_window;
+};
+
+struct BwdArgs {
+  const float *x_new;           // slot k [B][3][N]
+  const float *rec_f, *rec_n;   // record k
+  const int *rec_prim;
+  const float *mu;
+  float *gx, *gv;               // carried gradient, in: dL_dxnew/dL_dvnew, out: dL_dx/dL_dv   [B][3][N]
+  const float *ix, *iv;         // dL_dxinit / dL_dvinit or nullptr
+  float *d_xfixed;              // [B][3][Af] out (overwritten) or nullptr
+  float *d_mu;                  // [B][ngroups] accumulated (+=) or nullptr
+  dc_bwd_stats *stats;          // [B]
+  float bwd_tol, cg_tol, clip_thr;
+  int it_cap, cg_max, is_start, clip, stall_window;
+};
+
+void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
+void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);
+void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, hipStream_t st);
+void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, hipStream_t st);
+void launch_seed_gradient(const float *x, const float *target, float *gx, float *gv, int B, int N, float scale, hipStream_t st);
+
+}  // namespace dc

@@ -1,0 +1,617 @@
+// C-ABI layer of libdiffcloth_hip.so: context, device memory, tape, and the calls that enqueue the
+// persistent step kernels. See include/diffcloth_hip.h for the contract of every entry point.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "dc_device.h"
+#include "dc_system.h"
+
+using namespace dc;
+
+struct dc_ctx {
+  int device = 0;
+  bool host_only = false;   // dc_create(-1): table building / inspection only, every compute call fails
+  hipStream_t stream = nullptr;
+  std::string err;
+  HostSystem host;
+  dc_params params;
+  std::vector<dc_primitive> prims;
+  std::vector<int> group_of_prim;
+  int ngroups = 0;
+  bool mesh_set = false, built = false;
+
+  DevSystem S;
+  std::vector<void *> table_allocs;
+
+  int B = 0, tape = 0;
+  DevWork W;
+  std::vector<void *> batch_allocs;
+  float *X = nullptr, *V = nullptr, *F = nullptr, *R = nullptr, *NRM = nullptr;   // [(tape+1)][B][3][N]
+  int *PRIM = nullptr;                                                            // [(tape+1)][B][N]
+  float *xf_cur = nullptr;          // [B][3][Af]
+  float *mu = nullptr, *fu = nullptr;
+  bool fu_set = false;
+  float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DXF = nullptr, *DMU = nullptr, *target = nullptr;
+  dc_step_stats *fstats = nullptr;  // [(tape+1)][B]
+  dc_bwd_stats *bstats = nullptr;   // [(tape+1)][B], indexed by the slot whose record was differentiated
+  double *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_elems = 0;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  float fwd_ms = 0, bwd_ms = 0;
+  int fwd_launches = 0, bwd_launches = 0;
+};
+
+namespace {
+
+int fail(dc_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+#define HIPCHK(c, call)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(c, DC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+template <typename T>
+int dev_alloc(dc_ctx *c, std::vector<void *> &pool, T **out, size_t count) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIPCHK(c, hipMalloc(&p, bytes));
+  HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->stream));
+  pool.push_back(p);
+  *out = (T *) p;
+  return DC_OK;
+}
+template <typename T, typename U>
+int upload(dc_ctx *c, const T **out, const std::vector<U> &src) {
+  std::vector<T> tmp(src.begin(), src.end());
+  T *p = nullptr;
+  int rc = dev_alloc(c, c->table_allocs, &p, tmp.size());
+  if (rc) return rc;
+  if (!tmp.empty()) HIPCHK(c, hipMemcpy(p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return DC_OK;
+}
+void free_pool(std::vector<void *> &pool) {
+  for (void *p : pool) (void) hipFree(p);
+  pool.clear();
+}
+size_t slot_elems(const dc_ctx *c) { return (size_t) c->B * 3 * c->host.N; }
+
+int pd_cap(const dc_ctx *c) {
+  if (c->params.pd_iter_cap >= 0) return c->params.pd_iter_cap;
+  return (int) ((-std::log10(c->params.forward_tol)) * 150);   // Simulation.cpp:1182
+}
+
+int h2d_planar(dc_ctx *c, const double *src, float *dst, int n_per_rollout, int which_stage) {
+  size_t elems = (size_t) c->B * 3 * n_per_rollout;
+  HIPCHK(c, hipMemcpyAsync(c->stage[which_stage], src, elems * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  launch_f64i_to_f32p(c->stage[which_stage], dst, c->B, n_per_rollout, c->stream);
+  return DC_OK;
+}
+int d2h_planar(dc_ctx *c, const float *src, double *dst, int n_per_rollout, int which_stage) {
+  size_t elems = (size_t) c->B * 3 * n_per_rollout;
+  launch_f32p_to_f64i(src, c->stage[which_stage], c->B, n_per_rollout, c->stream);
+  HIPCHK(c, hipMemcpyAsync(dst, c->stage[which_stage], elems * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return DC_OK;
+}
+
+int check_batch(dc_ctx *c, int slot_lo, int slot_hi) {
+  if (!c->built) return fail(c, DC_ERR_STATE, "dc_build has not been called");
+  if (c->B <= 0) return fail(c, DC_ERR_STATE, "dc_alloc_batch has not been called");
+  if (slot_lo < 0 || slot_hi > c->tape) return fail(c, DC_ERR_INVALID, "tape slot out of range");
+  return DC_OK;
+}
+
+FwdArgs fwd_args(dc_ctx *c, int slot) {
+  const size_t se = slot_elems(c), sp = (size_t) c->B * c->host.N;
+  FwdArgs A;
+  A.x_in = c->X + se * slot; A.v_in = c->V + se * slot;
+  A.x_out = c->X + se * (slot + 1); A.v_out = c->V + se * (slot + 1);
+  A.rec_f = c->F + se * (slot + 1); A.rec_r = c->R + se * (slot + 1); A.rec_n = c->NRM + se * (slot + 1);
+  A.rec_prim = c->PRIM + sp * (slot + 1);
+  A.x_fixed = c->xf_cur; A.mu = c->mu; A.fu = c->fu_set ? c->fu : nullptr;
+  A.stats = c->fstats + (size_t) c->B * (slot + 1);
+  A.fwd_tol = (float) c->params.forward_tol;
+  A.cg_tol = (float) (c->params.cg_rel_tol > 0 ? c->params.cg_rel_tol : 1e-4);
+  A.pd_cap = pd_cap(c);
+  A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
+  A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 40;
+  return A;
+}
+BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
+  const size_t se = slot_elems(c), sp = (size_t) c->B * c->host.N;
+  BwdArgs A;
+  A.x_new = c->X + se * slot; A.rec_f = c->F + se * slot; A.rec_n = c->NRM + se * slot;
+  A.rec_prim = c->PRIM + sp * slot; A.mu = c->mu;
+  A.gx = c->GX; A.gv = c->GV;
+  A.ix = with_init ? c->IX : nullptr; A.iv = with_init ? c->IV : nullptr;
+  A.d_xfixed = c->DXF; A.d_mu = c->DMU; A.stats = c->bstats + (size_t) c->B * slot;
+  A.bwd_tol = (float) c->params.backward_tol;
+  A.cg_tol = (float) (c->params.cg_rel_tol > 0 ? c->params.cg_rel_tol : 1e-4);
+  A.clip_thr = (float) c->params.gradient_clipping_threshold;
+  A.it_cap = c->params.adjoint_iter_cap > 0 ? c->params.adjoint_iter_cap : 400;   // Simulation.cpp:1562
+  A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
+  A.is_start = is_start; A.clip = c->params.gradient_clipping;
+  A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 40;
+  return A;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dc_version(void) { return "diffcloth_hip 0.1 (gfx950)"; }
+
+void dc_default_params(dc_params *p) {
+  std::memset(p, 0, sizeof(*p));
+  p->time_step = 1.0 / 90; p->density = 0.1; p->k_stretch = 100; p->k_bend = 0.01; p->k_att = 10000;   // AttachmentSpring.cpp:10
+  p->gravity[0] = 0; p->gravity[1] = -9.8; p->gravity[2] = 0;                                          // Simulation.h:356
+  p->forward_tol = 1e-7; p->backward_tol = 5e-5;                                                        // Simulation.cpp:17-19
+  p->gravity_enabled = 1; p->contact_enabled = 1; p->selfcollision_enabled = 0;
+  p->gradient_clipping = 1; p->gradient_clipping_threshold = 16.0;                                      // Simulation.h:330-331
+  p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 40;
+}
+
+int dc_create(int device_id, dc_ctx **out) {
+  if (!out) return DC_ERR_INVALID;
+  *out = nullptr;
+  if (device_id == -1) {   // host-only context: no device memory, no kernels, no CPU compute path either
+    dc_ctx *c = new dc_ctx();
+    c->device = -1; c->host_only = true;
+    dc_default_params(&c->params);
+    std::memset(&c->S, 0, sizeof(c->S));
+    std::memset(&c->W, 0, sizeof(c->W));
+    *out = c;
+    return DC_OK;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DC_ERR_HIP;   // no CPU fallback: fail loudly
+  if (device_id < 0 || device_id >= count) return DC_ERR_INVALID;
+  dc_ctx *c = new dc_ctx();
+  c->device = device_id;
+  dc_default_params(&c->params);
+  std::memset(&c->S, 0, sizeof(c->S));
+  std::memset(&c->W, 0, sizeof(c->W));
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return DC_ERR_HIP; }
+  (void) hipEventCreate(&c->ev_a); (void) hipEventCreate(&c->ev_b);
+  (void) hipEventCreate(&c->ev_t0); (void) hipEventCreate(&c->ev_t1);
+  *out = c;
+  return DC_OK;
+}
+
+int dc_destroy(dc_ctx *c) {
+  if (!c) return DC_OK;
+  if (c->host_only) { delete c; return DC_OK; }
+  (void) hipSetDevice(c->device);
+  (void) hipStreamSynchronize(c->stream);
+  free_pool(c->table_allocs);
+  free_pool(c->batch_allocs);
+  (void) hipEventDestroy(c->ev_a); (void) hipEventDestroy(c->ev_b);
+  (void) hipEventDestroy(c->ev_t0); (void) hipEventDestroy(c->ev_t1);
+  (void) hipStreamDestroy(c->stream);
+  delete c;
+  return DC_OK;
+}
+
+const char *dc_last_error(const dc_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int dc_set_mesh(dc_ctx *c, int n, const double *pos, int t, const int *tris) {
+  if (!c) return DC_ERR_INVALID;
+  c->built = false;
+  if (!c->host.set_mesh(n, pos, t, tris)) { c->mesh_set = false; return fail(c, DC_ERR_TOPOLOGY, c->host.error); }
+  c->mesh_set = true;
+  return DC_OK;
+}
+
+int dc_set_attachments(dc_ctx *c, int count, const int *vertex) {
+  if (!c || count < 0 || (count > 0 && !vertex)) return fail(c, DC_ERR_INVALID, "dc_set_attachments: bad arguments");
+  c->host.att_vertex.assign(vertex, vertex + count);
+  c->built = false;
+  return DC_OK;
+}
+
+int dc_set_params(dc_ctx *c, const dc_params *p) {
+  if (!c || !p) return DC_ERR_INVALID;
+  if (!(p->time_step > 0) || !(p->density > 0)) return fail(c, DC_ERR_INVALID, "dc_set_params: time_step and density must be > 0");
+  c->params = *p;
+  c->built = false;
+  return DC_OK;
+}
+
+int dc_set_primitives(dc_ctx *c, int count, const dc_primitive *prims) {
+  if (!c || count < 0 || count > kMaxPrims) return fail(c, DC_ERR_INVALID, "dc_set_primitives: at most 8 flattened primitives");
+  c->prims.assign(prims, prims + count);
+  // compact the caller's group ids to 0..ngroups-1 in order of first appearance
+  std::vector<int> seen;
+  c->group_of_prim.assign(count, 0);
+  for (int k = 0; k < count; k++) {
+    int g = -1;
+    for (size_t s = 0; s < seen.size(); s++) if (seen[s] == prims[k].group) g = (int) s;
+    if (g < 0) { g = (int) seen.size(); seen.push_back(prims[k].group); }
+    c->group_of_prim[k] = g;
+  }
+  c->ngroups = (int) seen.size();
+  c->built = false;
+  return DC_OK;
+}
+
+int dc_build(dc_ctx *c) {
+  if (!c) return DC_ERR_INVALID;
+  if (!c->mesh_set) return fail(c, DC_ERR_STATE, "dc_build: dc_set_mesh has not been called");
+  const dc_params &p = c->params;
+  HostSystem &H = c->host;
+  if (!H.build_numerics(p.time_step, p.density, p.k_stretch, p.k_bend, p.k_att)) return fail(c, DC_ERR_TOPOLOGY, H.error);
+  if (c->host_only) { c->built = true; return DC_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_pool(c->table_allocs);
+  DevSystem &S = c->S;
+  std::memset(&S, 0, sizeof(S));
+  const int N = H.N, T = H.T, E = H.E, Af = (int) H.att_vertex.size();
+  S.N = N; S.T = T; S.E = E; S.Af = Af; S.NC = 3 * T + 4 * E;
+  // planar index tables
+  std::vector<int> triv(3 * (size_t) T), bendv(4 * (size_t) E);
+  for (int t = 0; t < T; t++) for (int k = 0; k < 3; k++) triv[(size_t) k * T + t] = H.tri[3 * t + k];
+  for (int e = 0; e < E; e++) for (int k = 0; k < 4; k++) bendv[(size_t) k * E + e] = H.bend_v[4 * e + k];
+  std::vector<float> bendnw(2 * (size_t) E), dinv(N);
+  for (int e = 0; e < E; e++) { bendnw[2 * e] = (float) H.bend_n[e]; bendnw[2 * e + 1] = (float) H.bend_w2[e]; }
+  for (int i = 0; i < N; i++) {
+    double d = 0;
+    for (int k = H.P_ptr[i]; k < H.P_ptr[i + 1]; k++) if (H.P_col[k] == i) d = H.P_val[k];
+    dinv[i] = (float) (1.0 / d);
+  }
+  std::vector<int> att_of(N, -1);
+  for (int a = 0; a < Af; a++) att_of[H.att_vertex[a]] = a;
+  int rc;
+  const float *f4;
+  if ((rc = upload<int>(c, &S.tri_v, triv))) return rc;
+  if ((rc = upload<float>(c, &f4, H.tri_D))) return rc;
+  S.tri_D = (const float4 *) f4;
+  if ((rc = upload<float>(c, &S.tri_w2, H.tri_w2))) return rc;
+  if ((rc = upload<int>(c, &S.bend_v, bendv))) return rc;
+  if ((rc = upload<float>(c, &f4, H.bend_w))) return rc;
+  S.bend_w = (const float4 *) f4;
+  if ((rc = upload<float>(c, &f4, bendnw))) return rc;
+  S.bend_nw = (const float2 *) f4;
+  if ((rc = upload<int>(c, &S.att_vertex, H.att_vertex))) return rc;
+  if ((rc = upload<int>(c, &S.att_of_vertex, att_of))) return rc;
+  if ((rc = upload<float>(c, &S.mass, H.mass))) return rc;
+  if ((rc = upload<float>(c, &S.dinv, dinv))) return rc;
+  if ((rc = upload<int>(c, &S.P_ptr, H.P_ptr))) return rc;
+  if ((rc = upload<int>(c, &S.P_col, H.P_col))) return rc;
+  if ((rc = upload<float>(c, &S.P_val, H.P_val))) return rc;
+  if ((rc = upload<int>(c, &S.inc_ptr, H.inc_ptr))) return rc;
+  if ((rc = upload<int>(c, &S.inc_idx, H.inc_idx))) return rc;
+  S.h = (float) p.time_step; S.k_att = (float) p.k_att;
+  S.gx = p.gravity_enabled ? (float) p.gravity[0] : 0.f;
+  S.gy = p.gravity_enabled ? (float) p.gravity[1] : 0.f;
+  S.gz = p.gravity_enabled ? (float) p.gravity[2] : 0.f;
+  S.contact_enabled = p.contact_enabled; S.self_enabled = p.selfcollision_enabled;
+  S.nprim = (int) c->prims.size(); S.ngroups = std::max(c->ngroups, 1);
+  for (int k = 0; k < S.nprim; k++) {
+    const dc_primitive &q = c->prims[k];
+    DevPrim &d = S.prims[k];
+    d.kind = q.kind; d.group = c->group_of_prim[k]; d.rotates = q.rotates; d.pad = 0;
+    d.cx = (float) q.center[0]; d.cy = (float) q.center[1]; d.cz = (float) q.center[2]; d.radius = (float) q.radius;
+    d.tx = (float) q.top_offset[0]; d.ty = (float) q.top_offset[1]; d.tz = (float) q.top_offset[2]; d.length = (float) q.length;
+  }
+  c->built = true;
+  // a batch allocated for a different system size is no longer valid
+  if (c->B > 0) {
+    int B = c->B, tape = c->tape;
+    c->B = 0;
+    return dc_alloc_batch(c, B, tape);
+  }
+  return DC_OK;
+}
+
+int dc_get_counts(const dc_ctx *c, int *out6) {
+  if (!c || !out6 || !c->mesh_set) return DC_ERR_INVALID;
+  out6[0] = c->host.N; out6[1] = c->host.T; out6[2] = c->host.E; out6[3] = (int) c->host.att_vertex.size();
+  out6[4] = (int) c->host.P_col.size(); out6[5] = c->host.rows();
+  return DC_OK;
+}
+int dc_get_system_matrix(const dc_ctx *c, int *row_ptr, int *col, double *val) {
+  if (!c || !c->built) return DC_ERR_STATE;
+  std::memcpy(row_ptr, c->host.P_ptr.data(), sizeof(int) * c->host.P_ptr.size());
+  std::memcpy(col, c->host.P_col.data(), sizeof(int) * c->host.P_col.size());
+  std::memcpy(val, c->host.P_val.data(), sizeof(double) * c->host.P_val.size());
+  return DC_OK;
+}
+int dc_get_vertex_data(const dc_ctx *c, double *mass, double *area, double *radii) {
+  if (!c || !c->built) return DC_ERR_STATE;
+  const int N = c->host.N;
+  if (mass) std::memcpy(mass, c->host.mass.data(), sizeof(double) * N);
+  if (area) std::memcpy(area, c->host.area.data(), sizeof(double) * N);
+  if (radii) std::memcpy(radii, c->host.radii.data(), sizeof(double) * N);
+  return DC_OK;
+}
+
+int dc_alloc_batch(dc_ctx *c, int B, int tape) {
+  if (!c) return DC_ERR_INVALID;
+  if (c->host_only) return fail(c, DC_ERR_STATE, "host-only context (dc_create(-1)): no device, and there is no CPU compute path");
+  if (!c->built) return fail(c, DC_ERR_STATE, "dc_alloc_batch: dc_build has not been called");
+  if (B <= 0 || tape <= 0) return fail(c, DC_ERR_INVALID, "dc_alloc_batch: batch and tape_steps must be > 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_pool(c->batch_allocs);
+  c->B = B; c->tape = tape;
+  const int N = c->host.N, Af = (int) c->host.att_vertex.size(), NC = c->S.NC, G = c->S.ngroups;
+  const size_t se = (size_t) B * 3 * N, slots = (size_t) tape + 1;
+  auto &pool = c->batch_allocs;
+  int rc;
+  if ((rc = dev_alloc(c, pool, &c->X, se * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->V, se * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->F, se * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->R, se * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->NRM, se * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->PRIM, (size_t) B * N * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.g, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.vnow, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.vbest, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.cg_r, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.cg_p, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.cg_ap, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.cg_x, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.corner, (size_t) B * 3 * NC))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->xf_cur, (size_t) B * 3 * Af))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->mu, (size_t) B * G))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->fu, (size_t) B * 3))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->GX, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->GV, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->IX, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->IV, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->DXF, (size_t) B * 3 * Af))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->DMU, (size_t) B * G))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->target, (size_t) 3 * N))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->fstats, (size_t) B * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->bstats, (size_t) B * slots))) return rc;
+  c->stage_elems = se;
+  for (int k = 0; k < 4; k++) if ((rc = dev_alloc(c, pool, &c->stage[k], se))) return rc;
+  c->fu_set = false;
+  // default fixed-point targets = rest positions of the attached vertices (FixedPoint::pos = pos_rest)
+  if (Af > 0) {
+    std::vector<float> xf((size_t) B * 3 * Af);
+    for (int b = 0; b < B; b++)
+      for (int a = 0; a < Af; a++)
+        for (int d = 0; d < 3; d++) xf[((size_t) b * 3 + d) * Af + a] = (float) c->host.rest[3 * c->host.att_vertex[a] + d];
+    HIPCHK(c, hipMemcpy(c->xf_cur, xf.data(), xf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return dc_set_mu(c, nullptr);
+}
+
+int dc_set_mu(dc_ctx *c, const double *mu) {
+  if (!c || c->B <= 0) return fail(c, DC_ERR_STATE, "dc_set_mu: no batch");
+  const int G = c->S.ngroups;
+  std::vector<float> m((size_t) c->B * G, 0.f);
+  for (int b = 0; b < c->B; b++)
+    for (int g = 0; g < G; g++) {
+      double v = 0;
+      if (mu) v = mu[(size_t) b * G + g];
+      else for (size_t k = 0; k < c->prims.size(); k++) if (c->group_of_prim[k] == g) { v = c->prims[k].mu; break; }
+      m[(size_t) b * G + g] = (float) v;
+    }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->mu, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
+  return DC_OK;
+}
+
+int dc_set_uniform_force(dc_ctx *c, const double *f) {
+  if (!c || c->B <= 0) return fail(c, DC_ERR_STATE, "dc_set_uniform_force: no batch");
+  if (!f) { c->fu_set = false; return DC_OK; }
+  std::vector<float> v((size_t) c->B * 3);
+  for (size_t k = 0; k < v.size(); k++) v[k] = (float) f[k];
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->fu, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->fu_set = true;
+  return DC_OK;
+}
+
+int dc_set_state(dc_ctx *c, int slot, const double *x, const double *v) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (!x || !v) return fail(c, DC_ERR_INVALID, "dc_set_state: null state");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c);
+  if ((rc = h2d_planar(c, x, c->X + se * slot, c->host.N, 0))) return rc;
+  if ((rc = h2d_planar(c, v, c->V + se * slot, c->host.N, 1))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller
+  return DC_OK;
+}
+
+int dc_get_state(dc_ctx *c, int slot, double *x, double *v) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c);
+  if (x && (rc = d2h_planar(c, c->X + se * slot, x, c->host.N, 0))) return rc;
+  if (v && (rc = d2h_planar(c, c->V + se * slot, v, c->host.N, 1))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DC_OK;
+}
+
+int dc_step_forward(dc_ctx *c, int slot, const double *fixed_pts, dc_step_stats *stats) {
+  int rc = check_batch(c, slot, slot + 1);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int Af = c->S.Af;
+  if (fixed_pts && Af > 0) {
+    if ((rc = h2d_planar(c, fixed_pts, c->xf_cur, Af, 2))) return rc;
+  }
+  launch_pd_step(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if (stats) {
+    HIPCHK(c, hipMemcpyAsync(stats, c->fstats + (size_t) c->B * (slot + 1), sizeof(dc_step_stats) * c->B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  } else if (fixed_pts && Af > 0) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return DC_OK;
+}
+
+int dc_get_record(dc_ctx *c, int slot, double *f, double *r) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_get_record: slot 0 has no record");
+  const size_t se = slot_elems(c);
+  if (f && (rc = d2h_planar(c, c->F + se * slot, f, c->host.N, 0))) return rc;
+  if (r && (rc = d2h_planar(c, c->R + se * slot, r, c->host.N, 1))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DC_OK;
+}
+
+int dc_get_contacts(dc_ctx *c, int slot, int *prim_group, double *normal) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_get_contacts: slot 0 has no record");
+  const size_t se = slot_elems(c), sp = (size_t) c->B * c->host.N;
+  if (normal && (rc = d2h_planar(c, c->NRM + se * slot, normal, c->host.N, 0))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (prim_group) {
+    HIPCHK(c, hipMemcpy(prim_group, c->PRIM + sp * slot, sp * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < sp; k++) if (prim_group[k] >= 0) prim_group[k] = c->prims[prim_group[k]].group;
+  }
+  return DC_OK;
+}
+
+int dc_step_backward(dc_ctx *c, int slot, const double *dL_dxnew, const double *dL_dvnew, const double *dL_dxinit,
+                     const double *dL_dvinit, int is_start, double *dL_dx, double *dL_dv, double *dL_dxfixed,
+                     double *dL_dmu, dc_bwd_stats *stats) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_step_backward: slot 0 has no record");
+  if (!dL_dxnew || !dL_dvnew || !dL_dx || !dL_dv) return fail(c, DC_ERR_INVALID, "dc_step_backward: null gradient");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->host.N, Af = c->S.Af, G = c->S.ngroups;
+  if ((rc = h2d_planar(c, dL_dxnew, c->GX, N, 0))) return rc;
+  if ((rc = h2d_planar(c, dL_dvnew, c->GV, N, 1))) return rc;
+  const bool with_init = dL_dxinit && dL_dvinit;
+  if (with_init) {
+    if ((rc = h2d_planar(c, dL_dxinit, c->IX, N, 2))) return rc;
+    if ((rc = h2d_planar(c, dL_dvinit, c->IV, N, 3))) return rc;
+  }
+  HIPCHK(c, hipMemsetAsync(c->DMU, 0, sizeof(float) * c->B * G, c->stream));
+  if (Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF, 0, sizeof(float) * c->B * 3 * Af, c->stream));
+  launch_adjoint_step(c->S, c->W, bwd_args(c, slot, is_start != 0, with_init), c->B, c->stream);
+  HIPCHK(c, hipGetLastError());
+  if ((rc = d2h_planar(c, c->GX, dL_dx, N, 0))) return rc;
+  if ((rc = d2h_planar(c, c->GV, dL_dv, N, 1))) return rc;
+  if (dL_dxfixed && Af > 0 && (rc = d2h_planar(c, c->DXF, dL_dxfixed, Af, 2))) return rc;
+  std::vector<float> dmu((size_t) c->B * G);
+  HIPCHK(c, hipMemcpyAsync(dmu.data(), c->DMU, dmu.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (stats) HIPCHK(c, hipMemcpyAsync(stats, c->bstats + (size_t) c->B * slot, sizeof(dc_bwd_stats) * c->B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (dL_dmu) for (size_t k = 0; k < dmu.size(); k++) dL_dmu[k] = dmu[k];
+  return DC_OK;
+}
+
+int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
+  int rc = check_batch(c, slot, slot + nsteps);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+  for (int k = 0; k < nsteps; k++) launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+  HIPCHK(c, hipGetLastError());
+  // kernel-time accounting is resolved lazily in dc_kernel_times / dc_sync
+  HIPCHK(c, hipEventSynchronize(c->ev_b));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+  c->fwd_ms += ms; c->fwd_launches += nsteps;
+  return DC_OK;
+}
+
+int dc_seed_gradient(dc_ctx *c, int slot, const double *target, double scale_x) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->host.N;
+  std::vector<float> t(3 * (size_t) N);
+  for (int i = 0; i < N; i++)
+    for (int d = 0; d < 3; d++) t[(size_t) d * N + i] = (float) (target ? target[3 * i + d] : c->host.rest[3 * i + d]);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->target, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+  launch_seed_gradient(c->X + slot_elems(c) * slot, c->target, c->GX, c->GV, c->B, N, (float) scale_x, c->stream);
+  HIPCHK(c, hipMemsetAsync(c->DMU, 0, sizeof(float) * c->B * c->S.ngroups, c->stream));
+  return DC_OK;
+}
+
+int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
+  int rc = check_batch(c, slot - nsteps + 1, slot);
+  if (rc) return rc;
+  if (slot - nsteps + 1 < 1) return fail(c, DC_ERR_INVALID, "dc_rollout_backward: would run past slot 1");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
+  for (int k = 0; k < nsteps; k++) {
+    const int s = slot - k;
+    launch_adjoint_step(c->S, c->W, bwd_args(c, s, s == 1, false), c->B, c->stream);   // isStart: Simulation.cpp:3947
+  }
+  HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventSynchronize(c->ev_b));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
+  c->bwd_ms += ms; c->bwd_launches += nsteps;
+  return DC_OK;
+}
+
+int dc_get_gradient(dc_ctx *c, double *dL_dx, double *dL_dv, double *dL_dmu) {
+  int rc = check_batch(c, 0, 0);
+  if (rc) return rc;
+  const int N = c->host.N, G = c->S.ngroups;
+  if (dL_dx && (rc = d2h_planar(c, c->GX, dL_dx, N, 0))) return rc;
+  if (dL_dv && (rc = d2h_planar(c, c->GV, dL_dv, N, 1))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (dL_dmu) {
+    std::vector<float> dmu((size_t) c->B * G);
+    HIPCHK(c, hipMemcpy(dmu.data(), c->DMU, dmu.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < dmu.size(); k++) dL_dmu[k] = dmu[k];
+  }
+  return DC_OK;
+}
+
+int dc_get_stats(dc_ctx *c, int slot, dc_step_stats *fwd, dc_bwd_stats *bwd) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (fwd) HIPCHK(c, hipMemcpy(fwd, c->fstats + (size_t) c->B * slot, sizeof(dc_step_stats) * c->B, hipMemcpyDeviceToHost));
+  if (bwd) HIPCHK(c, hipMemcpy(bwd, c->bstats + (size_t) c->B * slot, sizeof(dc_bwd_stats) * c->B, hipMemcpyDeviceToHost));
+  return DC_OK;
+}
+
+int dc_sync(dc_ctx *c) {
+  if (!c) return DC_ERR_INVALID;
+  if (c->host_only) return DC_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DC_OK;
+}
+
+int dc_timer_start(dc_ctx *c) {
+  if (!c) return DC_ERR_INVALID;
+  HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+  return DC_OK;
+}
+int dc_timer_stop(dc_ctx *c, float *ms) {
+  if (!c || !ms) return DC_ERR_INVALID;
+  HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev_t1));
+  HIPCHK(c, hipEventElapsedTime(ms, c->ev_t0, c->ev_t1));
+  return DC_OK;
+}
+int dc_kernel_times(dc_ctx *c, float *fwd_ms, int *fwd_launches, float *bwd_ms, int *bwd_launches, int reset) {
+  if (!c) return DC_ERR_INVALID;
+  if (fwd_ms) *fwd_ms = c->fwd_ms;
+  if (fwd_launches) *fwd_launches = c->fwd_launches;
+  if (bwd_ms) *bwd_ms = c->bwd_ms;
+  if (bwd_launches) *bwd_launches = c->bwd_launches;
+  if (reset) { c->fwd_ms = c->bwd_ms = 0; c->fwd_launches = c->bwd_launches = 0; }
+  return DC_OK;
+}
+
+}  // extern "C"

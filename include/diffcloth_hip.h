@@ -1,0 +1,165 @@
+/* diffcloth_hip.h — C-ABI of the MI355X-native DiffCloth stepper (libdiffcloth_hip.so).
+ *
+ * Drop-in boundary for the hot path of omegaiota/DiffCloth: the Projective-Dynamics forward step with
+ * Signorini–Coulomb dry friction and its adjoint backward step. Each entry point names the reference
+ * interface it replaces (paths relative to /root/reference/src/code/simulation/). The C++ host class
+ * `Simulation` (diffcloth_amd/csrc/host/) keeps the reference's step()/stepNN()/stepBackward()/
+ * stepBackwardNN() signatures and forwards to these functions; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain C, opaque handle, int status (0 = DC_OK); no exceptions cross the boundary;
+ *    dc_last_error() returns a message for the last failing call on that context.
+ *  - host vectors are float64, xyz-interleaved, length 3N (or 3*Af) PER ROLLOUT, rollouts concatenated:
+ *    exactly the reference's VecXd layout (Simulation.h: ForwardInformation::x etc.), batched.
+ *  - the device computes in fp32; device layout is component-planar [B][3][N].
+ *  - a context owns one HIP stream; calls are enqueued in order; calls that return host data synchronise.
+ *  - "slot" k of the tape holds the state after k steps; slot 0 is the initial state.
+ */
+#ifndef DIFFCLOTH_HIP_H
+#define DIFFCLOTH_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dc_ctx dc_ctx;
+
+enum { DC_OK = 0, DC_ERR_INVALID = 1, DC_ERR_HIP = 2, DC_ERR_STATE = 3, DC_ERR_TOPOLOGY = 4 };
+
+/* Primitive kinds (Primitive.h PrimitiveType; only the analytic isInContact family is on the hot path). */
+enum { DC_PRIM_SPHERE = 0, DC_PRIM_CAPSULE = 1 };
+
+/* One analytic obstacle. A LowerLeg (Primitive.cpp:383-418) is passed as its three children
+ * (joint sphere, foot capsule, leg capsule) sharing one `group`; friction uses the group's mu and the
+ * first child in contact wins, as LowerLeg::isInContact does.                                          */
+typedef struct dc_primitive {
+  int kind;            /* DC_PRIM_*                                                              */
+  int group;           /* primitive id seen by the caller (index into Simulation::primitives)    */
+  double center[3];    /* world position tested against: center_prim (+ child centerInit)        */
+  double top_offset[3];/* capsule: globalRotation * (0,length,0)  (Primitive.cpp:582)            */
+  double radius;
+  double length;       /* capsule length                                                         */
+  double mu;           /* Primitive::mu (default for rollouts without a per-rollout override)     */
+  int rotates;         /* Sphere::rotates (Primitive.cpp:255-257)                                 */
+} dc_primitive;
+
+/* Scene / solver parameters. Mirrors the process-global statics of the reference
+ * (Simulation.h:325-338, Simulation.cpp:9-22) and SceneConfiguration / FabricConfiguration.           */
+typedef struct dc_params {
+  double time_step;                 /* sceneConfig.timeStep                                       */
+  double density;                   /* fabric.density                                             */
+  double k_stretch, k_bend, k_att;  /* Triangle::k_stiff, TriangleBending::k_stiff, AttachmentSpring::k_stiff */
+  double gravity[3];                /* Simulation::gravity                                        */
+  double forward_tol;               /* Simulation::forwardConvergenceThreshold                    */
+  double backward_tol;              /* Simulation::backwardConvergenceThreshold                   */
+  int gravity_enabled, contact_enabled, selfcollision_enabled;
+  int gradient_clipping;            /* Simulation::gradientClipping                               */
+  double gradient_clipping_threshold;
+  int pd_iter_cap;                  /* <0: (-log10(forward_tol))*150 as Simulation.cpp:1182       */
+  int adjoint_iter_cap;             /* <=0: 400 as Simulation.cpp:1562                            */
+  /* inner block-Jacobi PCG (replaces SimplicialLLT::solve, Simulation.cpp:1267 / :1577) */
+  double cg_rel_tol;                /* stop when |r|_{D^-1} <= cg_rel_tol * |r0|_{D^-1}; <=0: 1e-4 */
+  int cg_max_iter;                  /* <=0: 500                                                   */
+  /* fp32 floor guard: leave the PD / adjoint loop when the update norm has not improved by 1 % for this many
+   * consecutive iterations (the reference's 1e-9..1e-10 thresholds are below fp32 resolution); the best
+   * iterate is returned and dc_step_stats::converged reads 2.  <=0: 40                                    */
+  int stall_window;
+} dc_params;
+
+/* Per-rollout statistics of one forward step (ForwardInformation::converged/convergeIter). */
+typedef struct dc_step_stats {
+  int converged;         /* 1: tolerance met; 2: stalled at the fp32 floor, best iterate returned; 0: cap hit */
+  int pd_iters;
+  int cg_iters;          /* total inner PCG iterations over the step */
+  int prim_contacts;
+  int self_contacts;
+  float last_xdiff;      /* |x_new - x_now|_2 / N of the final iteration */
+} dc_step_stats;
+
+/* Per-rollout statistics of one backward step (BackwardInformation::converged/backwardIters). */
+typedef struct dc_bwd_stats {
+  int converged;         /* 1: tolerance met; 2: stalled at the fp32 floor; 0: cap hit (reference falls back to SparseLU) */
+  int adjoint_iters;
+  int cg_iters;
+  int clipped;
+  float last_udiff;
+} dc_bwd_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+/* device_id >= 0: HIP device; fails with DC_ERR_HIP when no device is present — there is no CPU compute path.
+ * device_id == -1: host-only context for building / inspecting the constraint system (dc_set_*, dc_build,
+ * dc_get_counts/system_matrix/vertex_data); every batch or step call on it fails with DC_ERR_STATE.      */
+int dc_create(int device_id, dc_ctx **out);
+int dc_destroy(dc_ctx *ctx);
+const char *dc_last_error(const dc_ctx *ctx);
+const char *dc_version(void);
+
+/* ---- system definition: replaces createClothMeshFromModel/…FromConfig (Simulation.cpp:2170-2255,
+ *      2611-2757), createBendingConstraints (:2096-2131), updateCollisionRadii (:2407-2431),
+ *      updateAreaMatrix/updateMassMatrix (:2894-2966), initializePrefactoredMatrices (:2969-3059).
+ *      The caller passes the already oriented / normalised rest positions.                           */
+int dc_set_mesh(dc_ctx *ctx, int num_vertices, const double *rest_pos /*3N*/, int num_triangles, const int *tris /*3T*/);
+int dc_set_attachments(dc_ctx *ctx, int num_fixed, const int *vertex /*Af*/);   /* SystemMatrix::attachments */
+int dc_set_params(dc_ctx *ctx, const dc_params *p);
+int dc_set_primitives(dc_ctx *ctx, int count, const dc_primitive *prims);       /* Simulation::primitives */
+int dc_build(dc_ctx *ctx);      /* (re)assemble A, P = M + h^2 A^T A and upload; call after any of the setters */
+void dc_default_params(dc_params *p);
+
+/* sizes: N, T, E (bending flaps), Af, nnz(P), constraint rows (6T + 3E + 3Af) */
+int dc_get_counts(const dc_ctx *ctx, int *out6);
+/* host-side tables for inspection / parity tests: scalar P in CSR; per-vertex mass, area, radii */
+int dc_get_system_matrix(const dc_ctx *ctx, int *row_ptr /*N+1*/, int *col /*nnz*/, double *val /*nnz*/);
+int dc_get_vertex_data(const dc_ctx *ctx, double *mass, double *area, double *radii);
+
+/* ---- batch state ---------------------------------------------------------------------------------- */
+/* B independent rollouts sharing the system; tape_steps = how many forward steps can be recorded. */
+int dc_alloc_batch(dc_ctx *ctx, int batch, int tape_steps);
+/* Simulation::resetSystem / stepNN's state injection (Simulation.cpp:1020-1030): write slot `slot`. */
+int dc_set_state(dc_ctx *ctx, int slot, const double *x /*B*3N*/, const double *v /*B*3N*/);
+int dc_get_state(dc_ctx *ctx, int slot, double *x, double *v);
+/* per-rollout friction coefficient per primitive group: mu[b*num_groups + g]; NULL restores the defaults */
+int dc_set_mu(dc_ctx *ctx, const double *mu);
+/* uniform external force added to every vertex of rollout b during the NEXT forward steps (wind*windNorm*
+ * windFactor of fillForces, Simulation.cpp:96-105): f[b*3+d]; NULL = none                              */
+int dc_set_uniform_force(dc_ctx *ctx, const double *f);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* Simulation::step()/stepNN() (Simulation.cpp:1020-1428): advance slot -> slot+1 for all rollouts.
+ * fixed_pts: rlFixedPointPos per rollout, B*3Af (NULL: keep the previous targets / rest positions).
+ * stats (optional, length B) is filled after synchronising; pass NULL to stay asynchronous.            */
+int dc_step_forward(dc_ctx *ctx, int slot, const double *fixed_pts, dc_step_stats *stats);
+/* ForwardInformation fields of the step that produced `slot` (f, r): B*3N each; NULL to skip. */
+int dc_get_record(dc_ctx *ctx, int slot, double *f, double *r);
+/* per-vertex primitive contact of that step: group id or -1 (B*N) and contact normal (B*3N) */
+int dc_get_contacts(dc_ctx *ctx, int slot, int *prim_group, double *normal);
+
+/* Simulation::stepBackward()/stepBackwardNN() (Simulation.cpp:1443-1780) through the step that produced
+ * `slot` (forwardInfo_new = record `slot`). Inputs B*3N each; dL_dxinit/dL_dvinit may be NULL (zeros).
+ * Outputs: dL_dx, dL_dv (B*3N), dL_dxfixed (B*3Af, may be NULL), dL_dmu (B*num_groups, may be NULL).    */
+int dc_step_backward(dc_ctx *ctx, int slot, const double *dL_dxnew, const double *dL_dvnew,
+                     const double *dL_dxinit, const double *dL_dvinit, int is_start, double *dL_dx,
+                     double *dL_dv, double *dL_dxfixed, double *dL_dmu, dc_bwd_stats *stats);
+
+/* ---- device-resident rollouts (no host copies inside; used by bench.py and batched callers) --------- */
+/* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Asynchronous.   */
+int dc_rollout_forward(dc_ctx *ctx, int slot, int nsteps);
+/* Seed the carried gradient (dL_dx, dL_dv) on the device: g_x = scale_x * (x[slot] - target), g_v = 0
+ * (the MATCH-shape loss gradient of Simulation.cpp:3237-3488); target NULL means the rest shape.        */
+int dc_seed_gradient(dc_ctx *ctx, int slot, const double *target /*3N or NULL*/, double scale_x);
+/* nsteps backward steps from record `slot` down to slot-nsteps+1, carrying (dL_dx, dL_dv) on the device
+ * exactly as Simulation::runBackwardTask does (Simulation.cpp:3938-3952). Asynchronous.                 */
+int dc_rollout_backward(dc_ctx *ctx, int slot, int nsteps);
+int dc_get_gradient(dc_ctx *ctx, double *dL_dx, double *dL_dv, double *dL_dmu /*B*num_groups or NULL*/);
+int dc_get_stats(dc_ctx *ctx, int slot, dc_step_stats *fwd /*B or NULL*/, dc_bwd_stats *bwd /*B or NULL*/);
+int dc_sync(dc_ctx *ctx);
+/* HIP-event timing of everything enqueued between the two calls on the context's stream (ms). */
+int dc_timer_start(dc_ctx *ctx);
+int dc_timer_stop(dc_ctx *ctx, float *ms);
+/* accumulated device time (ms) and launch count of the forward / backward step kernels since the last
+ * reset, measured with HIP events on the context's stream; used by bench.py's roofline block.          */
+int dc_kernel_times(dc_ctx *ctx, float *fwd_ms, int *fwd_launches, float *bwd_ms, int *bwd_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFCLOTH_HIP_H */

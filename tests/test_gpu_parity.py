@@ -1,0 +1,220 @@
+"""GPU parity: the HIP step (through the C-ABI, diffcloth_amd.capi -> libdiffcloth_hip.so) against the fp64
+oracle on identical, fp32-representable inputs (teacher-forced single steps).
+
+Stated fp32 tolerances (BASELINE.json: "within a stated fp32 tolerance", gradients within 1e-4 rel-err):
+  positions   max_i |x_gpu - x_ref|_inf <= 1e-5 * L          L = scene scale (cloth size, 4.5)
+  velocities  |v_gpu - v_ref|_2 / max(|v_ref|_2, 1) <= 2e-4
+  gradients   |g_gpu - g_ref|_2 / |g_ref|_2 <= 1e-4          vs the oracle's direct adjoint solve
+"""
+import numpy as np
+import pytest
+
+import meshes
+import orc
+from diffcloth_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+L_SCENE = 4.5
+POS_TOL = 1e-5 * L_SCENE
+VEL_TOL = 2e-4
+GRAD_TOL = 1e-4
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def build_pair(nx, mu=0.4, att=(), h=1 / 180, k_stretch=150.0, k_bend=0.05, density=0.3, fwd_tol=1e-9,
+               bwd_tol=1e-9, cap=-1, cg_tol=1e-6, clip=False, radius=2.0, ny=None):
+    V, F = meshes.grid_cloth(nx, ny or nx, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    c = f32(meshes.sphere_scene_center(V, radius))
+    o = orc.Oracle(V, F, h=h, density=density, k_stretch=k_stretch, k_bend=k_bend, fwd_tol=fwd_tol, bwd_tol=bwd_tol,
+                   attachments=att, selfcollision=False, pd_iter_cap=cap, gradient_clipping=clip)
+    o.add_sphere(c, radius, mu)
+    o.build()
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_attachments(att)
+    e.set_params(time_step=h, density=density, k_stretch=k_stretch, k_bend=k_bend, forward_tol=fwd_tol,
+                 backward_tol=bwd_tol, pd_iter_cap=cap, cg_rel_tol=cg_tol, cg_max_iter=2000,
+                 gradient_clipping=int(clip), selfcollision_enabled=0)
+    e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=c, radius=radius, mu=mu)])
+    e.build()
+    return V, F, o, e
+
+
+def settle(o, V, steps, xf=None, tol=1e-7):
+    """Advance with the oracle at a loose tolerance to reach an interesting (draped, in-contact) state."""
+    saved = o.params["fwd_tol"]
+    o.set(fwd_tol=tol)
+    o.build()
+    x = V.reshape(-1).copy()
+    v = np.zeros_like(x)
+    for s in range(steps):
+        out = o.step(x, v, xf)
+        x, v = out["x"], out["v"]
+    o.set(fwd_tol=saved)
+    o.build()
+    return f32(x), f32(v)
+
+
+def test_forward_step_matches_oracle_with_contact():
+    V, F, o, e = build_pair(13, mu=0.4)
+    x0, v0 = settle(o, V, 50)
+    ref = o.step(x0, v0)
+    assert ref["converged"] and ref["nprim"] > 10
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    st = e.step_forward(0)
+    x1, v1 = e.get_state(1)
+    assert st["converged"][0] in (1, 2)
+    assert st["prim_contacts"][0] == ref["nprim"]
+    dx = np.abs(x1[0] - ref["x"]).max()
+    dv = np.linalg.norm(v1[0] - ref["v"]) / max(np.linalg.norm(ref["v"]), 1.0)
+    print(f"\n[fwd contact] pd_iters gpu {st['pd_iters'][0]} ref {ref['iters']}  cg {st['cg_iters'][0]}  max|dx| {dx:.3e}  rel dv {dv:.3e}")
+    assert dx <= POS_TOL and dv <= VEL_TOL
+    # record fields
+    f, r = e.get_record(1)
+    rf, rr = o.record_fr(ref["id"])
+    assert np.linalg.norm(f[0] - rf) <= 1e-3 * np.linalg.norm(rf)
+    assert np.linalg.norm(r[0] - rr) <= 2e-3 * max(np.linalg.norm(rr), 1e-6)
+    grp, nrm = e.get_contacts(1)
+    con = o.prim_contacts(ref["id"])
+    assert set(np.nonzero(grp[0] >= 0)[0].tolist()) == set(con["particle"].tolist())
+    np.testing.assert_allclose(nrm[0].reshape(-1, 3)[con["particle"]], con["normal"], atol=2e-6)
+
+
+def test_forward_iterates_track_reference_sequence():
+    """Same number of PD iterations on both sides (cap reached): the iterate sequence itself matches."""
+    K = 12
+    V, F, o, e = build_pair(11, mu=0.2, fwd_tol=1e-30, cap=K, cg_tol=1e-7)
+    x0, v0 = settle(o, V, 45)
+    ref = o.step(x0, v0)
+    assert ref["iters"] == K and not ref["converged"]
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    st = e.step_forward(0)
+    assert st["pd_iters"][0] == K and st["converged"][0] == 0
+    x1, v1 = e.get_state(1)
+    dx = np.abs(x1[0] - ref["x"]).max()
+    print(f"\n[iterate parity] K={K} max|dx| {dx:.3e}")
+    assert dx <= POS_TOL
+
+
+def test_forward_free_fall_and_attachments():
+    V, F, o, e = build_pair(9, att=(0, 8), k_bend=0.2)
+    xf = f32(V[[0, 8]].reshape(-1) + np.array([0.05, 0.1, -0.02, -0.03, 0.08, 0.04]))
+    x0, v0 = settle(o, V, 10, xf)
+    ref = o.step(x0, v0, xf)
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    st = e.step_forward(0, fixed_pts=xf)
+    x1, v1 = e.get_state(1)
+    dx = np.abs(x1[0] - ref["x"]).max()
+    dv = np.linalg.norm(v1[0] - ref["v"]) / max(np.linalg.norm(ref["v"]), 1.0)
+    print(f"\n[fwd attach] pd_iters gpu {st['pd_iters'][0]} ref {ref['iters']} max|dx| {dx:.3e} rel dv {dv:.3e}")
+    assert st["converged"][0] in (1, 2) and dx <= POS_TOL and dv <= VEL_TOL
+
+
+@pytest.mark.parametrize("mu", [0.05, 0.9])
+def test_backward_step_matches_oracle(mu):
+    V, F, o, e = build_pair(11, mu=mu, att=(0, 10))
+    xf = f32(V[[0, 10]].reshape(-1) + 0.02)
+    x0, v0 = settle(o, V, 50, xf)
+    ref = o.step(x0, v0, xf)
+    assert ref["nprim"] > 5
+    rng = np.random.default_rng(3)
+    gx = f32(rng.standard_normal(x0.size)); gv = f32(rng.standard_normal(x0.size) * 0.01)
+    rb = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    e.step_forward(0, fixed_pts=xf)
+    gb = e.step_backward(1, gx, gv, is_start=False)
+    assert gb["converged"][0] in (1, 2)
+
+    def rel(a, b):
+        return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    ex, ev = rel(gb["dL_dx"][0], rb["dL_dx"]), rel(gb["dL_dv"][0], rb["dL_dv"])
+    ef = rel(gb["dL_dxfixed"][0], rb["dL_dxfixed"])
+    em = abs(gb["dL_dmu"][0, 0] - rb["dL_dmu"][0]) / max(abs(rb["dL_dmu"][0]), 1e-12)
+    types = o.prim_contacts(ref["id"])["type"]
+    print(f"\n[bwd mu={mu}] adjoint iters {gb['adjoint_iters'][0]} cg {gb['cg_iters'][0]} rel err dx {ex:.2e} dv {ev:.2e} dxfixed {ef:.2e} dmu {em:.2e}"
+          f" (stick {np.sum(types == 1)}, slide {np.sum(types == 2)}, takeoff {np.sum(types == 0)})")
+    assert ex <= GRAD_TOL and ev <= GRAD_TOL and ef <= GRAD_TOL
+    if abs(rb["dL_dmu"][0]) > 1e-8:
+        assert em <= 5e-3      # a signed sum over the sliding contacts: cancellation amplifies fp32 rounding
+
+
+def test_batch_of_rollouts_each_matches_its_own_oracle_run():
+    B = 5
+    V, F, o, e = build_pair(9, mu=0.3)
+    rng = np.random.default_rng(0)
+    X0, V0, MU = [], [], []
+    for b in range(B):
+        shift = f32(rng.uniform(-0.2, 0.2, 3) * np.array([1, 0, 1]))
+        Vb = f32(V + shift)
+        o2 = o
+        x = Vb.reshape(-1).copy(); v = np.zeros_like(x)
+        o2.set(fwd_tol=1e-7); o2.build()
+        for s in range(40 + 3 * b):
+            out = o2.step(x, v); x, v = out["x"], out["v"]
+        X0.append(f32(x)); V0.append(f32(v)); MU.append(0.1 + 0.2 * b)
+    o.set(fwd_tol=1e-9); o.build()
+    e.alloc_batch(B, 1)
+    e.set_mu(np.array(MU).reshape(B, 1))
+    e.set_state(0, np.stack(X0), np.stack(V0))
+    st = e.step_forward(0)
+    x1, v1 = e.get_state(1)
+    rng = np.random.default_rng(9)
+    gx = f32(rng.standard_normal((B, X0[0].size))); gv = np.zeros_like(gx)
+    gb = e.step_backward(1, gx, gv, is_start=True)
+    for b in range(B):
+        o.set_mu(0, MU[b])
+        ref = o.step(X0[b], V0[b])
+        assert st["prim_contacts"][b] == ref["nprim"]
+        assert np.abs(x1[b] - ref["x"]).max() <= POS_TOL
+        rb = o.step_backward(ref["id"], gx[b], gv[b], is_start=True, direct=True)
+        err = np.linalg.norm(gb["dL_dx"][b] - rb["dL_dx"]) / np.linalg.norm(rb["dL_dx"])
+        assert err <= GRAD_TOL, (b, err)
+    assert len(set(st["pd_iters"].tolist())) > 1      # rollouts converge independently
+
+
+def test_gradient_clipping_matches_reference():
+    V, F, o, e = build_pair(7, clip=True)
+    x0, v0 = settle(o, V, 20)
+    ref = o.step(x0, v0)
+    n = x0.size // 3
+    gx = np.full(x0.size, 100.0)           # |g| = 100 sqrt(3N) = 1212 > 16 N = 784 for N = 49
+    assert np.linalg.norm(gx) > 16.0 * n
+    gv = np.zeros_like(gx)
+    rb = o.step_backward(ref["id"], gx, gv, is_start=True, direct=True)
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    e.step_forward(0)
+    gb = e.step_backward(1, gx, gv, is_start=True)
+    assert gb["clipped"][0] == 1
+    err = np.linalg.norm(gb["dL_dx"][0] - rb["dL_dx"]) / np.linalg.norm(rb["dL_dx"])
+    assert err <= GRAD_TOL
+
+
+def test_rollout_on_device_equals_stepwise_calls():
+    V, F, o, e = build_pair(9, fwd_tol=1e-6, bwd_tol=1e-6)
+    S = 6
+    x0 = f32(V.reshape(-1)); v0 = np.zeros_like(x0)
+    e.alloc_batch(2, S)
+    X = np.stack([x0, x0 + f32(np.tile([0.1, 0.0, 0.05], x0.size // 3))])
+    e.set_state(0, X, np.zeros_like(X))
+    e.rollout_forward(0, S)
+    xa, va = e.get_state(S)
+    for s in range(S):
+        e.step_forward(s)
+    xb, vb = e.get_state(S)
+    np.testing.assert_array_equal(xa, xb)      # same kernels, same inputs: bitwise identical
+    e.seed_gradient(S, None, 1.0)
+    e.rollout_backward(S, S)
+    dx, dv, dmu = e.get_gradient()
+    assert np.isfinite(dx).all() and np.isfinite(dv).all() and np.abs(dx).max() > 0
+    kt = e.kernel_times()
+    assert kt["fwd_launches"] == S and kt["bwd_launches"] == S and kt["fwd_ms"] > 0

@@ -1,0 +1,83 @@
+"""CPU-side checks of the product's host logic: the constraint-system builder inside libdiffcloth_hip.so
+(diffcloth_amd/csrc/dc_system.cpp) must produce the same tables as the fp64 oracle's independent restatement
+of Simulation::initializePrefactoredMatrices (reference Simulation.cpp:2969-3059), and the library must export
+every symbol include/diffcloth_hip.h declares. No compute call is made here (no GPU needed).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import meshes
+import orc
+from diffcloth_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    header = open(os.path.join(ROOT, "include", "diffcloth_hip.h")).read()
+    declared = set(re.findall(r"\b(dc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dc_version()
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by the C declarations (x86-64 SysV): guards the ctypes mirrors in capi.py
+    assert ctypes.sizeof(capi.dc_primitive) == 4 + 4 + 24 + 24 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(capi.dc_step_stats) == 24 and ctypes.sizeof(capi.dc_bwd_stats) == 20
+    assert ctypes.sizeof(capi.dc_params) == 8 * 5 + 24 + 16 + 16 + 8 + 8 + 8 + 8   # trailing cg_max_iter + stall_window share 8 bytes
+
+
+@pytest.mark.parametrize("shape", [(6, 5), (13, 13), (4, 9)])
+def test_system_tables_match_oracle(shape):
+    nx, ny = shape
+    V, F = meshes.grid_cloth(nx, ny, 4.5, 3.5, "DOWN")
+    rng = np.random.default_rng(5)
+    V = V + 0.03 * rng.standard_normal(V.shape)     # irregular rest shape: non-trivial cotan weights
+    att = [0, nx - 1]
+    prm = dict(h=1 / 120, density=0.27, k_stretch=321.0, k_bend=0.4, k_att=5000.0)
+    o = orc.Oracle(V, F, attachments=att, **prm).build()
+    e = capi.Engine(device=-1)       # host-only context: system building / inspection
+    e.set_mesh(V, F)
+    e.set_attachments(att)
+    e.set_params(time_step=prm["h"], density=prm["density"], k_stretch=prm["k_stretch"], k_bend=prm["k_bend"], k_att=prm["k_att"])
+    e.build()
+    assert (e.N, e.T, e.E, e.Af) == (o.N, o.T, o.E, o.Af)
+    assert e.rows == 6 * o.T + 3 * o.E + 3 * o.Af
+    ptr, col, val = e.system_matrix()
+    optr, ocol, oval = o.P_csr()
+    np.testing.assert_array_equal(ptr, optr)
+    np.testing.assert_array_equal(col, ocol)
+    np.testing.assert_allclose(val, oval, rtol=1e-11, atol=1e-14)
+    m, a, r = e.vertex_data()
+    om, oa, orad = o.vertex_data()
+    np.testing.assert_allclose(m, om, rtol=1e-13)
+    np.testing.assert_allclose(a, oa, rtol=1e-13)
+    np.testing.assert_allclose(r, orad, rtol=1e-13)
+
+
+def test_host_only_context_refuses_compute():
+    V, F = meshes.grid_cloth(4, 4)
+    e = capi.Engine(device=-1)
+    e.set_mesh(V, F)
+    e.build()
+    with pytest.raises(capi.DcError, match="no CPU compute path"):
+        e.alloc_batch(1, 1)
+
+
+def test_bad_inputs_are_rejected():
+    e = capi.Engine(device=-1)
+    with pytest.raises(capi.DcError):
+        e.set_mesh(np.zeros((3, 3)), [[0, 1, 5]])            # index out of range
+    V, F = meshes.grid_cloth(3, 3)
+    F2 = np.vstack([F, F[:1], F[:1]])                        # an edge shared by three triangles
+    with pytest.raises(capi.DcError, match="non-manifold"):
+        e.set_mesh(V, F2)
+    with pytest.raises(capi.DcError):
+        e.build()                                            # no valid mesh
