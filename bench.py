@@ -40,7 +40,8 @@ def make_engine(device, args, V, F, center):
     e.set_mesh(V, F)
     e.set_params(time_step=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_tol=args.fwd_tol,
                  backward_tol=args.bwd_tol, cg_rel_tol=args.cg_tol, cg_max_iter=args.cg_max,
-                 gradient_clipping=1, selfcollision_enabled=0)
+                 gradient_clipping=1, selfcollision_enabled=0, adjoint_mode=args.adjoint_mode,
+                 adjoint_rel_tol=args.adjoint_rel_tol)
     e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=center, radius=2.0, mu=0.9)])
     e.build()
     return e
@@ -94,6 +95,9 @@ def main():
     ap.add_argument("--bwd-tol", dest="bwd_tol", type=float, default=5e-4)   # every scene table
     ap.add_argument("--cg-tol", dest="cg_tol", type=float, default=1e-4)
     ap.add_argument("--cg-max", dest="cg_max", type=int, default=500)
+    ap.add_argument("--adjoint-mode", dest="adjoint_mode", type=int, default=1,
+                    help="1: direct adjoint solve (reference's solveDirect semantics); 0: reference fixed-point iteration")
+    ap.add_argument("--adjoint-rel-tol", dest="adjoint_rel_tol", type=float, default=1e-6)
     ap.add_argument("--cpu-steps", type=int, default=2, help="steps of the CPU baseline sample (0 disables)")
     args = ap.parse_args()
 
@@ -129,7 +133,9 @@ def main():
 
     # warm-up: W untimed forward steps (contact onset) + one untimed backward step
     e.rollout_forward(0, W)
-    e.seed_gradient(W, None, 1.0)
+    # loss gradient of MATCH_TRAJECTORY (Simulation.cpp:3260-3274): dL/dx = 2 (x - target) / (frames * N)
+    gscale = 2.0 / ((K + 1) * e.N)
+    e.seed_gradient(W, None, gscale)
     if W > 0:
         e.rollout_backward(W, 1)
     e.sync()
@@ -138,7 +144,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     e.rollout_forward(W, K)                 # K forward steps, tape on the device
-    e.seed_gradient(W + K, None, 1.0)       # dL/dx_K of the match-shape loss, on the device
+    e.seed_gradient(W + K, None, gscale)    # dL/dx_K of the match-trajectory loss, on the device
     e.rollout_backward(W + K, K)            # K backward steps
     e.sync()
     barrier()
@@ -176,7 +182,8 @@ def main():
             "config": {"workload": f"C4 grid {args.grid}x{args.grid} cloth (N={N}, T={e.T}, E={e.E}) on sphere r=2, "
                                    f"h=1/{round(1 / args.h)}, primitive Signorini-Coulomb contact",
                        "rollouts_per_gpu": B, "rollouts_total": world * B, "fwd_tol": args.fwd_tol,
-                       "bwd_tol": args.bwd_tol, "cg_rel_tol": args.cg_tol,
+                       "bwd_tol": args.bwd_tol, "cg_rel_tol": args.cg_tol, "adjoint_mode": args.adjoint_mode,
+                       "adjoint_rel_tol": args.adjoint_rel_tol,
                        "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
                        "mean_adjoint_iters_per_step": adj / (B * K), "converged_fraction": conv / (B * K),
                        "batch_steps_per_s": world * K / dt, "gradients_finite": finite,

@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libdiffcloth_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-ENGINE_SOURCES = ["dc_kernels.hip", "dc_engine.hip", "dc_system.cpp"]
+ENGINE_SOURCES = ["dc_forward.hip", "dc_adjoint.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp"]
 
 
 def _stale(target, deps):
@@ -26,7 +26,7 @@ def _stale(target, deps):
 def build_engine(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in ENGINE_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("dc_device.h", "dc_system.h")] + [os.path.join(ROOT, "include", "diffcloth_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("dc_device.h", "dc_devlib.h", "dc_system.h")] + [os.path.join(ROOT, "include", "diffcloth_hip.h")]
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",

@@ -30,7 +30,8 @@ class dc_params(C.Structure):
                 ("backward_tol", C.c_double), ("gravity_enabled", C.c_int), ("contact_enabled", C.c_int),
                 ("selfcollision_enabled", C.c_int), ("gradient_clipping", C.c_int),
                 ("gradient_clipping_threshold", C.c_double), ("pd_iter_cap", C.c_int), ("adjoint_iter_cap", C.c_int),
-                ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int)]
+                ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int),
+                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double)]
 
 
 class dc_step_stats(C.Structure):
@@ -39,7 +40,7 @@ class dc_step_stats(C.Structure):
 
 
 class dc_bwd_stats(C.Structure):
-    _fields_ = [("converged", C.c_int), ("adjoint_iters", C.c_int), ("cg_iters", C.c_int), ("clipped", C.c_int),
+    _fields_ = [("converged", C.c_int), ("adjoint_iters", C.c_int), ("cg_iters", C.c_int), ("clipped", C.c_int), ("used_direct", C.c_int),
                 ("last_udiff", C.c_float)]
 
 
@@ -237,7 +238,7 @@ class Engine:
         self._chk(self.lib.dc_step_backward(self.h, C.c_int(slot), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
                                             _d(dx), _d(dv), _d(dxf), _d(dmu), st))
         out = dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:, :3 * self.Af], dL_dmu=dmu)
-        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "last_udiff"]))
+        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff"]))
         return out
 
     # ---- device-resident rollouts ----
@@ -260,7 +261,7 @@ class Engine:
         f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()
         self._chk(self.lib.dc_get_stats(self.h, C.c_int(slot), f, b))
         return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff"]),
-                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "last_udiff"]))
+                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff"]))
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))

@@ -1,0 +1,321 @@
+// CDNA4 (gfx950) adjoint kernel: Simulation::stepBackward() (reference Simulation.cpp:1455-1780), one
+// workgroup per rollout, matrix-free.
+//
+//   reference fixed point   P u = g + dP^T u,  dP^T u = h^2 (dp/dx)^T A y - C^T w,  w = dr_df^T u,  y = u + w
+//   adjoint operator        K u := (P - dP^T) u = M u + h^2 (A - dp/dx)^T A y          (C = h^2 A^T A, P = M + C)
+//
+// The sparse Jacobian dproj_dxnew of the reference (66 % of its backward time, serial triplet assembly) is
+// never formed: the per-element blocks are re-derived from x_new in registers and applied on the fly, and the
+// contact Jacobian dr_df is applied per contact from (n, d, mu).
+//
+// Two solvers for K u = g:
+//   mode 0  the reference's iteration (Simulation.cpp:1561-1600): u <- u + P^-1 (g - K u) with the block-Jacobi
+//           PCG of the forward pass for P^-1, stop on |u_new - u|_2 / N < backwardConvergenceThreshold; when the
+//           cap is reached it falls back to the direct solve, as the reference does with SparseLU (:1589-1594);
+//   mode 1  direct solve (semantics of backwardGradientForceDirectSolver / solveDirect, Simulation.cpp:1431-1440):
+//           block-Jacobi preconditioned BiCGSTAB on K itself, relative residual <= adjoint_rel_tol.
+#include "dc_devlib.h"
+
+namespace dc {
+
+namespace {
+
+// two simultaneous workgroup sums
+template <int THREADS>
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) { red[w] = a; red[THREADS / 64 + w] = b; }
+  __syncthreads();
+  double sa = 0, sb = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; k++) { sa += red[k]; sb += red[THREADS / 64 + k]; }
+  a = sa; b = sb;
+}
+
+struct AdjCtx {
+  const float *xnew, *rec_f, *rec_n, *mu;
+  const int *rec_prim;
+  float *y, *corner;
+};
+
+// w = dr_df^T z for the (block-diagonal) primitive contacts: Simulation::calculatedr_df (Simulation.cpp:700-711)
+__device__ __forceinline__ f3 contact_JT(const DevSystem &S, const AdjCtx &C, int i, f3 z) {
+  const int prim = C.rec_prim[i];
+  if (prim < 0) return mk(0, 0, 0);
+  const int N = S.N;
+  f3 n = ld3(C.rec_n, i, N);
+  f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];
+  return dri_dfi_T(n, d, C.mu[S.prims[prim].group], z);
+}
+
+// out = K z with z = zin (optionally scaled by D^-1: right preconditioning). Also returns the partial sums
+// of out.d1 and out.out of this thread (d1 may be null). Ends WITHOUT a barrier: callers reduce next.
+template <int THREADS>
+__device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
+                                                 float *out, const float *d1, float &dot1, float &dot2) {
+  const int N = S.N, T = S.T, E = S.E, NC = S.NC, tid = threadIdx.x;
+  const float h2 = S.h * S.h;
+  float *y = C.y, *corner = C.corner;
+  const float *xnew = C.xnew;
+  // ---- y = (I + dr_df)^T z ----
+  for (int i = tid; i < N; i += THREADS) {
+    f3 z = ld3(zin, i, N);
+    if (precond) z = z * S.dinv[i];
+    st3(y, i, N, z + contact_JT(S, C, i, z));
+  }
+  __syncthreads();
+  // ---- per element: h^2 (A - dp/dx)^T A y ----
+  // triangles: Triangle::projectToManifoldBackward (Triangle.cpp:354-451) in closed form:
+  //   dT(Y) = TJ <TJ,Y> / tr(S) + (I - T T^T) Y S^-1,   TJ = [t1, -t0]
+  for (int t = tid; t < T; t += THREADS) {
+    const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+    const float4 D = S.tri_D[t];
+    f3 x0 = ld3(xnew, i0, N);
+    f3 e0 = ld3(xnew, i1, N) - x0, e1 = ld3(xnew, i2, N) - x0;
+    Polar P = polar3x2(e0 * D.x + e1 * D.z, e0 * D.y + e1 * D.w);
+    f3 q0 = ld3(y, i0, N);
+    f3 d0 = ld3(y, i1, N) - q0, d1v = ld3(y, i2, N) - q0;
+    f3 y0 = d0 * D.x + d1v * D.z, y1 = d0 * D.y + d1v * D.w;
+    const float c = (dot(P.t1, y0) - dot(P.t0, y1)) / P.trS;
+    f3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
+    z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
+    z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
+    const float s = h2 * S.tri_w2[t];
+    f3 r0 = (y0 - (P.t1 * c + z0)) * s, r1 = (y1 - (z1 - P.t0 * c)) * s;
+    f3 c1 = r0 * D.x + r1 * D.y, c2 = r0 * D.z + r1 * D.w;
+    st3(corner, t, NC, mk(0, 0, 0) - c1 - c2); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
+  }
+  // bending: TriangleBending::backwardGradient (TriangleBending.cpp:154-172)
+  for (int e = tid; e < E; e += THREADS) {
+    const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+    const float4 w = S.bend_w[e];
+    const float2 nw = S.bend_nw[e];
+    f3 q0 = ld3(y, i0, N);
+    f3 ey = (ld3(y, i1, N) - q0) * w.y + (ld3(y, i2, N) - q0) * w.z + (ld3(y, i3, N) - q0) * w.w;
+    f3 res = ey;
+    if (nw.x > 1e-6f) {
+      f3 x0 = ld3(xnew, i0, N);
+      f3 ev = (ld3(xnew, i1, N) - x0) * w.y + (ld3(xnew, i2, N) - x0) * w.z + (ld3(xnew, i3, N) - x0) * w.w;
+      float en = sqrtf(dot(ev, ev));
+      f3 eh = ev * (1.0f / en);
+      res = ey - (ey - eh * dot(eh, ey)) * (nw.x / en);
+    }
+    res = res * (h2 * nw.y);
+    const int base = 3 * T;
+    st3(corner, base + e, NC, res * w.x); st3(corner, base + E + e, NC, res * w.y);
+    st3(corner, base + 2 * E + e, NC, res * w.z); st3(corner, base + 3 * E + e, NC, res * w.w);
+  }
+  __syncthreads();
+  // ---- vertex gather: out = M z + sum(corners) + attachment term ----
+  dot1 = 0.f; dot2 = 0.f;
+  for (int i = tid; i < N; i += THREADS) {
+    f3 z = ld3(zin, i, N);
+    if (precond) z = z * S.dinv[i];
+    f3 o = z * S.mass[i];
+    const int k1 = S.inc_ptr[i + 1];
+    for (int k = S.inc_ptr[i]; k < k1; k++) o = o + ld3(corner, S.inc_idx[k], NC);
+    if (S.att_of_vertex[i] >= 0) o = o + ld3(y, i, N) * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
+    st3(out, i, N, o);
+    if (d1) dot1 += dot(o, ld3(d1, i, N));
+    dot2 += dot(o, o);
+  }
+}
+
+}  // namespace
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_adjoint_step(DevSystem S, DevWork W, BwdArgs A) {
+  __shared__ double red[2 * (THREADS / 64)];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = S.N;
+  const size_t off = (size_t) b * 3 * N;
+  AdjCtx C;
+  C.xnew = A.x_new + off; C.rec_f = A.rec_f + off; C.rec_n = A.rec_n + off;
+  C.rec_prim = A.rec_prim + (size_t) b * N;
+  C.mu = A.mu + (size_t) b * S.ngroups;
+  C.y = W.vbest + off; C.corner = W.corner + (size_t) b * 3 * S.NC;
+  float *gx = A.gx + off, *gv = A.gv + off;
+  float *gin = W.g + off, *u = W.vnow + off;
+  float *cg_r = W.cg_r + off, *cg_p = W.cg_p + off, *cg_ap = W.cg_ap + off, *cg_x = W.cg_x + off;
+  const float h = S.h, h2 = S.h * S.h;
+
+  // ---- gradient clipping (Simulation.cpp:1460-1466) and u = 0 ----
+  float part = 0.f;
+  for (int i = tid; i < N; i += THREADS) { f3 q = ld3(gx, i, N); part += dot(q, q); }
+  double gnorm = sqrt(block_sum<THREADS>((double) part, red));
+  float gscale = 1.f;
+  int clipped = 0;
+  if (A.clip && gnorm > (double) A.clip_thr * N) { gscale = (float) ((double) A.clip_thr * N / gnorm); clipped = 1; gnorm = (double) A.clip_thr * N; }
+  for (int i = tid; i < N; i += THREADS) {
+    st3(gin, i, N, ld3(gx, i, N) * gscale);
+    st3(u, i, N, mk(0, 0, 0));
+  }
+  int status = 0;          // 1 converged, 2 stalled at the fp32 floor, 0 cap hit
+  int iters = 0, cg_total = 0, used_direct = 0;
+  double udiff = 0;
+  __syncthreads();
+
+  bool need_direct = (A.mode == 1);
+  if (A.mode == 0 && gnorm > 0) {
+    // ---- the reference's iteration: u <- u + P^-1 (g - K u) ----
+    double min_udiff = 1e300;
+    int since_progress = 0;
+    for (int it = 0; it < A.it_cap; it++) {
+      float d1, d2;
+      adjoint_operator<THREADS>(S, C, u, false, cg_ap, nullptr, d1, d2);
+      part = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        f3 r = ld3(gin, i, N) - ld3(cg_ap, i, N);
+        const float di = S.dinv[i];
+        st3(cg_r, i, N, r);
+        st3(cg_p, i, N, r * di);
+        st3(cg_x, i, N, mk(0, 0, 0));
+        part += dot(r, r) * di;
+      }
+      const double rz = block_sum<THREADS>((double) part, red);
+      cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red);
+      part = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        f3 d = ld3(cg_x, i, N);
+        st3(u, i, N, ld3(u, i, N) + d);
+        part += dot(d, d);
+      }
+      udiff = sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
+      iters = it + 1;
+      if (udiff < (double) A.bwd_tol) { status = 1; break; }
+      if (udiff < 0.99 * min_udiff) since_progress = 0;
+      if (udiff < min_udiff) min_udiff = udiff;
+      if (++since_progress >= A.stall_window) { status = 2; break; }
+    }
+    need_direct = (status == 0);     // cap reached without convergence -> direct solve (Simulation.cpp:1589-1594)
+    __syncthreads();
+  }
+
+  if (need_direct && gnorm > 0) {
+    // ---- block-Jacobi preconditioned BiCGSTAB on K u = g, starting from the current u ----
+    used_direct = 1;
+    float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = gin;
+    float d1, d2;
+    adjoint_operator<THREADS>(S, C, u, false, v, nullptr, d1, d2);
+    part = 0.f;
+    for (int i = tid; i < N; i += THREADS) {
+      f3 q = ld3(gin, i, N) - ld3(v, i, N);
+      st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
+      part += dot(q, q);
+    }
+    double rho = block_sum<THREADS>((double) part, red);   // rhat.r = r.r
+    double rr = rho;
+    const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
+    double best_rr = rr;
+    int since_progress = 0;
+    status = (rr <= stop) ? 1 : 0;
+    const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
+    for (int k = 0; k < kcap && status == 0; k++) {
+      // v = K D^-1 p ;  alpha = rho / (rhat . v)
+      adjoint_operator<THREADS>(S, C, p, true, v, rhat, d1, d2);
+      double rv = block_sum<THREADS>((double) d1, red);
+      if (!(fabs(rv) > 1e-300)) { status = 2; break; }
+      const float alpha = (float) (rho / rv);
+      // s = r - alpha v  (in place)
+      part = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        f3 s = ld3(r, i, N) - ld3(v, i, N) * alpha;
+        st3(r, i, N, s);
+        part += dot(s, s);
+      }
+      double ss = block_sum<THREADS>((double) part, red);
+      iters++;
+      if (ss <= stop) {
+        for (int i = tid; i < N; i += THREADS) st3(u, i, N, ld3(u, i, N) + ld3(p, i, N) * (alpha * S.dinv[i]));
+        rr = ss; status = 1; break;
+      }
+      // t = K D^-1 s ;  omega = (t . s) / (t . t)
+      adjoint_operator<THREADS>(S, C, r, true, t, r, d1, d2);
+      double ts = (double) d1, tt = (double) d2;
+      block_sum2<THREADS>(ts, tt, red);
+      if (!(tt > 1e-300)) { status = 2; break; }
+      const float omega = (float) (ts / tt);
+      // u += alpha D^-1 p + omega D^-1 s ;  r = s - omega t ;  rho_new = rhat . r
+      float pa = 0.f, pb = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        const float di = S.dinv[i];
+        f3 s = ld3(r, i, N);
+        st3(u, i, N, ld3(u, i, N) + (ld3(p, i, N) * alpha + s * omega) * di);
+        f3 rn = s - ld3(t, i, N) * omega;
+        st3(r, i, N, rn);
+        pa += dot(rn, ld3(rhat, i, N));
+        pb += dot(rn, rn);
+      }
+      double rho_new = (double) pa;
+      rr = (double) pb;
+      block_sum2<THREADS>(rho_new, rr, red);
+      if (rr <= stop) { status = 1; break; }
+      if (rr < 0.9 * best_rr) { best_rr = rr; since_progress = 0; }
+      else if (++since_progress >= A.stall_window) { status = 2; break; }
+      if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { status = 2; break; }
+      const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));
+      rho = rho_new;
+      // p = r + beta (p - omega v)
+      for (int i = tid; i < N; i += THREADS) st3(p, i, N, ld3(r, i, N) + (ld3(p, i, N) - ld3(v, i, N) * omega) * beta);
+      __syncthreads();
+    }
+    udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual
+  }
+  __syncthreads();
+  // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650) ----
+  float dmu_part[kMaxPrims];
+#pragma unroll
+  for (int k = 0; k < kMaxPrims; k++) dmu_part[k] = 0.f;
+  float *dxf = A.d_xfixed ? A.d_xfixed + (size_t) b * 3 * S.Af : nullptr;
+  for (int i = tid; i < N; i += THREADS) {
+    f3 ui = ld3(u, i, N);
+    const float m = S.mass[i];
+    f3 w = mk(0, 0, 0);
+    const int prim = C.rec_prim[i];
+    if (prim >= 0) {
+      f3 n = ld3(C.rec_n, i, N);
+      f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * m;
+      const int grp = S.prims[prim].group;
+      w = dri_dfi_T(n, d, C.mu[grp], ui);
+      const float contrib = dot(dri_dmu(n, d, C.mu[grp]), ui) * h;
+#pragma unroll
+      for (int k = 0; k < kMaxPrims; k++) dmu_part[k] += (k == grp) ? contrib : 0.f;
+    }
+    f3 dx = ui * m - ld3(gv, i, N) * (1.0f / h);
+    f3 dv = (ui + w) * (h * m);
+    if (A.ix) dx = dx + ld3(A.ix + off, i, N);
+    if (A.iv) dv = dv + ld3(A.iv + off, i, N);
+    if (!A.is_start) dx = dx + dv * (1.0f / h);
+    st3(gx, i, N, dx);
+    st3(gv, i, N, dv);
+    const int a = S.att_of_vertex[i];
+    if (a >= 0 && dxf) st3(dxf, a, S.Af, (ui + w) * (h2 * S.k_att));   // A_t_dp_dxfixed (Simulation.cpp:3035-3048)
+  }
+  if (A.d_mu) {
+    for (int k = 0; k < S.ngroups; k++) {
+      const double s = block_sum<THREADS>((double) dmu_part[k], red);
+      if (tid == 0) A.d_mu[(size_t) b * S.ngroups + k] += (float) s;
+    }
+  }
+  if (tid == 0) {
+    dc_bwd_stats s;
+    s.converged = status; s.adjoint_iters = iters; s.cg_iters = cg_total; s.clipped = clipped;
+    s.used_direct = used_direct; s.last_udiff = (float) udiff;
+    A.stats[b] = s;
+  }
+}
+
+static int pick_threads_bwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
+
+void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+  switch (pick_threads_bwd(S.N)) {
+    case 256: hipLaunchKernelGGL(k_adjoint_step<256>, dim3(B), dim3(256), 0, st, S, W, A); break;
+    case 512: hipLaunchKernelGGL(k_adjoint_step<512>, dim3(B), dim3(512), 0, st, S, W, A); break;
+    default: hipLaunchKernelGGL(k_adjoint_step<1024>, dim3(B), dim3(1024), 0, st, S, W, A); break;
+  }
+}
+
+}  // namespace dc

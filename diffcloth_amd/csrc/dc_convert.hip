@@ -1,0 +1,51 @@
+// Layout conversion at the C-ABI boundary and small utility kernels.
+#include "dc_device.h"
+
+namespace dc {
+
+// ---------------------------------------------------------------------------------------------------
+// layout conversion at the boundary: host float64 xyz-interleaved  <->  device float32 planar
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_f64i_to_f32p(const double *__restrict__ src, float *__restrict__ dst, int n, long total) {
+  long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  long b = t / n;
+  int i = (int) (t - b * n);
+  const double *s = src + (b * n + i) * 3;
+  float *d = dst + b * 3 * n;
+  d[i] = (float) s[0]; d[n + i] = (float) s[1]; d[2 * n + i] = (float) s[2];
+}
+__global__ void k_f32p_to_f64i(const float *__restrict__ src, double *__restrict__ dst, int n, long total) {
+  long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  long b = t / n;
+  int i = (int) (t - b * n);
+  const float *s = src + b * 3 * n;
+  double *d = dst + (b * n + i) * 3;
+  d[0] = s[i]; d[1] = s[n + i]; d[2] = s[2 * n + i];
+}
+__global__ void k_seed_gradient(const float *__restrict__ x, const float *__restrict__ target, float *__restrict__ gx,
+                                float *__restrict__ gv, int n3, long total, float scale) {
+  long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int k = (int) (t % n3);
+  gx[t] = scale * (x[t] - target[k]);
+  gv[t] = 0.f;
+}
+
+void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, hipStream_t st) {
+  long total = (long) B * n;
+  if (total == 0) return;
+  hipLaunchKernelGGL(k_f64i_to_f32p, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total);
+}
+void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, hipStream_t st) {
+  long total = (long) B * n;
+  if (total == 0) return;
+  hipLaunchKernelGGL(k_f32p_to_f64i, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total);
+}
+void launch_seed_gradient(const float *x, const float *target, float *gx, float *gv, int B, int N, float scale, hipStream_t st) {
+  long total = (long) B * 3 * N;
+  hipLaunchKernelGGL(k_seed_gradient, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, x, target, gx, gv, 3 * N, total, scale);
+}
+
+}  // namespace dc

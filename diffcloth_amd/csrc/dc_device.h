@@ -70,7 +70,8 @@ struct BwdArgs {
   float *d_xfixed;              // [B][3][Af] out (overwritten) or nullptr
   float *d_mu;                  // [B][ngroups] accumulated (+=) or nullptr
   dc_bwd_stats *stats;          // [B]
-  float bwd_tol, cg_tol, clip_thr;
+  float bwd_tol, cg_tol, clip_thr, rel_tol;
+  int mode;                     // 0: reference fixed-point iteration (+ direct fallback), 1: direct Krylov solve
   int it_cap, cg_max, is_start, clip, stall_window;
 };
 

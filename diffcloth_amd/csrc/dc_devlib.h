@@ -1,0 +1,203 @@
+// Device-side building blocks shared by the forward and adjoint kernels (included by dc_forward.hip / dc_adjoint.hip).
+#pragma once
+#include "dc_device.h"
+
+namespace dc {
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------
+struct f3 {
+  float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ f3 fma3(f3 a, float s, f3 acc) { return {fmaf(a.x, s, acc.x), fmaf(a.y, s, acc.y), fmaf(a.z, s, acc.z)}; }
+__device__ __forceinline__ f3 ld3(const float *p, int i, int n) { return {p[i], p[n + i], p[2 * n + i]}; }
+__device__ __forceinline__ void st3(float *p, int i, int n, f3 v) { p[i] = v.x; p[n + i] = v.y; p[2 * n + i] = v.z; }
+__device__ __forceinline__ f3 normalized(f3 a) {
+  float n2 = dot(a, a);
+  return n2 > 0.f ? a * (1.0f / sqrtf(n2)) : a;    // Eigen::normalized(): unchanged when the norm is 0
+}
+
+// Sum over the whole workgroup; every thread receives the result. Partials are combined in fp64.
+template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double *red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; k++) s += red[k];
+  return s;
+}
+
+// Closest 3x2 isometry T = F S^-1, S = (F^T F)^(1/2) in closed form.  Equals Q * (U V^T) of
+// Triangle::projectToManifold (Triangle.cpp:329-351): the Gram-Schmidt frame Q spans F's column space, so
+// Q Q^T F S^-1 = F S^-1.
+struct Polar {
+  f3 t0, t1;
+  float i00, i01, i11, trS;   // S^-1 (symmetric) and trace(S)
+};
+__device__ __forceinline__ Polar polar3x2(f3 f0, f3 f1) {
+  float a = dot(f0, f0), b = dot(f0, f1), c = dot(f1, f1);
+  float det = fmaxf(a * c - b * b, 1e-30f);
+  float s = sqrtf(det);
+  float t = sqrtf(a + c + 2.f * s);
+  float inv = 1.0f / (t * s);
+  Polar P;
+  P.i00 = (c + s) * inv; P.i01 = -b * inv; P.i11 = (a + s) * inv; P.trS = t;
+  P.t0 = f0 * P.i00 + f1 * P.i01;
+  P.t1 = f0 * P.i01 + f1 * P.i11;
+  return P;
+}
+
+// Signorini–Coulomb response r(d) of one contact: Simulation::calcualteDryFrictionForce (Simulation.cpp:829-862).
+__device__ __forceinline__ f3 dry_friction(f3 n, f3 d, float mu) {
+  float sd = dot(d, n);
+  if (sd >= 0.f) return mk(0, 0, 0);                       // take-off
+  f3 dN = n * sd, dT = d - dN;
+  float nT = sqrtf(dot(dT, dT));
+  f3 r = mk(0, 0, 0) - dN;
+  if (nT <= mu * fabsf(sd)) return r - dT;                 // stick
+  return r - dT * (mu * fabsf(sd) / nT);                   // slide
+}
+// w = J^T u with J = dr/dd of the same contact: Simulation::calculatedri_dfi (Simulation.cpp:881-919), applied
+// matrix-free. take-off: 0; stick: -u; slide: J = -n n^T + mu (b (I - a a^T)/|dT| (I - n n^T) + a n^T).
+__device__ __forceinline__ f3 dri_dfi_T(f3 n, f3 d, float mu, f3 u) {
+  float sd = dot(d, n);
+  if (sd >= 0.f) return mk(0, 0, 0);
+  f3 dN = n * sd, dT = d - dN;
+  float nT = sqrtf(dot(dT, dT));
+  if (nT <= mu * fabsf(sd)) return mk(0, 0, 0) - u;
+  f3 a = dT * (1.0f / nT);
+  // J^T u = -n (n.u) + mu [ (I - n n^T) (I - a a^T) u * b/|dT| + n (a.u) ]
+  f3 q = u - a * dot(a, u);
+  q = q - n * dot(n, q);
+  f3 w = n * (-dot(n, u));
+  w = w + (q * (sd / nT) + n * dot(a, u)) * mu;
+  return w;
+}
+// dr/dmu of the same contact: Simulation::calculatedri_dmu (Simulation.cpp:865-879).
+__device__ __forceinline__ f3 dri_dmu(f3 n, f3 d, float mu) {
+  float sd = dot(d, n);
+  if (sd >= 0.f) return mk(0, 0, 0);
+  f3 dT = d - n * sd;
+  float nT = sqrtf(dot(dT, dT));
+  if (nT > mu * fabsf(sd)) return dT * (-fabsf(sd) / nT);
+  return mk(0, 0, 0);
+}
+
+// Primitive::isInContact family (Sphere Primitive.cpp:221-261, Capsule :570-604) for one flattened primitive.
+__device__ __forceinline__ bool prim_in_contact(const DevPrim &p, f3 pos, f3 &normal) {
+  f3 c = mk(p.cx, p.cy, p.cz);
+  f3 q = pos - c;
+  if (p.kind == DC_PRIM_SPHERE) {
+    float dist = sqrtf(dot(q, q)) - p.radius;
+    normal = normalized(q);
+    return dist < 0.1f;
+  }
+  // capsule: Primitive.h:198-211 projectionOnLine + Primitive.cpp:583-603
+  f3 top = mk(p.tx, p.ty, p.tz);
+  float ab2 = dot(top, top);
+  f3 pr = top * (dot(q, top) / ab2);
+  float AB = sqrtf(ab2), AP = sqrtf(dot(pr, pr));
+  f3 pb = pr - top;
+  float PB = sqrtf(dot(pb, pb));
+  float t = AP / AB;
+  if (PB > AB) t = -t;
+  float rl = p.radius / p.length;
+  if ((t < 0.f - rl) || (t > 1.f + rl)) return false;
+  float dist;
+  if (t < 0.f) { dist = sqrtf(dot(q, q)) - p.radius; normal = normalized(q); }
+  else if (t > 1.f) { f3 e = q - top; dist = sqrtf(dot(e, e)) - (p.radius + 0.1f); normal = normalized(e); }
+  else { f3 e = q - pr; dist = sqrtf(dot(e, e)) - (p.radius + 0.1f); normal = normalized(e); }
+  return dist < 0.1f;
+}
+// Simulation::isInContactWithObstacle (Simulation.cpp:153-191): t = 0, h/2, h; first primitive / first sample wins.
+// Children of one LowerLeg share a group and are tested, per sample, in child order (Primitive.cpp:410-418).
+__device__ __forceinline__ int detect_primitive(const DevSystem &S, f3 pos, f3 vel, f3 &normal) {
+  int p0 = 0;
+  while (p0 < S.nprim) {
+    int p1 = p0;
+    while (p1 < S.nprim && S.prims[p1].group == S.prims[p0].group) p1++;
+    for (int k = 0; k < 3; k++) {
+      f3 q = pos + vel * (S.h * 0.5f * (float) k);
+      for (int p = p0; p < p1; p++)
+        if (prim_in_contact(S.prims[p], q, normal)) return p;
+    }
+    p0 = p1;
+  }
+  return -1;
+}
+__device__ __forceinline__ f3 prim_vout(const DevPrim &p, f3 n) {
+  return p.rotates ? cross(mk(0, 1, 0), n) * 8.0f : mk(0, 0, 0);   // Primitive.cpp:254-257, static primitives
+}
+
+// ---------------------------------------------------------------------------------------------------
+// block-Jacobi PCG for P d = rhs (P = P_s (x) I3, so the 3x3 diagonal blocks are P_ii * I3).
+// On entry: cg_r = rhs, cg_p = D^-1 rhs, cg_x = 0 and rz = rhs . D^-1 rhs (already reduced).
+// Replaces SimplicialLLT::solve of Simulation.cpp:1267 / :1577.
+// ---------------------------------------------------------------------------------------------------
+template <int THREADS>
+__device__ __forceinline__ int block_pcg(const DevSystem &S, float *cg_r, float *cg_p, float *cg_ap, float *cg_x,
+                                         double rz, float rel_tol, int max_iter, double *red) {
+  const int N = S.N, tid = threadIdx.x;
+  const double stop = (double) rel_tol * (double) rel_tol * rz;
+  if (!(rz > 1e-300)) return 0;
+  int it = 0;
+  __syncthreads();
+  for (; it < max_iter;) {
+    float part = 0.f;
+    for (int i = tid; i < N; i += THREADS) {
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      const int k1 = S.P_ptr[i + 1];
+      for (int k = S.P_ptr[i]; k < k1; k++) {
+        const float a = S.P_val[k];
+        const int j = S.P_col[k];
+        ax = fmaf(a, cg_p[j], ax); ay = fmaf(a, cg_p[N + j], ay); az = fmaf(a, cg_p[2 * N + j], az);
+      }
+      cg_ap[i] = ax; cg_ap[N + i] = ay; cg_ap[2 * N + i] = az;
+      part += cg_p[i] * ax + cg_p[N + i] * ay + cg_p[2 * N + i] * az;
+    }
+    const double pAp = block_sum<THREADS>((double) part, red);
+    const float alpha = (float) (rz / pAp);
+    part = 0.f;
+    for (int i = tid; i < N; i += THREADS) {
+      const float di = S.dinv[i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int o = c * N + i;
+        cg_x[o] = fmaf(alpha, cg_p[o], cg_x[o]);
+        const float r = fmaf(-alpha, cg_ap[o], cg_r[o]);
+        cg_r[o] = r;
+        part = fmaf(r * di, r, part);
+      }
+    }
+    const double rz_new = block_sum<THREADS>((double) part, red);
+    it++;
+    if (!(rz_new > stop)) break;
+    const float beta = (float) (rz_new / rz);
+    rz = rz_new;
+    for (int i = tid; i < N; i += THREADS) {
+      const float di = S.dinv[i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int o = c * N + i;
+        cg_p[o] = fmaf(beta, cg_p[o], cg_r[o] * di);
+      }
+    }
+    __syncthreads();
+  }
+  return it;
+}
+
+}  // namespace dc

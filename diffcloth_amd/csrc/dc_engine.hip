@@ -138,6 +138,8 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.it_cap = c->params.adjoint_iter_cap > 0 ? c->params.adjoint_iter_cap : 400;   // Simulation.cpp:1562
   A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
   A.is_start = is_start; A.clip = c->params.gradient_clipping;
+  A.mode = c->params.adjoint_mode;
+  A.rel_tol = (float) (c->params.adjoint_rel_tol > 0 ? c->params.adjoint_rel_tol : 1e-6);
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 40;
   return A;
 }
@@ -156,6 +158,7 @@ void dc_default_params(dc_params *p) {
   p->gravity_enabled = 1; p->contact_enabled = 1; p->selfcollision_enabled = 0;
   p->gradient_clipping = 1; p->gradient_clipping_threshold = 16.0;                                      // Simulation.h:330-331
   p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 40;
+  p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6;
 }
 
 int dc_create(int device_id, dc_ctx **out) {

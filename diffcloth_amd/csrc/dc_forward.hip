@@ -1,0 +1,179 @@
+// CDNA4 (gfx950) kernels of the DiffCloth stepper.
+//
+// Execution model: ONE workgroup owns ONE rollout for a whole time step. All Projective-Dynamics
+// iterations, the inner block-Jacobi PCG solves, the convergence test and the best-iterate tracking of
+// Simulation::step() (reference Simulation.cpp:1043-1428) run inside a single launch, synchronised by
+// workgroup barriers only — no host round trip, no grid-wide sync, per-rollout early exit for free.
+// 256 CUs x (1..8 workgroups) rollouts are in flight at once; rollouts are the data-parallel axis.
+//
+// Reformulation used (same fixed point as the reference):
+//   f      = [h^2 A^T (p(x) - A x) + M (s_n - x_n)] / h          (== b~ - C v_now of Simulation.cpp:1248-1249)
+//   P dv   = f + r(f) - M v_now ,  v_new = v_now + dv             (== v_new = P^-1 (b~ + r), :1267)
+// so the constraint residual p - A x is evaluated per element in fp32 without cancellation against P x_n,
+// and the global solve is a PCG for the *correction*, warm-started for free.
+#include "dc_devlib.h"
+
+namespace dc {
+
+// ---------------------------------------------------------------------------------------------------
+// Forward: Simulation::step()
+// ---------------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_pd_step(DevSystem S, DevWork W, FwdArgs A) {
+  __shared__ double red[THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = S.N, T = S.T, E = S.E, NC = S.NC;
+  const size_t off = (size_t) b * 3 * N;
+  const float *xn = A.x_in + off, *vn = A.v_in + off;
+  float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off;
+  float *cg_r = W.cg_r + off, *cg_p = W.cg_p + off, *cg_ap = W.cg_ap + off, *cg_x = W.cg_x + off;
+  float *corner = W.corner + (size_t) b * 3 * NC;
+  float *rec_f = A.rec_f + off, *rec_r = A.rec_r + off, *rec_n = A.rec_n + off;
+  int *rec_prim = A.rec_prim + (size_t) b * N;
+  const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
+  const float *mu = A.mu + (size_t) b * S.ngroups;
+  const float h = S.h;
+  const f3 grav = mk(S.gx, S.gy, S.gz);
+  const f3 fu = A.fu ? mk(A.fu[3 * b], A.fu[3 * b + 1], A.fu[3 * b + 2]) : mk(0, 0, 0);
+
+  // ---- step set-up: s_n, initial guess, contact detection (Simulation.cpp:1097-1160, :1254-1256) ----
+  float part = 0.f;
+  int ncontact = 0;
+  for (int i = tid; i < N; i += THREADS) {
+    const float m = S.mass[i];
+    f3 v = ld3(vn, i, N);
+    f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
+    f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
+    st3(vnow, i, N, v0);
+    st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h
+    part += dot(v0, v0);
+    int prim = -1;
+    f3 nrm = mk(0, 0, 0);
+    if (S.contact_enabled) prim = detect_primitive(S, ld3(xn, i, N), v0, nrm);
+    rec_prim[i] = prim;
+    st3(rec_n, i, N, nrm);
+    ncontact += (prim >= 0);
+  }
+  double min_xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
+  const int total_contacts = (int) block_sum<THREADS>((double) ncontact, red);
+  bool improved = false, converged = false, stalled = false;
+  int iters = 0, cg_total = 0, since_progress = 0;
+  double xdiff = 0;
+
+  for (int iter = 0; iter < A.pd_cap; iter++) {
+    // ---- local step: per-element projection residual, written per constraint corner ----
+    // triangles: Triangle::project (Triangle.cpp:310-351); contribution h * w^2 * (T - F) D^T
+    for (int t = tid; t < T; t += THREADS) {
+      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+      const float4 D = S.tri_D[t];
+      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
+      // edges as (x_n differences) + h (v differences): exact fp32 differences, no cancellation error
+      f3 e0 = (ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h;
+      f3 e1 = (ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h;
+      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
+      Polar P = polar3x2(f0, f1);
+      const float s = h * S.tri_w2[t];
+      f3 g0 = (P.t0 - f0) * s, g1 = (P.t1 - f1) * s;
+      f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
+      f3 c0 = mk(0, 0, 0) - c1 - c2;
+      st3(corner, t, NC, c0); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
+    }
+    // bending: TriangleBending::project (TriangleBending.cpp:138-151); contribution h * w^2 * w_i * (p - e)
+    for (int e = tid; e < E; e += THREADS) {
+      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+      const float4 w = S.bend_w[e];
+      const float2 nw = S.bend_nw[e];
+      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
+      // sum_i w_i x_i with sum_i w_i = 0  ->  sum_{i>0} w_i (x_i - x_0)
+      f3 ev = ((ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h) * w.y;
+      ev = ev + ((ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h) * w.z;
+      ev = ev + ((ld3(xn, i3, N) - x0) + (ld3(vnow, i3, N) - v0) * h) * w.w;
+      f3 p = mk(0, 0, 0);
+      if (nw.x > 1e-6f) p = normalized(ev) * nw.x;
+      f3 d = (p - ev) * (h * nw.y);
+      const int base = 3 * T;
+      st3(corner, base + e, NC, d * w.x); st3(corner, base + E + e, NC, d * w.y);
+      st3(corner, base + 2 * E + e, NC, d * w.z); st3(corner, base + 3 * E + e, NC, d * w.w);
+    }
+    __syncthreads();
+    // ---- vertex pass: f, friction r, right-hand side of the correction solve ----
+    part = 0.f;
+    for (int i = tid; i < N; i += THREADS) {
+      f3 f = ld3(g, i, N);
+      const int k1 = S.inc_ptr[i + 1];
+      for (int k = S.inc_ptr[i]; k < k1; k++) f = f + ld3(corner, S.inc_idx[k], NC);
+      f3 v = ld3(vnow, i, N);
+      const int a = S.att_of_vertex[i];
+      if (a >= 0) {    // AttachmentSpring::project (AttachmentSpring.cpp:25-29): h * k_att * (x_fixed - x_i)
+        // (x_fixed - x_n) is an exact fp32 difference; only then subtract the small h v term (k_att = 1e4 amplifies error)
+        f = f + ((ld3(xfix, a, S.Af) - ld3(xn, i, N)) - v * h) * (h * S.k_att);
+      }
+      const float m = S.mass[i];
+      f3 r = mk(0, 0, 0);
+      const int prim = rec_prim[i];
+      if (prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
+        f3 n = ld3(rec_n, i, N);
+        f3 d = f - prim_vout(S.prims[prim], n) * m;
+        r = dry_friction(n, d, mu[S.prims[prim].group]);
+      }
+      st3(rec_f, i, N, f);
+      st3(rec_r, i, N, r);
+      f3 rhs = f + r - v * m;
+      const float di = S.dinv[i];
+      st3(cg_r, i, N, rhs);
+      st3(cg_p, i, N, rhs * di);
+      st3(cg_x, i, N, mk(0, 0, 0));
+      part += dot(rhs, rhs) * di;
+    }
+    const double rz = block_sum<THREADS>((double) part, red);
+    // ---- global step: P dv = rhs (Simulation.cpp:1267) ----
+    cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red);
+    // ---- update + convergence (Simulation.cpp:1268, 1310-1373) ----
+    part = 0.f;
+    for (int i = tid; i < N; i += THREADS) {
+      f3 d = ld3(cg_x, i, N);
+      st3(vnow, i, N, ld3(vnow, i, N) + d);
+      part += dot(d, d);
+    }
+    xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
+    iters = iter + 1;
+    converged = xdiff < (double) A.fwd_tol;
+    if (xdiff < min_xdiff) {
+      if (xdiff < 0.99 * min_xdiff) since_progress = 0;
+      min_xdiff = xdiff;
+      improved = true;
+      if (!converged)
+        for (int i = tid; i < N; i += THREADS) st3(vbest, i, N, ld3(vnow, i, N));
+    }
+    if (converged) break;
+    // fp32 floor: |x_new - x_now| stopped decreasing although the tolerance (often 1e-9..1e-10 in the reference's
+    // scene tables, below fp32 resolution) is not met -> return the best iterate instead of burning the whole cap
+    if (++since_progress >= A.stall_window) { stalled = true; break; }
+  }
+  // ---- write the new state (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
+  float *xo = A.x_out + off, *vo = A.v_out + off;
+  for (int i = tid; i < N; i += THREADS) {
+    f3 x = ld3(xn, i, N);
+    if (converged) { f3 v = ld3(vnow, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
+    else if (improved) { f3 v = ld3(vbest, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
+    else { st3(vo, i, N, ld3(vn, i, N)); st3(xo, i, N, x); }
+  }
+  if (tid == 0) {
+    dc_step_stats s;
+    s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
+    s.self_contacts = 0; s.last_xdiff = (float) xdiff;
+    A.stats[b] = s;
+  }
+}
+
+static int pick_threads_fwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
+
+void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+  switch (pick_threads_fwd(S.N)) {
+    case 256: hipLaunchKernelGGL(k_pd_step<256>, dim3(B), dim3(256), 0, st, S, W, A); break;
+    case 512: hipLaunchKernelGGL(k_pd_step<512>, dim3(B), dim3(512), 0, st, S, W, A); break;
+    default: hipLaunchKernelGGL(k_pd_step<1024>, dim3(B), dim3(1024), 0, st, S, W, A); break;
+  }
+}
+
+}  // namespace dc

@@ -64,6 +64,12 @@ typedef struct dc_params {
    * consecutive iterations (the reference's 1e-9..1e-10 thresholds are below fp32 resolution); the best
    * iterate is returned and dc_step_stats::converged reads 2.  <=0: 40                                    */
   int stall_window;
+  /* adjoint solver: 0 = the reference's fixed-point iteration u <- P^-1 (g + dP^T u) (Simulation.cpp:1561-1600)
+   * with a direct solve when the cap is hit (:1589-1594); 1 = always the direct solve, i.e. the semantics of
+   * Simulation::backwardGradientForceDirectSolver / solveDirect (:1431-1440). On the GPU the direct solve is a
+   * block-Jacobi preconditioned BiCGSTAB on (P - dP^T) run to adjoint_rel_tol (relative residual; <=0: 1e-6). */
+  int adjoint_mode;
+  double adjoint_rel_tol;
 } dc_params;
 
 /* Per-rollout statistics of one forward step (ForwardInformation::converged/convergeIter). */
@@ -82,7 +88,8 @@ typedef struct dc_bwd_stats {
   int adjoint_iters;
   int cg_iters;
   int clipped;
-  float last_udiff;
+  int used_direct;       /* 1 when the direct (Krylov) solve ran; adjoint_iters then counts its iterations too */
+  float last_udiff;      /* mode 0: |u_new - u|_2 / N; direct solve: relative residual |g - K u| / |g| */
 } dc_bwd_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

@@ -218,3 +218,28 @@ def test_rollout_on_device_equals_stepwise_calls():
     assert np.isfinite(dx).all() and np.isfinite(dv).all() and np.abs(dx).max() > 0
     kt = e.kernel_times()
     assert kt["fwd_launches"] == S and kt["bwd_launches"] == S and kt["fwd_ms"] > 0
+
+
+@pytest.mark.parametrize("mu", [0.1, 0.7])
+def test_direct_adjoint_solve_matches_oracle(mu):
+    """adjoint_mode = 1 (BiCGSTAB on P - dP^T) == the reference's solveDirect semantics (Simulation.cpp:1431-1440)."""
+    V, F, o, e = build_pair(13, mu=mu, att=(0, 12))
+    e.set_params(adjoint_mode=1, adjoint_rel_tol=1e-7)
+    e.build()
+    xf = f32(V[[0, 12]].reshape(-1) + 0.02)
+    x0, v0 = settle(o, V, 55, xf)
+    ref = o.step(x0, v0, xf)
+    rng = np.random.default_rng(4)
+    gx = f32(rng.standard_normal(x0.size) * 1e-3); gv = f32(rng.standard_normal(x0.size) * 1e-5)
+    rb = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    e.step_forward(0, fixed_pts=xf)
+    gb = e.step_backward(1, gx, gv, is_start=False)
+    assert gb["used_direct"][0] == 1 and gb["converged"][0] in (1, 2)
+
+    def rel(a, b):
+        return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    ex, ev, ef = rel(gb["dL_dx"][0], rb["dL_dx"]), rel(gb["dL_dv"][0], rb["dL_dv"]), rel(gb["dL_dxfixed"][0], rb["dL_dxfixed"])
+    print(f"\n[direct adjoint mu={mu}] bicgstab iters {gb['adjoint_iters'][0]} rel res {gb['last_udiff'][0]:.1e} rel err dx {ex:.2e} dv {ev:.2e} dxfixed {ef:.2e}")
+    assert ex <= GRAD_TOL and ev <= GRAD_TOL and ef <= GRAD_TOL
