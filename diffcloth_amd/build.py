@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libdiffcloth_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-ENGINE_SOURCES = ["dc_forward.hip", "dc_adjoint.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp"]
+ENGINE_SOURCES = ["dc_forward.hip", "dc_forward_res.hip", "dc_adjoint.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp"]
 
 
 def _stale(target, deps):
@@ -31,6 +31,7 @@ def build_engine(force=False, verbose=False):
         return LIB
     cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
            "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-o", LIB]
+    cmd += os.environ.get("DC_CXXFLAGS", "").split()     # e.g. -DDC_PROFILE_PHASES for in-kernel phase timing
     for s in srcs:
         if s.endswith(".cpp"):
             cmd += ["-x", "hip", s]

@@ -127,7 +127,8 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
 }  // namespace
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_adjoint_step(DevSystem S, DevWork W, BwdArgs A) {
+__global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
+  const DevSystem &S = *Sp;
   __shared__ double red[2 * (THREADS / 64)];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = S.N;
@@ -312,9 +313,9 @@ static int pick_threads_bwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 :
 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
   switch (pick_threads_bwd(S.N)) {
-    case 256: hipLaunchKernelGGL(k_adjoint_step<256>, dim3(B), dim3(256), 0, st, S, W, A); break;
-    case 512: hipLaunchKernelGGL(k_adjoint_step<512>, dim3(B), dim3(512), 0, st, S, W, A); break;
-    default: hipLaunchKernelGGL(k_adjoint_step<1024>, dim3(B), dim3(1024), 0, st, S, W, A); break;
+    case 256: hipLaunchKernelGGL(k_adjoint_step<256>, dim3(B), dim3(256), 0, st, S.self_dev, W, A); break;
+    case 512: hipLaunchKernelGGL(k_adjoint_step<512>, dim3(B), dim3(512), 0, st, S.self_dev, W, A); break;
+    default: hipLaunchKernelGGL(k_adjoint_step<1024>, dim3(B), dim3(1024), 0, st, S.self_dev, W, A); break;
   }
 }
 

@@ -33,9 +33,17 @@ struct DevSystem {
   const float *P_val;           // [nnz]
   const int *inc_ptr;           // [N+1] vertex -> constraint corners
   const int *inc_idx;
+  // P again, in wave-sliced ELL for the resident PCG: chunk c = rows 64c..64c+63, entry (s, lane) at
+  // ell[ell_ptr[c] + 64 s + lane] = (column, float bits of the value); padded entries are (row, 0.0f)
+  const int2 *ell;
+  const int *ell_ptr;           // [ceil(N/64)]
+  const int *ell_w;             // [ceil(N/64)] width of the chunk
   float h, k_att, gx, gy, gz;
   int contact_enabled, self_enabled, pad1;
   DevPrim prims[kMaxPrims];
+  // device-resident copy of this struct: kernels receive THIS pointer and read fields with scalar loads on
+  // demand (passing the ~450-byte struct by value cost > 100 spilled SGPRs per kernel)
+  const DevSystem *self_dev;
 };
 
 // Per-batch work buffers (one set, reused by forward and backward kernels).
@@ -45,6 +53,7 @@ struct DevWork {
   float *vbest;    // [B][3][N]  best iterate                          | backward: y = u + dr_df^T u
   float *cg_r, *cg_p, *cg_ap, *cg_x;   // [B][3][N] each
   float *corner;   // [B][3][NC] per-constraint-corner contributions
+  float4 *ap4;     // [B][N] per-vertex float4 scratch of the resident PCG (A p, one 16-byte access per vertex)
 };
 
 struct FwdArgs {
@@ -76,6 +85,8 @@ struct BwdArgs {
 };
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
+// LDS/register-resident variant (dc_forward_res.hip); returns false when N is too large for it.
+bool launch_pd_step_resident(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st, int variant);
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);
 void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, hipStream_t st);
 void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, hipStream_t st);

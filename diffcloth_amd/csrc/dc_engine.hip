@@ -291,6 +291,33 @@ int dc_build(dc_ctx *c) {
   if ((rc = upload<float>(c, &S.P_val, H.P_val))) return rc;
   if ((rc = upload<int>(c, &S.inc_ptr, H.inc_ptr))) return rc;
   if ((rc = upload<int>(c, &S.inc_idx, H.inc_idx))) return rc;
+  {  // wave-sliced ELL copy of P for the LDS-resident PCG
+    const int nchunks = (N + 63) / 64;
+    std::vector<int> eptr(nchunks), ew(nchunks);
+    std::vector<int> flat;   // (col, value bits) pairs
+    for (int ch = 0; ch < nchunks; ch++) {
+      int w = 0;
+      for (int r = 64 * ch; r < std::min(N, 64 * ch + 64); r++) w = std::max(w, H.P_ptr[r + 1] - H.P_ptr[r]);
+      eptr[ch] = (int) (flat.size() / 2); ew[ch] = w;
+      flat.resize(flat.size() + (size_t) 2 * 64 * w);
+      for (int s = 0; s < w; s++)
+        for (int l = 0; l < 64; l++) {
+          const int r = 64 * ch + l;
+          int col = std::min(r, N - 1);
+          float val = 0.f;
+          if (r < N && H.P_ptr[r] + s < H.P_ptr[r + 1]) { col = H.P_col[H.P_ptr[r] + s]; val = (float) H.P_val[H.P_ptr[r] + s]; }
+          int bits;
+          std::memcpy(&bits, &val, sizeof(int));
+          const size_t o = 2 * ((size_t) eptr[ch] + (size_t) s * 64 + l);
+          flat[o] = col; flat[o + 1] = bits;
+        }
+    }
+    const int *ellp;
+    if ((rc = upload<int>(c, &ellp, flat))) return rc;
+    S.ell = (const int2 *) ellp;
+    if ((rc = upload<int>(c, &S.ell_ptr, eptr))) return rc;
+    if ((rc = upload<int>(c, &S.ell_w, ew))) return rc;
+  }
   S.h = (float) p.time_step; S.k_att = (float) p.k_att;
   S.gx = p.gravity_enabled ? (float) p.gravity[0] : 0.f;
   S.gy = p.gravity_enabled ? (float) p.gravity[1] : 0.f;
@@ -303,6 +330,12 @@ int dc_build(dc_ctx *c) {
     d.kind = q.kind; d.group = c->group_of_prim[k]; d.rotates = q.rotates; d.pad = 0;
     d.cx = (float) q.center[0]; d.cy = (float) q.center[1]; d.cz = (float) q.center[2]; d.radius = (float) q.radius;
     d.tx = (float) q.top_offset[0]; d.ty = (float) q.top_offset[1]; d.tz = (float) q.top_offset[2]; d.length = (float) q.length;
+  }
+  {  // device-resident copy of the descriptor itself (kernels take a pointer to it)
+    DevSystem *dS = nullptr;
+    if ((rc = dev_alloc(c, c->table_allocs, &dS, 1))) return rc;
+    S.self_dev = dS;
+    HIPCHK(c, hipMemcpy(dS, &S, sizeof(DevSystem), hipMemcpyHostToDevice));
   }
   c->built = true;
   // a batch allocated for a different system size is no longer valid
@@ -363,6 +396,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->W.cg_ap, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.cg_x, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.corner, (size_t) B * 3 * NC))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.ap4, (size_t) B * N))) return rc;
   if ((rc = dev_alloc(c, pool, &c->xf_cur, (size_t) B * 3 * Af))) return rc;
   if ((rc = dev_alloc(c, pool, &c->mu, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fu, (size_t) B * 3))) return rc;

@@ -11,6 +11,7 @@
 //   P dv   = f + r(f) - M v_now ,  v_new = v_now + dv             (== v_new = P^-1 (b~ + r), :1267)
 // so the constraint residual p - A x is evaluated per element in fp32 without cancellation against P x_n,
 // and the global solve is a PCG for the *correction*, warm-started for free.
+#include <cstdlib>
 #include "dc_devlib.h"
 
 namespace dc {
@@ -19,7 +20,8 @@ namespace dc {
 // Forward: Simulation::step()
 // ---------------------------------------------------------------------------------------------------
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_pd_step(DevSystem S, DevWork W, FwdArgs A) {
+__global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
+  const DevSystem &S = *Sp;
   __shared__ double red[THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = S.N, T = S.T, E = S.E, NC = S.NC;
@@ -168,11 +170,24 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(DevSystem S, DevWork W, Fwd
 
 static int pick_threads_fwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
 
+// DC_FWD_VARIANT (read once): "global" forces this file's global-memory kernel (any N); "0" / "1" select the
+// register/thread shape of the resident kernel (dc_forward_res.hip). Default: resident, shape 0.
+static int fwd_variant() {
+  static int v = -2;
+  if (v == -2) {
+    const char *e = getenv("DC_FWD_VARIANT");
+    v = !e ? 0 : (e[0] == 'g' ? -1 : atoi(e));
+  }
+  return v;
+}
+
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+  const int variant = fwd_variant();
+  if (variant >= 0 && launch_pd_step_resident(S, W, A, B, st, variant)) return;
   switch (pick_threads_fwd(S.N)) {
-    case 256: hipLaunchKernelGGL(k_pd_step<256>, dim3(B), dim3(256), 0, st, S, W, A); break;
-    case 512: hipLaunchKernelGGL(k_pd_step<512>, dim3(B), dim3(512), 0, st, S, W, A); break;
-    default: hipLaunchKernelGGL(k_pd_step<1024>, dim3(B), dim3(1024), 0, st, S, W, A); break;
+    case 256: hipLaunchKernelGGL(k_pd_step<256>, dim3(B), dim3(256), 0, st, S.self_dev, W, A); break;
+    case 512: hipLaunchKernelGGL(k_pd_step<512>, dim3(B), dim3(512), 0, st, S.self_dev, W, A); break;
+    default: hipLaunchKernelGGL(k_pd_step<1024>, dim3(B), dim3(1024), 0, st, S.self_dev, W, A); break;
   }
 }
 
