@@ -43,5 +43,25 @@ def build_engine(force=False, verbose=False):
     return LIB
 
 
+def build_pymodule(force=False, verbose=False):
+    """diffcloth_py: C++ host `Simulation` (csrc/host) + pybind11 surface of the reference, linked against the engine."""
+    import sysconfig
+    import pybind11
+    host = os.path.join(CSRC, "host")
+    srcs = [os.path.join(host, s) for s in ("simulation.cpp", "scene_tables.cpp", "pymodule.cpp")]
+    out = os.path.join(LIBDIR, "diffcloth_py" + sysconfig.get_config_var("EXT_SUFFIX"))
+    deps = srcs + [os.path.join(host, "simulation.h"), os.path.join(ROOT, "include", "diffcloth_hip.h"), LIB]
+    if not force and not _stale(out, deps):
+        return out
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+           "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], "-o", out] + srcs + \
+          ["-L", LIBDIR, "-ldiffcloth_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_engine(force="--force" in sys.argv, verbose=True))
+    print(build_pymodule(force="--force" in sys.argv, verbose=True))

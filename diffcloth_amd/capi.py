@@ -46,7 +46,7 @@ class dc_bwd_stats(C.Structure):
 
 EXPORTED_SYMBOLS = [
     "dc_create", "dc_destroy", "dc_last_error", "dc_version", "dc_set_mesh", "dc_set_attachments", "dc_set_params",
-    "dc_set_primitives", "dc_build", "dc_default_params", "dc_get_counts", "dc_get_system_matrix",
+    "dc_set_primitives", "dc_build", "dc_default_params", "dc_set_solver", "dc_set_flags", "dc_get_counts", "dc_get_system_matrix",
     "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force",
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_stats", "dc_sync", "dc_timer_start",

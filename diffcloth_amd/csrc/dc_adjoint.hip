@@ -58,8 +58,11 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
                                                  float *out, const float *d1, float &dot1, float &dot2) {
   const int N = S.N, T = S.T, E = S.E, NC = S.NC, tid = threadIdx.x;
   const float h2 = S.h * S.h;
-  float *y = C.y, *corner = C.corner;
-  const float *xnew = C.xnew;
+  // __restrict__ + unroll: lets the scheduler overlap the index -> gather -> store chains of neighbouring
+  // iterations (each wave otherwise exposes two dependent memory latencies per element)
+  float *__restrict__ y = C.y;
+  float *__restrict__ corner = C.corner;
+  const float *__restrict__ xnew = C.xnew;
   // ---- y = (I + dr_df)^T z ----
   for (int i = tid; i < N; i += THREADS) {
     f3 z = ld3(zin, i, N);
@@ -70,6 +73,7 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   // ---- per element: h^2 (A - dp/dx)^T A y ----
   // triangles: Triangle::projectToManifoldBackward (Triangle.cpp:354-451) in closed form:
   //   dT(Y) = TJ <TJ,Y> / tr(S) + (I - T T^T) Y S^-1,   TJ = [t1, -t0]
+#pragma unroll 2
   for (int t = tid; t < T; t += THREADS) {
     const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
     const float4 D = S.tri_D[t];
@@ -89,6 +93,7 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
     st3(corner, t, NC, mk(0, 0, 0) - c1 - c2); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
   }
   // bending: TriangleBending::backwardGradient (TriangleBending.cpp:154-172)
+#pragma unroll 2
   for (int e = tid; e < E; e += THREADS) {
     const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
     const float4 w = S.bend_w[e];
@@ -111,6 +116,7 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   __syncthreads();
   // ---- vertex gather: out = M z + sum(corners) + attachment term ----
   dot1 = 0.f; dot2 = 0.f;
+#pragma unroll 2
   for (int i = tid; i < N; i += THREADS) {
     f3 z = ld3(zin, i, N);
     if (precond) z = z * S.dinv[i];
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       udiff = sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
       iters = it + 1;
       if (udiff < (double) A.bwd_tol) { status = 1; break; }
-      if (udiff < 0.99 * min_udiff) since_progress = 0;
+      if (udiff < min_udiff) since_progress = 0;
       if (udiff < min_udiff) min_udiff = udiff;
       if (++since_progress >= A.stall_window) { status = 2; break; }
     }
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       rr = (double) pb;
       block_sum2<THREADS>(rho_new, rr, red);
       if (rr <= stop) { status = 1; break; }
-      if (rr < 0.9 * best_rr) { best_rr = rr; since_progress = 0; }
+      if (rr < best_rr) { best_rr = rr; since_progress = 0; }
       else if (++since_progress >= A.stall_window) { status = 2; break; }
       if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { status = 2; break; }
       const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));

@@ -347,6 +347,29 @@ int dc_build(dc_ctx *c) {
   return DC_OK;
 }
 
+int dc_set_solver(dc_ctx *c, double forward_tol, double backward_tol, int gradient_clipping, double clip_threshold, int force_direct_adjoint) {
+  if (!c) return DC_ERR_INVALID;
+  c->params.forward_tol = forward_tol; c->params.backward_tol = backward_tol;
+  c->params.gradient_clipping = gradient_clipping; c->params.gradient_clipping_threshold = clip_threshold;
+  c->params.adjoint_mode = force_direct_adjoint ? 1 : 0;
+  return DC_OK;   // solver knobs are kernel arguments: no rebuild, the batch and its tape stay valid
+}
+
+int dc_set_flags(dc_ctx *c, int gravity_enabled, int contact_enabled, int selfcollision_enabled) {
+  if (!c) return DC_ERR_INVALID;
+  c->params.gravity_enabled = gravity_enabled; c->params.contact_enabled = contact_enabled;
+  c->params.selfcollision_enabled = selfcollision_enabled;
+  if (!c->built || c->host_only) return DC_OK;
+  DevSystem &S = c->S;
+  S.gx = gravity_enabled ? (float) c->params.gravity[0] : 0.f;
+  S.gy = gravity_enabled ? (float) c->params.gravity[1] : 0.f;
+  S.gz = gravity_enabled ? (float) c->params.gravity[2] : 0.f;
+  S.contact_enabled = contact_enabled; S.self_enabled = selfcollision_enabled;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy((void *) S.self_dev, &S, sizeof(DevSystem), hipMemcpyHostToDevice));
+  return DC_OK;
+}
+
 int dc_get_counts(const dc_ctx *c, int *out6) {
   if (!c || !out6 || !c->mesh_set) return DC_ERR_INVALID;
   out6[0] = c->host.N; out6[1] = c->host.T; out6[2] = c->host.E; out6[3] = (int) c->host.att_vertex.size();

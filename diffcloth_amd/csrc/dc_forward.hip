@@ -141,7 +141,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
     iters = iter + 1;
     converged = xdiff < (double) A.fwd_tol;
     if (xdiff < min_xdiff) {
-      if (xdiff < 0.99 * min_xdiff) since_progress = 0;
+      since_progress = 0;     // any new minimum counts: slow monotone convergence must never look like a stall
       min_xdiff = xdiff;
       improved = true;
       if (!converged)

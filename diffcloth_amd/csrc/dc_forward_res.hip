@@ -152,10 +152,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
         __syncthreads();
         part = 0.f;
 #pragma unroll 1
-        for (int kk = 0; kk < VPT; kk++) {  // SpMV rows of this thread; touches no register array -> not unrolled
-          // every workgroup streams the SAME matrix: rotate the row-block order by the workgroup id so the CUs of
-          // an XCD are spread over the stream instead of hammering one L2 channel in lockstep
-          const int k = (kk + b) % VPT;
+        for (int k = 0; k < VPT; k++) {     // SpMV rows of this thread; touches no register array -> not unrolled
           const int i = tid + k * THREADS;
           const int chunk = i >> 6;
           float ax = 0.f, ay = 0.f, az = 0.f;
@@ -167,24 +164,16 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
             for (int s0 = 0; s0 < w; s0 += 8) {
               int2 e[8];
 #pragma unroll
-#if DC_EXP == 2   /* timing experiment: no matrix stream */
-              for (int j = 0; j < 8; j++) e[j] = make_int2(i < N ? i : 0, (s0 + j < w) ? 0x3a000000 : 0);
-#else
               // unconditional (clamped) loads + select on the value: a conditional load forces a wait at its merge
               // point and serialises the batch
               for (int j = 0; j < 8; j++) {
                 e[j] = row[min(s0 + j, w - 1) * 64];
                 e[j].y = (s0 + j < w) ? e[j].y : 0;
               }
-#endif
 #pragma unroll
               for (int j = 0; j < 8; j++) {
                 const float a = __int_as_float(e[j].y);
-#if DC_EXP == 1   /* timing experiment: no LDS gathers */
-                ax = fmaf(a, (float) e[j].x, ax); ay = fmaf(a, 1.0f, ay); az = fmaf(a, 2.0f, az);
-#else
                 ax = fmaf(a, lp[e[j].x], ax); ay = fmaf(a, lp[NP + e[j].x], ay); az = fmaf(a, lp[2 * NP + e[j].x], az);
-#endif
               }
             }
           }
@@ -240,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
     iters = iter + 1;
     converged = xdiff < (double) A.fwd_tol;
     if (xdiff < min_xdiff) {
-      if (xdiff < 0.99 * min_xdiff) since_progress = 0;
+      since_progress = 0;     // any new minimum counts: slow monotone convergence must never look like a stall
       min_xdiff = xdiff;
       improved = true;
       if (!converged)

@@ -1,0 +1,245 @@
+// pybind11 module `diffcloth_py`: same module name, functions, classes and attribute names as the reference's
+// src/code/python_interface.cpp:164-378, backed by the MI355X stepper. Vectors cross the boundary as numpy float64
+// arrays (the reference uses pybind11/eigen.h, which gives Python exactly that). Additive, batched entry points
+// live on `SimulationBatch` and do not change the reference surface.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+#include <cstdio>
+#include <fstream>
+#include <memory>
+#include "simulation.h"
+
+namespace py = pybind11;
+using namespace dchost;
+
+typedef py::array_t<double, py::array::c_style | py::array::forcecast> NpArr;
+
+static VecXd toVec(const NpArr &a) {
+  auto r = a.unchecked();
+  VecXd v((size_t) a.size());
+  const double *p = a.data();
+  for (size_t k = 0; k < v.size(); k++) v[k] = p[k];
+  (void) r;
+  return v;
+}
+static py::array_t<double> toNp(const VecXd &v) { return py::array_t<double>((py::ssize_t) v.size(), v.data()); }
+template <size_t K>
+static py::array_t<double> toNp(const std::array<double, K> &v) { return py::array_t<double>((py::ssize_t) K, v.data()); }
+
+// OptimizeHelper: only the attributes the Python drivers read (python_interface.cpp:336-362); the L-BFGS machinery
+// of src/code/optimization stays with the reference (out of scope).
+struct OptimizeHelper {
+  Simulation *sim = nullptr;
+  BackwardTaskInformation taskInfo;
+  LossInfo lossInfo;
+  int forward_steps = 0;
+  std::string lossType = "MATCHSHAPE";
+};
+
+static Simulation *makeSim(const std::string &exampleName, bool runBackward) {
+  Simulation::forwardConvergenceThreshold = 1e-5;      // python_interface.cpp:13
+  SceneConfiguration cfg = sceneByName(exampleName);   // throws "Undefined example name (...)" like throwError
+  Simulation *sim = Simulation::createSystem(cfg, {0, 0, 0}, runBackward);
+  if (exampleName == "wear_hat") {                     // python_interface.cpp:21-25
+    const Primitive &head = sim->primitives.at(0);
+    Vec3d bust = {head.center[0], head.center[1] + head.radius * 0.6, head.center[2]};
+    for (int d = 0; d < 3; d++) sim->taskLossInfo.targetTranslation[d] = bust[d] - 0.5 * (sim->restShapeMinDim[d] + sim->restShapeMaxDim[d]);
+  }
+  return sim;
+}
+
+static OptimizeHelper *makeOptimizeHelperWithSim(const std::string &exampleName, Simulation *sim) {
+  Simulation::forwardConvergenceThreshold = 1e-5;      // python_interface.cpp:99
+  OptimizeHelper *h = new OptimizeHelper();
+  h->sim = sim;
+  sim->setPrintVerbose(false);
+  h->forward_steps = sim->sceneConfig.stepNum;
+  // per-demo gradient switches (optimization/OptimizationTaskSetup.cpp:154-225)
+  if (exampleName == "wear_hat" || exampleName == "wear_sock") h->taskInfo.dL_dcontrolPoints = true;
+  else if (exampleName == "wind_tshirt") { h->taskInfo.dL_dk_pertype[2] = true; h->taskInfo.dL_dfwind = true; }
+  else if (exampleName == "sphere") { h->taskInfo.dL_dmu = true; h->taskInfo.mu_primitives = {0}; }
+  else if (exampleName == "inverse_design" || exampleName == "wind_sim2real") { h->taskInfo.dL_dx0 = true; }
+  else throw std::runtime_error("Undefined example name (" + exampleName + ").");
+  h->taskInfo.forwardAccuracyLevel = sim->sceneConfig.forwardConvergenceThresh;
+  h->taskInfo.backwardAccuracyLevel = sim->sceneConfig.backwardConvergenceThresh;
+  if (exampleName == "wear_hat") {                     // target shape of the hat demo (assets: remeshed/Hat/hat_target.txt)
+    std::string root = Simulation::assetRoot.empty() ? (std::getenv("DIFFCLOTH_ASSETS") ? std::getenv("DIFFCLOTH_ASSETS") : "/root/reference/src/assets/meshes") : Simulation::assetRoot;
+    std::ifstream in(root + "/remeshed/Hat/hat_target.txt");
+    VecXd shape;
+    double v;
+    while (in >> v) shape.push_back(v);
+    if (shape.size() == 3 * (size_t) sim->getNumParticles()) h->lossInfo.targetFrameShape.push_back({sim->sceneConfig.stepNum, shape});
+  }
+  return h;
+}
+
+static OptimizeHelper *makeOptimizeHelper(const std::string &exampleName) {
+  Simulation *sim = Simulation::createSystem(sceneByName("wear_hat"), {0, 0, 0}, false);   // python_interface.cpp:139-144
+  return makeOptimizeHelperWithSim(exampleName, sim);
+}
+
+PYBIND11_MODULE(diffcloth_py, m) {
+  m.doc() = "MI355X-native DiffCloth stepper with the reference's diffcloth_py surface";
+
+  py::enum_<WindConfig>(m, "WindConfig")
+      .value("NO_WIND", NO_WIND).value("WIND_CONSTANT", WIND_CONSTANT).value("WIND_SIN", WIND_SIN)
+      .value("WIND_SIN_AND_FALLOFF", WIND_SIN_AND_FALLOFF).value("WIND_FACTOR_PER_STEP", WIND_FACTOR_PER_STEP).export_values();
+
+  py::class_<SceneConfiguration>(m, "SceneConfiguration")
+      .def_readwrite("timeStep", &SceneConfiguration::timeStep)
+      .def_readwrite("windConfig", &SceneConfiguration::windConfig)
+      .def_readonly("stepNum", &SceneConfiguration::stepNum)
+      .def_readwrite("customAttachmentVertexIdx", &SceneConfiguration::customAttachmentVertexIdx);
+
+  py::class_<PrimitiveCollisionInformation>(m, "PrimitiveCollisionInformation")
+      .def_readonly("primitiveId", &PrimitiveCollisionInformation::primitiveId)
+      .def_readonly("particleId", &PrimitiveCollisionInformation::particleId);
+  py::class_<SelfCollisionInformation>(m, "SelfCollisionInformation")
+      .def_readonly("particleId1", &SelfCollisionInformation::particleId1)
+      .def_readonly("particleId2", &SelfCollisionInformation::particleId2);
+
+  py::class_<ForwardInformation>(m, "ForwardInformation")
+      .def_property_readonly("x", [](const ForwardInformation &r) { return toNp(r.x); })
+      .def_property_readonly("v", [](const ForwardInformation &r) { return toNp(r.v); })
+      .def_property_readonly("x_prev", [](const ForwardInformation &r) { return toNp(r.x_prev); })
+      .def_property_readonly("v_prev", [](const ForwardInformation &r) { return toNp(r.v_prev); })
+      .def_property_readonly("f", [](const ForwardInformation &r) { return toNp(r.f); })
+      .def_property_readonly("r", [](const ForwardInformation &r) { return toNp(r.r); })
+      .def_property_readonly("x_fixedpoints", [](const ForwardInformation &r) { return toNp(r.x_fixedpoints); })
+      .def_readonly("stepIdx", &ForwardInformation::stepIdx)
+      .def_readonly("sysMatId", &ForwardInformation::sysMatId)
+      .def_readonly("t", &ForwardInformation::t)
+      .def_readonly("avgDeformation", &ForwardInformation::avgDeformation)
+      .def_readonly("maxDeformation", &ForwardInformation::maxDeformation)
+      .def_readonly("converged", &ForwardInformation::converged)
+      .def_readonly("convergeIter", &ForwardInformation::convergeIter)
+      .def_property_readonly("collisionInfos", [](const ForwardInformation &r) {
+        // completeCollisionInfo = ((primitive contacts, self contacts), layers)
+        return py::make_tuple(py::make_tuple(r.primitiveCollisions, std::vector<SelfCollisionInformation>()),
+                              std::vector<std::vector<SelfCollisionInformation>>());
+      });
+
+  py::class_<BackwardInformation>(m, "BackwardInformation")
+      .def_property_readonly("dL_dx", [](const BackwardInformation &b) { return toNp(b.dL_dx); })
+      .def_property_readonly("dL_dv", [](const BackwardInformation &b) { return toNp(b.dL_dv); })
+      .def_property_readonly("dL_dxfixed", [](const BackwardInformation &b) { return toNp(b.dL_dxfixed); })
+      .def_property_readonly("dL_dfext", [](const BackwardInformation &b) { return toNp(b.dL_dfext); })
+      .def_property_readonly("dL_dwind", [](const BackwardInformation &b) { return toNp(b.dL_dwind); })
+      .def_readonly("dL_ddensity", &BackwardInformation::dL_ddensity)
+      .def_readonly("dL_dk_pertype", &BackwardInformation::dL_dk_pertype)
+      .def_readonly("dL_dmu", &BackwardInformation::dL_dmu)
+      .def_readonly("loss", &BackwardInformation::loss)
+      .def_readonly("totalRuntime", &BackwardInformation::totalRuntime)
+      .def_readonly("converged", &BackwardInformation::converged)
+      .def_readonly("convergedAccum", &BackwardInformation::convergedAccum)
+      .def_readonly("backwardIters", &BackwardInformation::backwardIters)
+      .def_readonly("backwardTotalIters", &BackwardInformation::backwardTotalIters);
+
+  py::class_<BackwardTaskInformation>(m, "BackwardTaskInformation")
+      .def(py::init<>())
+      .def_readwrite("dL_dk_pertype", &BackwardTaskInformation::dL_dk_pertype)
+      .def_readwrite("dL_density", &BackwardTaskInformation::dL_density)
+      .def_readwrite("dL_dfext", &BackwardTaskInformation::dL_dfext)
+      .def_readwrite("dL_dfwind", &BackwardTaskInformation::dL_dfwind)
+      .def_readwrite("adddr_dd", &BackwardTaskInformation::adddr_dd)
+      .def_readwrite("dL_dcontrolPoints", &BackwardTaskInformation::dL_dcontrolPoints)
+      .def_readwrite("dL_dmu", &BackwardTaskInformation::dL_dmu)
+      .def_readwrite("mu_primitives", &BackwardTaskInformation::mu_primitives)
+      .def_readwrite("dL_dx0", &BackwardTaskInformation::dL_dx0)
+      .def_readwrite("dL_dwindFactor", &BackwardTaskInformation::dL_dwindFactor)
+      .def_readonly("forwardAccuracyLevel", &BackwardTaskInformation::forwardAccuracyLevel)
+      .def_readonly("backwardAccuracyLevel", &BackwardTaskInformation::backwardAccuracyLevel)
+      .def_readonly("randSeed", &BackwardTaskInformation::randSeed)
+      .def_readonly("srandSeed", &BackwardTaskInformation::srandSeed);
+
+  py::class_<LossInfo>(m, "LossInfo")
+      .def_property("targetLoc", [](const LossInfo &l) { return toNp(l.targetLoc); },
+                    [](LossInfo &l, const NpArr &a) { VecXd v = toVec(a); for (int d = 0; d < 3; d++) l.targetLoc[d] = v.at(d); })
+      .def_property("targetTranslation", [](const LossInfo &l) { return toNp(l.targetTranslation); },
+                    [](LossInfo &l, const NpArr &a) { VecXd v = toVec(a); for (int d = 0; d < 3; d++) l.targetTranslation[d] = v.at(d); })
+      .def_property("targetFrameShape",
+                    [](const LossInfo &l) { py::list out; for (auto &p : l.targetFrameShape) out.append(py::make_tuple(p.first, toNp(p.second))); return out; },
+                    [](LossInfo &l, const std::vector<std::pair<int, NpArr>> &v) { l.targetFrameShape.clear(); for (auto &p : v) l.targetFrameShape.push_back({p.first, toVec(p.second)}); });
+
+  py::class_<Primitive> primitive(m, "Primitive");
+  py::enum_<PrimitiveType>(primitive, "PrimitiveType")
+      .value("PLANE", PLANE).value("CUBE", CUBE).value("SPHERE", SPHERE).value("CAPSULE", CAPSULE)
+      .value("FOOT", FOOT_PRIM).value("LOWER_LEG", LOWER_LEG).value("BOWL", BOWL).export_values();
+  primitive.def_readwrite("primitives", &Primitive::primitives)
+      .def_readwrite("isPrimitiveCollection", &Primitive::isPrimitiveCollection)
+      .def_readwrite("type", &Primitive::type)
+      .def_property("center", [](const Primitive &p) { return toNp(p.center); },
+                    [](Primitive &p, const NpArr &a) { VecXd v = toVec(a); for (int d = 0; d < 3; d++) p.center[d] = v.at(d); })
+      .def_property_readonly("centerInit", [](const Primitive &p) { return toNp(p.centerInit); })
+      .def_readonly("radius", &Primitive::radius)
+      .def_readwrite("mu", &Primitive::mu)
+      .def("getPointVec", [](const Primitive &p) { return toNp(p.getPointVec()); }, "getPointVec");
+
+  py::class_<Simulation>(m, "Simulation")
+      .def_readonly("taskLossInfo", &Simulation::taskLossInfo)
+      .def_readonly("primitives", &Simulation::primitives)
+      .def_readonly("sceneConfig", &Simulation::sceneConfig)
+      .def_readwrite("forwardRecords", &Simulation::forwardRecords)
+      .def_readwrite("useCustomRLFixedPoint", &Simulation::useCustomRLFixedPoint)
+      .def_property("perStepGradient",
+                    [](const Simulation &s) { py::list out; for (auto &g : s.perStepGradient) out.append(toNp(g)); return out; },
+                    [](Simulation &s, const std::vector<NpArr> &v) { s.perStepGradient.clear(); for (auto &a : v) s.perStepGradient.push_back(toVec(a)); })
+      .def_readwrite("gradientClipping", &Simulation::gradientClipping)
+      .def_readwrite("gradientClippingThreshold", &Simulation::gradientClippingThreshold)
+      .def_readwrite("backwardGradientForceDirectSolver", &Simulation::backwardGradientForceDirectSolver)
+      .def_property_readonly("ndof_u", &Simulation::getActionDim)
+      .def_property_readonly("num_particles", &Simulation::getNumParticles)
+      .def_readwrite_static("forwardConvergenceThreshold", &Simulation::forwardConvergenceThreshold)
+      .def_readwrite_static("backwardConvergenceThreshold", &Simulation::backwardConvergenceThreshold)
+      .def_readwrite_static("assetRoot", &Simulation::assetRoot)
+      .def("resetSystem", &Simulation::resetSystem, "reset the simulation")
+      .def("step", &Simulation::step, "forward one step")
+      .def("getCurrentPosVelocityVec", [](const Simulation &s) { auto p = s.getCurrentPosVelocityVec(); return py::make_tuple(toNp(p.first), toNp(p.second)); }, "get posvel vecs")
+      .def("appendPerStepGradient", [](Simulation &s, const NpArr &x) { s.appendPerStepGradient(toVec(x)); }, "append grad", py::arg("x"))
+      .def("stepNN", [](Simulation &s, int idx, const NpArr &x, const NpArr &v, const NpArr &fp) { s.stepNN(idx, toVec(x), toVec(v), toVec(fp)); },
+           "forward one step with arg", py::arg("idx"), py::arg("x"), py::arg("v"), py::arg("fixedPointPos"))
+      .def("setWindAndCollision", &Simulation::setWindAncCollision, "setWindAndCollision", py::arg("windEnable"), py::arg("collisionEnable"),
+           py::arg("selfCollisionEnable"), py::arg("enableConstantForcefield"))
+      .def("getStateInfo", &Simulation::getStateInfo, "get the forward info of the current step")
+      .def("setAction", [](Simulation &s, const NpArr &a) { s.setAction(toVec(a)); }, "set the target position for clips")
+      .def("exportCurrentMeshPos", &Simulation::exportCurrentMeshPos, "export the mesh at certain step", py::arg("step"), py::arg("filename"))
+      .def("setPrintVerbose", &Simulation::setPrintVerbose, "set whether to print verbose info", py::arg("flag"))
+      .def("getPastStateInfo", &Simulation::getPastStateInfo, "get the forward info of a past time step", py::arg("stepIdx"))
+      .def("exportCurrentSimulation", &Simulation::exportCurrentSimulation, "export the simulation to files", py::arg("fileName"))
+      .def("stepBackward",
+           [](Simulation &s, BackwardTaskInformation &ti, BackwardInformation &g, const ForwardInformation &f, bool isStart, const NpArr &ix, const NpArr &iv) {
+             return s.stepBackward(ti, g, f, isStart, toVec(ix), toVec(iv));
+           }, "stepbackward one step", py::arg("taskInfo"), py::arg("dL_dxvfnew"), py::arg("forwardInfo_new"), py::arg("isStart"),
+           py::arg("dL_dxinit"), py::arg("dL_dvinit"))
+      .def("stepBackwardNN",
+           [](Simulation &s, BackwardTaskInformation &ti, const NpArr &gx, const NpArr &gv, const ForwardInformation &f, bool isStart, const NpArr &ix, const NpArr &iv) {
+             VecXd a = toVec(gx), b = toVec(gv);
+             return s.stepBackwardNN(ti, a, b, f, isStart, toVec(ix), toVec(iv));
+           }, "stepbackward one step", py::arg("taskInfo"), py::arg("dL_dxnew"), py::arg("dL_dvnew"), py::arg("forwardInfo_new"), py::arg("isStart"),
+           py::arg("dL_dxinit"), py::arg("dL_dvinit"))
+      // additive: rest mesh access for callers that build their own inputs
+      .def("getRestPositions", [](const Simulation &s) { return toNp(s.restPositions()); })
+      .def("getTriangles", [](const Simulation &s) { return s.triangles(); })
+      .def("getAttachmentVertices", [](const Simulation &s) { return s.attachments(); });
+
+  py::class_<OptimizeHelper>(m, "OptimizeHelper")
+      .def_readonly("forward_steps", &OptimizeHelper::forward_steps)
+      .def_readonly("sim", &OptimizeHelper::sim, py::return_value_policy::reference)
+      .def_readonly("taskInfo", &OptimizeHelper::taskInfo)
+      .def_readonly("lossType", &OptimizeHelper::lossType)
+      .def_readonly("lossInfo", &OptimizeHelper::lossInfo);
+
+  m.def("makeSim", &makeSim, "initialize a simulation instance", py::arg("exampleName"), py::arg("runBackward") = true);
+  m.def("makeSimFromMesh",
+        [](const std::string &sceneName, const NpArr &verts, const std::vector<int> &tris, bool runBackward) {
+          return Simulation::createSystemFromMesh(sceneByName(sceneName), toVec(verts), tris, runBackward);
+        }, "additive: build a scene from an in-memory mesh (raw file coordinates) instead of an asset path",
+        py::arg("sceneName"), py::arg("verts"), py::arg("tris"), py::arg("runBackward") = true);
+  m.def("makeOptimizeHelper", &makeOptimizeHelper, "initialize an optimize helper", py::arg("exampleName"));
+  m.def("makeOptimizeHelperWithSim", &makeOptimizeHelperWithSim, "initialize an optimize helper", py::arg("exampleName"), py::arg("sim"));
+  m.def("enableOpenMP", [](int n_threads) { (void) n_threads; std::printf("diffcloth_py (MI355X): host threads are not used by the GPU stepper\n"); },
+        "set up Open MP", py::arg("n_threads") = 5);
+  m.def("render", [](Simulation *, bool, bool) { throw std::runtime_error("render: the OpenGL viewer is not part of the MI355X stepper"); },
+        "rendering the previous trajectry", py::arg("sim"), py::arg("renderPosPairs") = false, py::arg("autoExit") = true);
+}

@@ -1,0 +1,444 @@
+// Host-side `Simulation` (see simulation.h). Scene construction follows the reference's
+// Simulation::createSystem / createClothMeshFromConfig / createClothMeshFromModel / createAttachments / initScene
+// (reference Simulation.cpp:1804-2067, 2170-2405, 2611-2757); the per-step work is delegated to the dc_* C-ABI.
+#include "simulation.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace dchost {
+
+double Simulation::forwardConvergenceThreshold = 1e-7;          // Simulation.cpp:17
+double Simulation::backwardConvergenceThreshold = 1e-4 * 0.5;   // Simulation.cpp:19
+std::string Simulation::assetRoot = "";
+
+namespace {
+
+typedef std::array<double, 9> Mat3;
+Mat3 axisAngle(Vec3d axis, double angle) {
+  double n = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+  double x = axis[0] / n, y = axis[1] / n, z = axis[2] / n, c = std::cos(angle), s = std::sin(angle), t = 1 - c;
+  return {t * x * x + c, t * x * y - s * z, t * x * z + s * y, t * x * y + s * z, t * y * y + c, t * y * z - s * x,
+          t * x * z - s * y, t * y * z + s * x, t * z * z + c};
+}
+Mat3 identity3() { return {1, 0, 0, 0, 1, 0, 0, 0, 1}; }
+Mat3 mul(const Mat3 &a, const Mat3 &b) {
+  Mat3 c{};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) c[3 * i + j] += a[3 * i + k] * b[3 * k + j];
+  return c;
+}
+Vec3d rotv(const Mat3 &m, const Vec3d &v) {
+  return {m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]};
+}
+Vec3d normalized(Vec3d v) { double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); return {v[0] / n, v[1] / n, v[2] / n}; }
+// engine/UtilityFunctions.h:77-88
+Mat3 axisToRotation(Vec3d finalDir, Vec3d initialDir) {
+  finalDir = normalized(finalDir); initialDir = normalized(initialDir);
+  Vec3d d = {finalDir[0] - initialDir[0], finalDir[1] - initialDir[1], finalDir[2] - initialDir[2]};
+  if (std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > 1e-5) {
+    Vec3d perp = {initialDir[1] * finalDir[2] - initialDir[2] * finalDir[1], initialDir[2] * finalDir[0] - initialDir[0] * finalDir[2],
+                  initialDir[0] * finalDir[1] - initialDir[1] * finalDir[0]};
+    double angle = std::acos(finalDir[0] * initialDir[0] + finalDir[1] * initialDir[1] + finalDir[2] * initialDir[2]);
+    return axisAngle(perp, angle);
+  }
+  return identity3();
+}
+void bbox(const VecXd &p, Vec3d &mn, Vec3d &mx) {
+  mn = mx = {p[0], p[1], p[2]};
+  for (size_t i = 0; i < p.size() / 3; i++)
+    for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], p[3 * i + d]); mx[d] = std::max(mx[d], p[3 * i + d]); }
+}
+void check(dc_ctx *c, int rc, const char *what) {
+  if (rc != DC_OK) throw std::runtime_error(std::string(what) + ": " + (c ? dc_last_error(c) : "no context"));
+}
+// engine/MeshFileHandler.h:137-267 (OBJ subset: v / f with optional /vt/vn)
+void loadObj(const std::string &path, VecXd &verts, std::vector<int> &tris) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("cannot open mesh file " + path);
+  std::string line;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::string tag;
+    ss >> tag;
+    if (tag == "v") { double x, y, z; ss >> x >> y >> z; verts.push_back(x); verts.push_back(y); verts.push_back(z); }
+    else if (tag == "f") {
+      std::vector<int> idx;
+      std::string tok;
+      while (ss >> tok) idx.push_back(std::stoi(tok.substr(0, tok.find('/'))) - 1);
+      for (size_t k = 1; k + 1 < idx.size(); k++) { tris.push_back(idx[0]); tris.push_back(idx[k]); tris.push_back(idx[k + 1]); }
+    }
+  }
+}
+
+}  // namespace
+
+Simulation::~Simulation() {
+  if (ctx) dc_destroy(ctx);
+}
+
+// rotatePointsAccordingToConfig + rotatePointsAroundCenter (Simulation.h:641-671, Simulation.cpp:2151-2168)
+static void orientPoints(VecXd &p, const SceneConfiguration &cfg) {
+  Mat3 R = identity3();
+  switch (cfg.orientation) {
+    case FRONT: return;
+    case DOWN: R = axisToRotation({0, 1, 0}, {0, 0, 1}); break;
+    case BACK: R = mul(axisToRotation({0, 0, 1}, {1, 0, 0}), axisToRotation({1, 0, 0}, {0, 0, -1})); break;
+    case CUSTOM_ORIENTATION: R = axisToRotation(cfg.upVector, {0, 1, 0}); break;
+  }
+  Vec3d mn, mx;
+  bbox(p, mn, mx);
+  for (size_t i = 0; i < p.size() / 3; i++) {
+    Vec3d q = rotv(R, {p[3 * i] - mn[0], p[3 * i + 1] - mn[1], p[3 * i + 2] - mn[2]});
+    p[3 * i] = q[0]; p[3 * i + 1] = q[1]; p[3 * i + 2] = q[2];
+  }
+}
+
+Simulation *Simulation::createSystem(SceneConfiguration cfg, Vec3d /*center*/, bool runBackward_) {
+  VecXd pts;
+  std::vector<int> tr;
+  if (cfg.fabric.isModel) {
+    std::string root = assetRoot;
+    if (root.empty()) { const char *e = std::getenv("DIFFCLOTH_ASSETS"); root = e ? e : "/root/reference/src/assets/meshes"; }
+    loadObj(root + "/" + cfg.fabric.name, pts, tr);
+  } else {
+    // getInitParticlePos (Simulation.cpp:1783-1791) + triangle pattern of createClothMeshFromConfig (:2716-2735)
+    const int nx = cfg.fabric.gridNumX, ny = cfg.fabric.gridNumY;
+    const double gsx = cfg.fabric.clothDimX / (nx - 1), gsy = cfg.fabric.clothDimY / (ny - 1);
+    for (int i = 0; i < ny; i++)
+      for (int j = 0; j < nx; j++) { pts.push_back(j * gsy - (ny - 1) / 4.0 * gsy); pts.push_back(15 - i * gsx); pts.push_back(0); }
+    auto pid = [&](int a, int b) { return (a < 0 || b < 0 || a >= ny || b >= nx) ? -1 : a * nx + b; };
+    for (int i = 0; i < ny; i++)
+      for (int j = 0; j < nx; j++) {
+        int self = pid(i, j), left = pid(i, j - 1), up = pid(i - 1, j), upRight = pid(i - 1, j + 1);
+        if (self >= 0 && up >= 0 && upRight >= 0) { tr.push_back(upRight); tr.push_back(up); tr.push_back(self); }   // createTriangle stores (c,b,a)
+        if (up >= 0 && self >= 0 && left >= 0) { tr.push_back(left); tr.push_back(self); tr.push_back(up); }
+      }
+  }
+  Simulation *s = new Simulation();
+  s->sceneConfig = cfg;
+  s->runBackward = runBackward_;
+  try {
+    s->buildFromMesh(pts, tr, cfg.fabric.isModel);
+  } catch (...) { delete s; throw; }
+  return s;
+}
+
+Simulation *Simulation::createSystemFromMesh(SceneConfiguration cfg, const VecXd &verts, const std::vector<int> &tr, bool runBackward_) {
+  Simulation *s = new Simulation();
+  s->sceneConfig = cfg;
+  s->runBackward = runBackward_;
+  try {
+    s->buildFromMesh(verts, tr, true);
+  } catch (...) { delete s; throw; }
+  return s;
+}
+
+void Simulation::buildFromMesh(VecXd pts, const std::vector<int> &tr, bool isModel) {
+  orientPoints(pts, sceneConfig);
+  Vec3d mn, mx;
+  bbox(pts, mn, mx);
+  Vec3d dim = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+  N = (int) pts.size() / 3;
+  if (isModel) {   // createClothMeshFromModel (Simulation.cpp:2170-2226)
+    const bool keep = sceneConfig.fabric.keepOriginalScalePoint;
+    double scale = keep ? 1.0 : std::max(std::max(dim[0], dim[1]), dim[2]) / sceneConfig.fabric.clothDimX;
+    if (keep) { restShapeMaxDim = mx; restShapeMinDim = mn; }
+    else {
+      for (int d = 0; d < 3; d++) { restShapeMaxDim[d] = dim[d] / scale; restShapeMinDim[d] = 0; }
+      Vec3d tr2 = {restShapeMaxDim[0] / 2, restShapeMaxDim[1] / 2, restShapeMaxDim[2] / 2};
+      for (int d = 0; d < 3; d++) { restShapeMinDim[d] -= tr2[d]; restShapeMaxDim[d] -= tr2[d]; }
+      for (int i = 0; i < N; i++)
+        for (int d = 0; d < 3; d++) pts[3 * i + d] = (pts[3 * i + d] - mn[d]) / scale - restShapeMaxDim[d];
+    }
+  } else {         // createClothMeshFromConfig (Simulation.cpp:2677-2703)
+    if (!sceneConfig.fabric.keepOriginalScalePoint)
+      for (int i = 0; i < N; i++)
+        for (int d = 0; d < 3; d++) pts[3 * i + d] = pts[3 * i + d] - mn[d] - dim[d] / 2;
+    for (int d = 0; d < 3; d++) { restShapeMaxDim[d] = dim[d] / 2; restShapeMinDim[d] = -dim[d] / 2; }
+  }
+  for (int d = 0; d < 3; d++) restShapeMidPoint[d] = 0.5 * (restShapeMinDim[d] + restShapeMaxDim[d]);
+  rest = pts;
+  tris = tr;
+
+  // createAttachments (Simulation.cpp:2258-2405)
+  attachmentVertices.clear();
+  if (sceneConfig.attachmentPoints == CUSTOM_ARRAY) {
+    if (!sceneConfig.customAttachmentVertexIdx.empty()) attachmentVertices = sceneConfig.customAttachmentVertexIdx[0].second;
+  } else if (sceneConfig.attachmentPoints == LEFT_RIGHT_CORNERS_2) {
+    if (isModel) {
+      double zmid = (restShapeMinDim[2] + restShapeMaxDim[2]) / 2.0;
+      Vec3d goals[2] = {{restShapeMinDim[0], restShapeMaxDim[1], zmid}, {restShapeMaxDim[0], restShapeMaxDim[1], zmid}};
+      for (auto &g : goals) {
+        int best = 0;
+        auto d2 = [&](int i) { double s = 0; for (int d = 0; d < 3; d++) s += (rest[3 * i + d] - g[d]) * (rest[3 * i + d] - g[d]); return std::sqrt(s); };
+        for (int i = 0; i < N; i++) if (d2(i) < d2(best)) best = i;
+        attachmentVertices.push_back(best);
+      }
+    } else {
+      attachmentVertices.push_back(0);
+      attachmentVertices.push_back(sceneConfig.fabric.gridNumX - 1);
+    }
+  }
+  fixedPointRest.clear();
+  for (int a : attachmentVertices) for (int d = 0; d < 3; d++) fixedPointRest.push_back(rest[3 * a + d]);
+  fixedPointCur = fixedPointRest;
+  initScene();
+  configureDevice();
+  resetSystem();
+}
+
+// Simulation::initScene (Simulation.cpp:1804-2067): analytic obstacles of the shipped scenes.
+void Simulation::initScene() {
+  primitives.clear();
+  Vec3d low = {restShapeMidPoint[0], restShapeMinDim[1], restShapeMidPoint[2]};
+  switch (sceneConfig.primitiveConfig) {
+    case PLANE_AND_SPHERE: {        // :1894-1903
+      Primitive s; s.type = SPHERE; s.radius = 2; s.mu = 0.9;
+      Vec3d plane = {low[0], low[1] - (s.radius * 2 + 0.1), low[2]};
+      s.center = s.centerInit = {plane[0] + s.radius * 0.3, plane[1] + s.radius, plane[2] + s.radius * 0.1};
+      primitives.push_back(s);
+      break;
+    }
+    case PLANE_BUST_WEARHAT: {      // :1932-1944
+      Primitive s; s.type = SPHERE; s.radius = 2.1; s.mu = 0.1;
+      Vec3d plane = {low[0], low[1] - 0.5, low[2] - 4};
+      s.center = s.centerInit = {plane[0], plane[1] + s.radius + 0.5, plane[2] - 4};
+      primitives.push_back(s);
+      break;
+    }
+    case BIG_SPHERE: {              // :1905-1912
+      Primitive s; s.type = SPHERE; s.radius = 15; s.mu = 0.0; s.center = s.centerInit = {-0.50, -16.00, 0.00};
+      primitives.push_back(s);
+      break;
+    }
+    case FOOT: {                    // :1916-1925 + LowerLeg::createNewMesh (Primitive.h:350-374)
+      Primitive leg; leg.type = LOWER_LEG; leg.isPrimitiveCollection = true; leg.mu = 0;
+      Vec3d high = {restShapeMidPoint[0], restShapeMaxDim[1], restShapeMidPoint[2]};
+      leg.center = leg.centerInit = {high[0], high[1] + 3, high[2] - 4};
+      const double radius = 0.8, footLength = 4, legLength = 5;
+      Vec3d axis = normalized(sceneConfig.sockLegOrientation);
+      Mat3 footRot = axisToRotation(axis, {0, 1, 0});                       // foot: parentAxis (0,1,0), axis
+      Vec3d footGlobalAxis = rotv(footRot, {0, 1, 0});
+      Mat3 footGlobalRot = axisToRotation(footGlobalAxis, {0, 1, 0});
+      Vec3d legCenter = rotv(footRot, {0, footLength, 0});
+      Mat3 legRot = axisToRotation({0, 0.7, 0.3}, {0, 1, 0});               // leg: parentAxis = axis, axis (0,0.7,0.3)
+      Vec3d legGlobalAxis = rotv(legRot, axis);
+      Mat3 legGlobalRot = axisToRotation(legGlobalAxis, {0, 1, 0});
+      Primitive joint; joint.type = SPHERE; joint.radius = radius + 0.05; joint.centerInit = joint.center = legCenter;
+      Primitive foot; foot.type = CAPSULE; foot.radius = radius; foot.length = footLength; foot.centerInit = foot.center = {0, 0, 0};
+      foot.topOffset = rotv(footGlobalRot, {0, footLength, 0});
+      Primitive lg; lg.type = CAPSULE; lg.radius = radius; lg.length = legLength; lg.centerInit = lg.center = legCenter;
+      lg.topOffset = rotv(legGlobalRot, {0, legLength, 0});
+      leg.primitives = {joint, foot, lg};
+      primitives.push_back(leg);
+      break;
+    }
+    default: break;
+  }
+}
+
+void Simulation::configureDevice() {
+  check(nullptr, dc_create(0, &ctx) == DC_OK ? DC_OK : DC_ERR_HIP, "dc_create (no HIP device: the stepper has no CPU path)");
+  check(ctx, dc_set_mesh(ctx, N, rest.data(), (int) tris.size() / 3, tris.data()), "dc_set_mesh");
+  check(ctx, dc_set_attachments(ctx, (int) attachmentVertices.size(), attachmentVertices.data()), "dc_set_attachments");
+  std::vector<dc_primitive> flat;
+  for (size_t g = 0; g < primitives.size(); g++) {
+    const Primitive &p = primitives[g];
+    auto add = [&](const Primitive &q, const Vec3d &c) {
+      dc_primitive d{};
+      d.kind = q.type == CAPSULE ? DC_PRIM_CAPSULE : DC_PRIM_SPHERE;
+      d.group = (int) g;
+      for (int k = 0; k < 3; k++) { d.center[k] = c[k]; d.top_offset[k] = q.topOffset[k]; }
+      d.radius = q.radius; d.length = q.length; d.mu = p.mu; d.rotates = q.rotates;
+      flat.push_back(d);
+    };
+    if (p.isPrimitiveCollection)
+      for (const Primitive &q : p.primitives) add(q, {p.center[0] + q.centerInit[0], p.center[1] + q.centerInit[1], p.center[2] + q.centerInit[2]});
+    else add(p, p.center);
+  }
+  check(ctx, dc_set_primitives(ctx, (int) flat.size(), flat.data()), "dc_set_primitives");
+  dc_params prm;
+  dc_default_params(&prm);
+  prm.time_step = sceneConfig.timeStep;
+  prm.density = sceneConfig.fabric.density;
+  prm.k_stretch = sceneConfig.fabric.k_stiff_stretching;
+  prm.k_bend = sceneConfig.fabric.k_stiff_bending;
+  for (int d = 0; d < 3; d++) prm.gravity[d] = gravity[d];
+  prm.gravity_enabled = gravityEnabled; prm.contact_enabled = contactEnabled; prm.selfcollision_enabled = selfcollisionEnabled;
+  prm.forward_tol = forwardConvergenceThreshold; prm.backward_tol = backwardConvergenceThreshold;
+  prm.gradient_clipping = gradientClipping; prm.gradient_clipping_threshold = gradientClippingThreshold;
+  check(ctx, dc_set_params(ctx, &prm), "dc_set_params");
+  check(ctx, dc_build(ctx), "dc_build");
+  tapeSlots = std::max(sceneConfig.stepNum, 1) + 8;
+  check(ctx, dc_alloc_batch(ctx, 1, tapeSlots), "dc_alloc_batch");
+  paramsFwdTol = prm.forward_tol; paramsBwdTol = prm.backward_tol; paramsClip = gradientClipping;
+  paramsClipThr = gradientClippingThreshold; paramsDirect = false;
+}
+
+// The reference reads its mutable statics at every step; mirror that by refreshing the solver knobs when they changed.
+void Simulation::pushParams() {
+  if (paramsFwdTol == forwardConvergenceThreshold && paramsBwdTol == backwardConvergenceThreshold &&
+      paramsClip == gradientClipping && paramsClipThr == gradientClippingThreshold && paramsDirect == backwardGradientForceDirectSolver)
+    return;
+  check(ctx, dc_set_solver(ctx, forwardConvergenceThreshold, backwardConvergenceThreshold, gradientClipping ? 1 : 0,
+                           gradientClippingThreshold, backwardGradientForceDirectSolver ? 1 : 0), "dc_set_solver");
+  paramsFwdTol = forwardConvergenceThreshold; paramsBwdTol = backwardConvergenceThreshold; paramsClip = gradientClipping;
+  paramsClipThr = gradientClippingThreshold; paramsDirect = backwardGradientForceDirectSolver;
+}
+
+void Simulation::setWindAncCollision(bool wind_, bool collision, bool selfCollision, bool) {
+  windEnabled = wind_; contactEnabled = collision; selfcollisionEnabled = selfCollision;
+  check(ctx, dc_set_flags(ctx, gravityEnabled ? 1 : 0, contactEnabled ? 1 : 0, selfcollisionEnabled ? 1 : 0), "dc_set_flags");
+}
+
+// Simulation::resetSystem (Simulation.cpp:3490-3584 without the parameter overloads): back to the rest pose.
+void Simulation::resetSystem() {
+  forwardRecords.clear();
+  perStepGradient.clear();
+  ForwardInformation r0;
+  r0.x = rest; r0.v.assign(rest.size(), 0.0);
+  r0.x_prev = r0.x; r0.v_prev = r0.v;
+  r0.f.assign(rest.size(), 0.0); r0.r = r0.f; r0.s_n = r0.x;
+  r0.x_fixedpoints = fixedPointRest;
+  r0.stepIdx = 0; r0.deviceSlot = 0; r0.t = 0;
+  forwardRecords.push_back(r0);
+  fixedPointCur = fixedPointRest;
+  check(ctx, dc_set_state(ctx, 0, r0.x.data(), r0.v.data()), "dc_set_state");
+}
+
+double Simulation::windFactorAt(double t) const {   // fillForces (Simulation.cpp:64-87)
+  switch (sceneConfig.windConfig) {
+    case WIND_SIN: case WIND_SIN_AND_FALLOFF: return (std::sin(windFrequency * t + windPhase) + 1.0) / 2.0;
+    case NO_WIND: return 0.0;
+    default: return 1.0;
+  }
+}
+
+// stepFixPoints (Simulation.cpp:964-1018): PER_STEP (RL action), dress twirl, otherwise the points stay put
+// (the cubic-Hermite spline trajectories of Spline.h are a host-side next-tier item).
+VecXd Simulation::fixedPointTargets(double) {
+  const size_t Af = attachmentVertices.size();
+  if (sceneConfig.trajectory == PER_STEP_TRAJECTORY && rlFixedPointPos.size() == 3 * Af) fixedPointCur = rlFixedPointPos;
+  else if (sceneConfig.trajectory == TRAJECTORY_DRESS_TWIRL) {
+    Mat3 R = axisAngle({0, 1, 0}, 0.02);
+    for (size_t a = 0; a < Af; a++) {
+      Vec3d c = {restShapeMidPoint[0], fixedPointCur[3 * a + 1], restShapeMidPoint[2]};
+      Vec3d rel = {fixedPointCur[3 * a] - c[0], 0.0, fixedPointCur[3 * a + 2] - c[2]};
+      Vec3d q = rotv(R, rel);
+      fixedPointCur[3 * a] = q[0] + c[0]; fixedPointCur[3 * a + 2] = q[2] + c[2];
+    }
+  }
+  return fixedPointCur;
+}
+
+void Simulation::step() {
+  if ((int) forwardRecords.size() >= tapeSlots) throw std::runtime_error("Simulation::step: tape exhausted (stepNum + 8 records)");
+  pushParams();
+  const ForwardInformation &prev = forwardRecords.back();
+  ForwardInformation rec;
+  rec.t = prev.t + sceneConfig.timeStep;
+  rec.stepIdx = (int) forwardRecords.size();
+  rec.deviceSlot = prev.deviceSlot + 1;
+  rec.x_prev = prev.x; rec.v_prev = prev.v;
+  rec.windFactor = windFactorAt(rec.t);
+  if (windEnabled) {
+    double f[3];
+    for (int d = 0; d < 3; d++) f[d] = wind[d] * windNorm * rec.windFactor;
+    check(ctx, dc_set_uniform_force(ctx, f), "dc_set_uniform_force");
+  } else check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
+  rec.x_fixedpoints = fixedPointTargets(rec.t);
+  dc_step_stats st;
+  check(ctx, dc_step_forward(ctx, prev.deviceSlot, rec.x_fixedpoints.empty() ? nullptr : rec.x_fixedpoints.data(), &st), "dc_step_forward");
+  rec.x.resize(3 * (size_t) N); rec.v.resize(3 * (size_t) N); rec.f.resize(3 * (size_t) N); rec.r.resize(3 * (size_t) N);
+  check(ctx, dc_get_state(ctx, rec.deviceSlot, rec.x.data(), rec.v.data()), "dc_get_state");
+  check(ctx, dc_get_record(ctx, rec.deviceSlot, rec.f.data(), rec.r.data()), "dc_get_record");
+  std::vector<int> grp(N);
+  VecXd nrm(3 * (size_t) N);
+  check(ctx, dc_get_contacts(ctx, rec.deviceSlot, grp.data(), nrm.data()), "dc_get_contacts");
+  for (int i = 0; i < N; i++)
+    if (grp[i] >= 0) rec.primitiveCollisions.push_back({grp[i], i, {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}});
+  rec.converged = st.converged != 0;
+  rec.convergeIter = st.pd_iters;
+  rec.totalConverged = prev.totalConverged + (rec.converged ? 1 : 0);
+  rec.cumulateIter = prev.cumulateIter + st.pd_iters;
+  rec.s_n.assign(3 * (size_t) N, 0.0);
+  forwardRecords.push_back(std::move(rec));
+}
+
+// Simulation::stepNN (Simulation.cpp:1020-1042)
+void Simulation::stepNN(int idx, const VecXd &x, const VecXd &v, const VecXd &fixedPointPos) {
+  sceneConfig.trajectory = PER_STEP_TRAJECTORY;
+  if (x.size() != 3 * (size_t) N || v.size() != 3 * (size_t) N) throw std::runtime_error("stepNN: x / v must have 3 * num_particles entries");
+  if (fixedPointPos.size() != 3 * attachmentVertices.size())
+    std::fprintf(stderr, "WARNING: require %zu fixed point dofs but input fixed point dof is %zu\n", 3 * attachmentVertices.size(), fixedPointPos.size());
+  ForwardInformation &cur = forwardRecords.back();
+  cur.x = x; cur.v = v;
+  check(ctx, dc_set_state(ctx, cur.deviceSlot, x.data(), v.data()), "dc_set_state");
+  rlFixedPointPos = fixedPointPos;
+  step();
+  forwardRecords.back().stepIdx = idx;
+}
+
+// Simulation::stepBackwardNN (Simulation.cpp:1443-1452)
+BackwardInformation Simulation::stepBackwardNN(BackwardTaskInformation &taskInfo, VecXd &dL_dxnew, VecXd &dL_dvnew,
+                                               const ForwardInformation &forwardInfo_new, bool isStart, const VecXd &dL_dxinit,
+                                               const VecXd &dL_dvinit) {
+  BackwardInformation g;
+  g.dL_dx = dL_dxnew; g.dL_dv = dL_dvnew;
+  return stepBackward(taskInfo, g, forwardInfo_new, isStart, dL_dxinit, dL_dvinit);
+}
+
+// Simulation::stepBackward (Simulation.cpp:1455-1780)
+BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,
+                                             const ForwardInformation &fwd, bool isStart, const VecXd &dL_dxinit, const VecXd &dL_dvinit) {
+  const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
+  if (gradient_new.dL_dx.size() != n3 || gradient_new.dL_dv.size() != n3) throw std::runtime_error("stepBackward: gradient size mismatch");
+  if (fwd.deviceSlot < 1 || fwd.deviceSlot >= (int) forwardRecords.size() + 1) throw std::runtime_error("stepBackward: record has no device slot");
+  pushParams();
+  BackwardInformation ret;
+  ret.dL_dx.resize(n3); ret.dL_dv.resize(n3);
+  VecXd dxf(3 * std::max<size_t>(Af, 1), 0.0);
+  VecXd dmu(std::max<size_t>(primitives.size(), 1), 0.0);
+  const bool haveInit = dL_dxinit.size() == n3 && dL_dvinit.size() == n3;
+  dc_bwd_stats st;
+  check(ctx, dc_step_backward(ctx, fwd.deviceSlot, gradient_new.dL_dx.data(), gradient_new.dL_dv.data(),
+                              haveInit ? dL_dxinit.data() : nullptr, haveInit ? dL_dvinit.data() : nullptr, isStart ? 1 : 0,
+                              ret.dL_dx.data(), ret.dL_dv.data(), dxf.data(), dmu.data(), &st), "dc_step_backward");
+  ret.converged = st.converged != 0;
+  ret.backwardIters = st.adjoint_iters;
+  ret.backwardTotalIters = st.adjoint_iters + gradient_new.backwardTotalIters;
+  ret.convergedAccum = gradient_new.convergedAccum + (st.converged == 1 ? 1 : 0);
+  ret.loss = gradient_new.loss;
+  ret.dL_dxfixed.assign(3 * Af, 0.0);
+  ret.dL_dxfixed_accum.assign(3 * Af, 0.0);
+  if (taskInfo.dL_dcontrolPoints && Af > 0) {   // Simulation.cpp:1642-1660
+    ret.dL_dxfixed.assign(dxf.begin(), dxf.begin() + 3 * Af);
+    perStepGradient.push_back(ret.dL_dxfixed);
+    if (fwd.stepIdx == 1) std::reverse(perStepGradient.begin(), perStepGradient.end());
+    if (gradient_new.dL_dxfixed_accum.size() == 3 * Af)
+      for (size_t k = 0; k < 3 * Af; k++) ret.dL_dxfixed_accum[k] = ret.dL_dxfixed[k] + gradient_new.dL_dxfixed_accum[k];
+  }
+  if (taskInfo.dL_dmu)                          // Simulation.cpp:1622-1632
+    for (size_t k = 0; k < taskInfo.mu_primitives.size(); k++) {
+      int prim = taskInfo.mu_primitives[k];
+      double prev = k < gradient_new.dL_dmu.size() ? gradient_new.dL_dmu[k].second : 0.0;
+      ret.dL_dmu.push_back({prim, prev + (prim >= 0 && prim < (int) dmu.size() ? dmu[prim] : 0.0)});
+    }
+  return ret;
+}
+
+void Simulation::exportCurrentMeshPos(int step, const std::string &fileName) const {   // OBJ frame dump (Simulation.cpp:4131-4238)
+  const ForwardInformation &r = forwardRecords.at(step);
+  std::ofstream out(fileName + ".obj");
+  for (int i = 0; i < N; i++) out << "v " << r.x[3 * i] << " " << r.x[3 * i + 1] << " " << r.x[3 * i + 2] << "\n";
+  for (size_t t = 0; t < tris.size() / 3; t++) out << "f " << tris[3 * t] + 1 << " " << tris[3 * t + 1] + 1 << " " << tris[3 * t + 2] + 1 << "\n";
+}
+void Simulation::exportCurrentSimulation(const std::string &fileName) const {
+  for (size_t s = 0; s < forwardRecords.size(); s++) exportCurrentMeshPos((int) s, fileName + "_" + std::to_string(s));
+}
+
+}  // namespace dchost

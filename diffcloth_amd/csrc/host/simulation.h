@@ -1,0 +1,189 @@
+// Host-side `Simulation` of the MI355X DiffCloth stepper: keeps the entry points and record types of the
+// reference class (reference: /root/reference/src/code/simulation/Simulation.h) and forwards the hot path to
+// the C-ABI of libdiffcloth_hip.so (include/diffcloth_hip.h). No Eigen: vectors are std::vector<double> in the
+// reference's layout (xyz-interleaved, length 3N); the pybind layer exposes them as numpy arrays exactly as
+// pybind11/eigen.h does for the reference.
+//
+//   reference member                         here
+//   Simulation::step()            :703       Simulation::step()
+//   stepNN(idx,x,v,fixedPointPos) :705       Simulation::stepNN(...)
+//   stepBackward(...)             :569-572   Simulation::stepBackward(...)
+//   stepBackwardNN(...)           :564-567   Simulation::stepBackwardNN(...)
+//   createSystem(scene,center,rb) :499-500   Simulation::createSystem(...)
+//   resetSystem()                 :923-941   Simulation::resetSystem()
+//   getStateInfo/getPastStateInfo :966-989   same names
+#pragma once
+#include <array>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../../include/diffcloth_hip.h"
+
+namespace dchost {
+
+typedef std::vector<double> VecXd;
+typedef std::array<double, 3> Vec3d;
+
+enum Orientation { FRONT, DOWN, BACK, CUSTOM_ORIENTATION };                       // engine/Constants.h:35-37
+enum AttachmentConfigs { NO_ATTACHMENTS, LEFT_RIGHT_CORNERS_2, CUSTOM_ARRAY };    // :38-42
+enum TrajectoryConfigs { NO_TRAJECTORY, CORNERS_2_UP, CORNERS_2_WEARHAT, CORNERS_1_WEARHAT, CORNERS_2_WEARSOCK,
+                         TRAJECTORY_DRESS_TWIRL, FIXED_POINT_TRAJECTORY, PER_STEP_TRAJECTORY };
+enum PrimitiveConfiguration { PRIM_NONE, PLANE_AND_SPHERE, PLANE_BUST_WEARHAT, FOOT, BIG_SPHERE };
+enum WindConfig { NO_WIND, WIND_CONSTANT, WIND_SIN, WIND_SIN_AND_FALLOFF, WIND_FACTOR_PER_STEP };   // :55-61
+enum PrimitiveType { PLANE, CUBE, SPHERE, CAPSULE, FOOT_PRIM, LOWER_LEG, BOWL };
+
+struct FabricConfiguration {      // Simulation.h:103-118
+  double clothDimX = 6, clothDimY = 6;
+  double k_stiff_stretching = 100, k_stiff_bending = 0.01;
+  int gridNumX = 25, gridNumY = 25;
+  double density = 0.1;
+  bool keepOriginalScalePoint = false, isModel = false;
+  std::string name;             // mesh path (relative to the asset root) when isModel
+};
+
+struct SceneConfiguration {       // Simulation.h:276-296
+  FabricConfiguration fabric;
+  Orientation orientation = FRONT;
+  Vec3d upVector = {0, 1, 0};
+  AttachmentConfigs attachmentPoints = NO_ATTACHMENTS;
+  std::vector<std::pair<double, std::vector<int>>> customAttachmentVertexIdx;
+  TrajectoryConfigs trajectory = NO_TRAJECTORY;
+  PrimitiveConfiguration primitiveConfig = PRIM_NONE;
+  WindConfig windConfig = NO_WIND;
+  Vec3d sockLegOrientation = {0, 1, 0};
+  double timeStep = 1.0 / 90;
+  int stepNum = 100;
+  double forwardConvergenceThresh = 1e-7, backwardConvergenceThresh = 5e-4;
+  std::string name;
+};
+
+struct Primitive {                // the fields of Primitive.h the Python side reads
+  PrimitiveType type = SPHERE;
+  Vec3d center = {0, 0, 0}, centerInit = {0, 0, 0};
+  double radius = 1, length = 0, mu = 0;
+  bool rotates = false, isPrimitiveCollection = false;
+  Vec3d topOffset = {0, 0, 0};
+  std::vector<Primitive> primitives;            // children of a LowerLeg
+  VecXd getPointVec() const { return VecXd(center.begin(), center.end()); }
+};
+
+struct PrimitiveCollisionInformation { int primitiveId = -1, particleId = -1; Vec3d normal = {0, 0, 0}; };   // Simulation.h:39-51
+struct SelfCollisionInformation { int particleId1 = -1, particleId2 = -1; };
+
+struct ForwardInformation {       // Simulation.h:68-100 (hot-path fields)
+  VecXd x, v, x_prev, v_prev, f, r, s_n, x_fixedpoints;
+  std::vector<PrimitiveCollisionInformation> primitiveCollisions;
+  int sysMatId = 0;
+  double t = 0, windFactor = 0, avgDeformation = 0, maxDeformation = 0;
+  bool converged = false;
+  int convergeIter = 0, totalConverged = 0, cumulateIter = 0, stepIdx = 0;
+  double loss = 0;
+  int deviceSlot = 0;             // tape slot of libdiffcloth_hip holding this record
+};
+
+struct BackwardInformation {      // Simulation.h:136-162 (hot-path fields)
+  VecXd dL_dx, dL_dv, dL_dxfixed, dL_dxfixed_accum;
+  Vec3d dL_dfext = {0, 0, 0};
+  std::array<double, 5> dL_dwind = {0, 0, 0, 0, 0};
+  double dL_ddensity = 0;
+  std::array<double, 4> dL_dk_pertype = {0, 0, 0, 0};
+  std::vector<std::pair<int, double>> dL_dmu;
+  double loss = 0;
+  long long totalRuntime = 0;
+  bool converged = false;
+  int convergedAccum = 0, backwardIters = 0, backwardTotalIters = 0;
+};
+
+struct BackwardTaskInformation {  // Simulation.h:188-209
+  std::array<bool, 4> dL_dk_pertype = {false, false, false, false};
+  bool dL_density = false, dL_dfext = false, dL_dconstantForceField = false, dL_dfwind = false, adddr_dd = false;
+  bool dL_dcontrolPoints = false, dL_dxfixed = false, dL_dmu = false, dL_dx0 = false, dL_dwindFactor = false;
+  double forwardAccuracyLevel = 1e-7, backwardAccuracyLevel = 5e-4;
+  std::vector<int> mu_primitives;
+  int randSeed = 0, srandSeed = 0;
+};
+
+struct LossInfo {                 // Simulation.h:252-261 (fields bound in python_interface.cpp:262-266)
+  Vec3d targetLoc = {0, 0, 0}, targetTranslation = {0, 0, 0};
+  std::vector<std::pair<int, VecXd>> targetFrameShape;
+};
+
+class Simulation {
+ public:
+  // process-global thresholds, as in the reference (Simulation.h:333-334, Simulation.cpp:17-19)
+  static double forwardConvergenceThreshold, backwardConvergenceThreshold;
+  static std::string assetRoot;   // directory holding "remeshed/..." meshes (DIFFCLOTH_ASSETS or the reference's src/assets/meshes)
+
+  SceneConfiguration sceneConfig;
+  std::vector<Primitive> primitives;
+  std::vector<ForwardInformation> forwardRecords;
+  std::vector<VecXd> perStepGradient;
+  LossInfo taskLossInfo;
+  bool gradientClipping = true;              // Simulation.h:330
+  double gradientClippingThreshold = 16.0;   // :331
+  bool useCustomRLFixedPoint = false;
+  bool backwardGradientForceDirectSolver = false;   // :324
+  bool printVerbose = false;
+  bool windEnabled = false, contactEnabled = true, selfcollisionEnabled = false, gravityEnabled = true;
+  Vec3d gravity = {0, -9.8, 0};              // :356
+  Vec3d wind = {0.01, 0, 1};                 // :357
+  double windNorm = 0.15, windFrequency = 14, windPhase = 0;
+  Vec3d restShapeMinDim = {0, 0, 0}, restShapeMaxDim = {0, 0, 0}, restShapeMidPoint = {0, 0, 0};
+  VecXd rlFixedPointPos;
+
+  ~Simulation();
+  static Simulation *createSystem(SceneConfiguration sceneConfig, Vec3d center, bool runBackward = true);
+  // same, from an in-memory mesh (already in the reference's raw file coordinates): used for the GPU-box tests
+  static Simulation *createSystemFromMesh(SceneConfiguration sceneConfig, const VecXd &verts, const std::vector<int> &tris,
+                                          bool runBackward = true);
+
+  void resetSystem();
+  void step();
+  void stepNN(int idx, const VecXd &x, const VecXd &v, const VecXd &fixedPointPos);
+  BackwardInformation stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,
+                                   const ForwardInformation &forwardInfo_new, bool isStart, const VecXd &dL_dxinit,
+                                   const VecXd &dL_dvinit);
+  BackwardInformation stepBackwardNN(BackwardTaskInformation &taskInfo, VecXd &dL_dxnew, VecXd &dL_dvnew,
+                                     const ForwardInformation &forwardInfo_new, bool isStart, const VecXd &dL_dxinit,
+                                     const VecXd &dL_dvinit);
+  ForwardInformation getStateInfo() const { return forwardRecords.back(); }
+  ForwardInformation getPastStateInfo(int stepIdx) const { return forwardRecords.at(stepIdx); }
+  std::pair<VecXd, VecXd> getCurrentPosVelocityVec() const { return {forwardRecords.back().x, forwardRecords.back().v}; }
+  void setAction(const VecXd &a) { rlFixedPointPos = a; }
+  int getActionDim() const { return 3 * (int) attachmentVertices.size(); }
+  int getNumParticles() const { return N; }
+  void setPrintVerbose(bool v) { printVerbose = v; }
+  void setWindAncCollision(bool wind_, bool collision, bool selfCollision, bool constantForceField);
+  void appendPerStepGradient(const VecXd &x) { perStepGradient.push_back(x); }
+  void exportCurrentMeshPos(int step, const std::string &fileName) const;
+  void exportCurrentSimulation(const std::string &fileName) const;
+  const VecXd &restPositions() const { return rest; }
+  const std::vector<int> &triangles() const { return tris; }
+  const std::vector<int> &attachments() const { return attachmentVertices; }
+  dc_ctx *context() const { return ctx; }
+
+ private:
+  Simulation() {}
+  void buildFromMesh(VecXd pts, const std::vector<int> &tris, bool isModel);
+  void initScene();
+  void configureDevice();
+  void pushParams();
+  VecXd fixedPointTargets(double t);
+  double windFactorAt(double t) const;
+
+  dc_ctx *ctx = nullptr;
+  int N = 0, tapeSlots = 0;
+  VecXd rest;
+  std::vector<int> tris;
+  std::vector<int> attachmentVertices;
+  VecXd fixedPointRest, fixedPointCur;
+  bool runBackward = true;
+  double paramsFwdTol = -1, paramsBwdTol = -1;
+  bool paramsClip = true, paramsDirect = false;
+  double paramsClipThr = 16.0;
+};
+
+// scene tables (optimization/OptimizationTaskConfigurations.cpp:10-349)
+SceneConfiguration sceneByName(const std::string &name);
+
+}  // namespace dchost

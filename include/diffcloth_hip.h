@@ -111,6 +111,13 @@ int dc_set_params(dc_ctx *ctx, const dc_params *p);
 int dc_set_primitives(dc_ctx *ctx, int count, const dc_primitive *prims);       /* Simulation::primitives */
 int dc_build(dc_ctx *ctx);      /* (re)assemble A, P = M + h^2 A^T A and upload; call after any of the setters */
 void dc_default_params(dc_params *p);
+/* The reference reads its process-global statics at every step (Simulation::forwardConvergenceThreshold,
+ * backwardConvergenceThreshold, gradientClipping[Threshold], backwardGradientForceDirectSolver, and the
+ * gravity/contact/self-collision switches of setWindAncCollision): these two calls change them between steps
+ * without rebuilding the system or invalidating the batch / tape.                                          */
+int dc_set_solver(dc_ctx *ctx, double forward_tol, double backward_tol, int gradient_clipping, double clip_threshold,
+                  int force_direct_adjoint);
+int dc_set_flags(dc_ctx *ctx, int gravity_enabled, int contact_enabled, int selfcollision_enabled);
 
 /* sizes: N, T, E (bending flaps), Af, nnz(P), constraint rows (6T + 3E + 3Af) */
 int dc_get_counts(const dc_ctx *ctx, int *out6);

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the READ-ONLY reference checkout (run in the build container only).
+
+The GPU box has no /root/reference, so everything the tests need from it is frozen here as small fixtures:
+  meshes.npz         raw OBJ vertices / triangles of the demo meshes (src/assets/meshes/remeshed/...)
+  tshirt_golden.npz  the reference's only golden data: output/tshirt-exampleopt/iter0 — first frames of the
+                     1426-vertex T-shirt rollout of L-BFGS evaluation 0, with the parameters of that run
+                     (iter0/param.txt) and the loss / iteration counts of forwardLog.txt
+"""
+import os
+import re
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_obj(path):
+    V, F = [], []
+    for line in open(path):
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            V.append([float(p[1]), float(p[2]), float(p[3])])
+        elif p[0] == "f":
+            idx = [int(t.split("/")[0]) - 1 for t in p[1:]]
+            for k in range(1, len(idx) - 1):
+                F.append([idx[0], idx[k], idx[k + 1]])
+    return np.asarray(V, dtype=np.float64), np.asarray(F, dtype=np.int32)
+
+
+def main():
+    meshes = {
+        "hat": "src/assets/meshes/remeshed/agenthat2-579-rotated.obj",
+        "tshirt": "src/assets/meshes/remeshed/T-shirt/tshirt1000-tri.obj",
+        "sock": "src/assets/meshes/remeshed/sock1055-2081.obj",
+        "dress": "src/assets/meshes/remeshed/dress-handsup-drape.obj",
+    }
+    out = {}
+    for name, rel in meshes.items():
+        V, F = load_obj(os.path.join(REF, rel))
+        out[name + "_v"] = V
+        out[name + "_f"] = F
+        print(name, V.shape, F.shape)
+    np.savez_compressed(os.path.join(OUT, "meshes.npz"), **out)
+
+    run = os.path.join(REF, "output/tshirt-exampleopt")
+    frames = []
+    for k in range(0, 41):
+        V, _ = load_obj(os.path.join(run, "iter0", f"{k}.obj"))
+        frames.append(V)
+    last, _ = load_obj(os.path.join(run, "iter0", "250.obj"))
+    param = open(os.path.join(run, "iter0", "param.txt")).read()
+    k_stretch = float(re.search(r"k_CONSTRAINT_TRIANGLE:([-\d.eE]+)", param).group(1))
+    wind = [float(v) for v in re.search(r"f_wind:\(([^)]*)\)", param).group(1).split(",")]
+    clips = [[float(v) for v in m.split(",")] for m in re.findall(r"CLIP_\d:([-\d.,eE]+)", param)]
+    flog = open(os.path.join(run, "forwardLog.txt")).read()
+    losses = [float(v) for v in re.findall(r"Loss:([-\d.eE]+)", flog)]
+    pditers = [int(v) for v in re.findall(r"Total PD Iters:(\d+)", flog)]
+    np.savez_compressed(os.path.join(OUT, "tshirt_golden.npz"), frames=np.asarray(frames, dtype=np.float64),
+                        frame250=last, k_stretch=k_stretch, f_wind=np.asarray(wind), clips=np.asarray(clips),
+                        losses=np.asarray(losses), pd_iters=np.asarray(pditers))
+    print("golden frames", np.asarray(frames).shape, "k", k_stretch, "wind", wind, "clips", clips, "loss0", losses[0], "pd0", pditers[0])
+
+
+if __name__ == "__main__":
+    main()

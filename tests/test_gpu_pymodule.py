@@ -1,0 +1,84 @@
+"""GPU: the reference-shaped Python surface (diffcloth_py.Simulation.stepNN / stepBackwardNN, as driven by
+src/python_code/pySim/functional.py) on the hat scene, teacher-forced against the fp64 oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+import scenes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "diffcloth_amd", "lib"))
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def hat():
+    import diffcloth_py as d
+    V, F = scenes.load_mesh("hat")
+    sim = d.makeSimFromMesh("wear_hat", V.reshape(-1), F.reshape(-1).tolist())
+    cfg = scenes.HAT
+    P, rmin, rmax = scenes.normalise_model(V, cfg["orientation"], cfg["cloth_dim"])
+    o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"],
+                   fwd_tol=1e-8, bwd_tol=1e-9, attachments=cfg["attachments"], selfcollision=False, gradient_clipping=False)
+    o.add_sphere(scenes.hat_head_center(rmin, rmax, cfg["sphere_radius"]), cfg["sphere_radius"], cfg["sphere_mu"])
+    o.build()
+    return d, sim, o, P, F, cfg
+
+
+def test_scene_construction_matches_reference_formulas(hat):
+    d, sim, o, P, F, cfg = hat
+    assert sim.num_particles == 579 and sim.ndof_u == 6
+    np.testing.assert_allclose(sim.getRestPositions().reshape(-1, 3), P, atol=1e-12)
+    assert sim.getAttachmentVertices() == cfg["attachments"]
+    rmin, rmax = P.min(axis=0), P.max(axis=0)
+    np.testing.assert_allclose(sim.primitives[0].center, scenes.hat_head_center(rmin, rmax, 2.1), atol=1e-12)
+    np.testing.assert_allclose(sim.primitives[0].getPointVec(), sim.primitives[0].center)
+    assert sim.sceneConfig.stepNum == 400 and abs(sim.sceneConfig.timeStep - 0.01) < 1e-15
+
+
+def test_stepNN_and_stepBackwardNN_like_functional_py(hat):
+    d, sim, o, P, F, cfg = hat
+    helper = d.makeOptimizeHelperWithSim("wear_hat", sim)      # resets forwardConvergenceThreshold to 1e-5, like the reference
+    assert helper.taskInfo.dL_dcontrolPoints and d.Simulation.forwardConvergenceThreshold == 1e-5
+    # hatController.py:83 trains at 1e-8. This stiff scene (k_stretch 1200, k_bend 120, k_att 1e4) converges at a PD
+    # rate of ~0.995 per iteration, so both sides stop several hundred iterations in, on the same iterate sequence.
+    d.Simulation.forwardConvergenceThreshold = 1e-8
+    d.Simulation.backwardConvergenceThreshold = 1e-9
+    sim.gradientClipping = False
+    sim.backwardGradientForceDirectSolver = True     # solveDirect semantics, as the oracle's direct=True
+    sim.resetSystem()
+    rec = sim.getStateInfo()
+    x, v = f32(rec.x), f32(rec.v)
+    a = f32(rec.x_fixedpoints)
+    assert a.shape == (6,)
+    S = 4
+    for s in range(S):
+        a = f32(a + np.array([0.02, -0.05, 0.01, 0.02, -0.05, 0.01]))       # move the two clips towards the head
+        sim.stepNN(s + 1, x, v, a)
+        new = sim.getStateInfo()
+        ref = o.step(x, v, a)
+        assert new.stepIdx == s + 1
+        assert np.abs(new.x - ref["x"]).max() < 6e-5                        # 1e-5 * cloth size
+        x, v = f32(new.x), f32(new.v)
+    rng = np.random.default_rng(1)
+    gx = f32(rng.standard_normal(x.size) * 1e-2); gv = f32(rng.standard_normal(x.size) * 1e-4)
+    z = np.zeros_like(gx)
+    back = sim.stepBackwardNN(helper.taskInfo, gx, gv, new, new.stepIdx == 1, z, z)
+    rb = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    for name in ("dL_dx", "dL_dv", "dL_dxfixed"):
+        got, want = getattr(back, name), rb[name]
+        # the two forward runs may stop one or two PD iterations apart (|dx| ~ 1e-5), hence 1e-3 here; the 1e-4 bound at
+        # identical linearisation points is enforced in test_gpu_parity.py
+        assert np.linalg.norm(got - want) <= 1e-3 * np.linalg.norm(want), name
+    assert len(sim.perStepGradient) == 1
+    # the "isLast" convention of functional.py: zeros as incoming gradient, the loss gradient as dL_dxinit
+    back2 = sim.stepBackwardNN(helper.taskInfo, z, z, new, False, gx, gv)
+    np.testing.assert_allclose(back2.dL_dx, gx + gv / cfg["h"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(back2.dL_dv, gv, rtol=1e-6, atol=1e-12)
