@@ -31,7 +31,7 @@ class dc_params(C.Structure):
                 ("selfcollision_enabled", C.c_int), ("gradient_clipping", C.c_int),
                 ("gradient_clipping_threshold", C.c_double), ("pd_iter_cap", C.c_int), ("adjoint_iter_cap", C.c_int),
                 ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int),
-                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double)]
+                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double), ("max_self_contacts", C.c_int)]
 
 
 class dc_step_stats(C.Structure):
@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "dc_create", "dc_destroy", "dc_last_error", "dc_version", "dc_set_mesh", "dc_set_attachments", "dc_set_params",
     "dc_set_primitives", "dc_build", "dc_default_params", "dc_set_solver", "dc_set_flags", "dc_get_counts", "dc_get_system_matrix",
     "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force",
-    "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_step_backward", "dc_rollout_forward",
+    "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times",
 ]
@@ -226,6 +226,14 @@ class Engine:
         g = np.zeros((self.B, self.N), dtype=np.int32); n = np.zeros((self.B, 3 * self.N))
         self._chk(self.lib.dc_get_contacts(self.h, C.c_int(slot), _i(g), _d(n)))
         return g, n
+
+    def get_self_contacts(self, slot, rollout=0, cap=8192):
+        cnt = C.c_int(); nl = C.c_int()
+        pairs = np.zeros((cap, 2), dtype=np.int32); layer = np.zeros(cap, dtype=np.int32); nrm = np.zeros((cap, 3))
+        self._chk(self.lib.dc_get_self_contacts(self.h, C.c_int(slot), C.c_int(rollout), C.c_int(cap), C.byref(cnt), C.byref(nl),
+                                                _i(pairs), _i(layer), _d(nrm)))
+        n = min(cnt.value, cap)
+        return dict(count=cnt.value, layers=nl.value, pairs=pairs[:n], layer=layer[:n], normal=nrm[:n])
 
     def step_backward(self, slot, dL_dxnew, dL_dvnew, dL_dxinit=None, dL_dvinit=None, is_start=False):
         n3 = 3 * self.N

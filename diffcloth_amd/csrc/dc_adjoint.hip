@@ -39,6 +39,8 @@ struct AdjCtx {
   const float *xnew, *rec_f, *rec_n, *mu;
   const int *rec_prim;
   float *y, *corner;
+  SelfRec self;
+  int nself, b;
 };
 
 // w = dr_df^T z for the (block-diagonal) primitive contacts: Simulation::calculatedr_df (Simulation.cpp:700-711)
@@ -49,6 +51,33 @@ __device__ __forceinline__ f3 contact_JT(const DevSystem &S, const AdjCtx &C, in
   f3 n = ld3(C.rec_n, i, N);
   f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];
   return dri_dfi_T(n, d, C.mu[S.prims[prim].group], z);
+}
+
+// y = (I + dr_df)^T z with (I + dr_df) = (I + J_L) ... (I + J_0)(I + J_prim) (calculatedr_df, Simulation.cpp:686-768):
+// self layers L..0 first (Gauss-Seidel order reversed), the block-diagonal primitive part last. Ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ void contact_transpose(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond, float *y) {
+  const int N = S.N, tid = threadIdx.x;
+  if (C.nself > 0) {
+    for (int i = tid; i < N; i += THREADS) {
+      f3 z = ld3(zin, i, N);
+      if (precond) z = z * S.dinv[i];
+      st3(y, i, N, z);
+    }
+    __syncthreads();
+    self_JT_layers<THREADS>(S, C.self, C.b, y);
+    for (int i = tid; i < N; i += THREADS) {
+      f3 z = ld3(y, i, N);
+      st3(y, i, N, z + contact_JT(S, C, i, z));
+    }
+  } else {
+    for (int i = tid; i < N; i += THREADS) {
+      f3 z = ld3(zin, i, N);
+      if (precond) z = z * S.dinv[i];
+      st3(y, i, N, z + contact_JT(S, C, i, z));
+    }
+  }
+  __syncthreads();
 }
 
 // out = K z with z = zin (optionally scaled by D^-1: right preconditioning). Also returns the partial sums
@@ -64,12 +93,7 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   float *__restrict__ corner = C.corner;
   const float *__restrict__ xnew = C.xnew;
   // ---- y = (I + dr_df)^T z ----
-  for (int i = tid; i < N; i += THREADS) {
-    f3 z = ld3(zin, i, N);
-    if (precond) z = z * S.dinv[i];
-    st3(y, i, N, z + contact_JT(S, C, i, z));
-  }
-  __syncthreads();
+  contact_transpose<THREADS>(S, C, zin, precond, y);
   // ---- per element: h^2 (A - dp/dx)^T A y ----
   // triangles: Triangle::projectToManifoldBackward (Triangle.cpp:354-451) in closed form:
   //   dT(Y) = TJ <TJ,Y> / tr(S) + (I - T T^T) Y S^-1,   TJ = [t1, -t0]
@@ -144,6 +168,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   C.rec_prim = A.rec_prim + (size_t) b * N;
   C.mu = A.mu + (size_t) b * S.ngroups;
   C.y = W.vbest + off; C.corner = W.corner + (size_t) b * 3 * S.NC;
+  C.self = A.self; C.b = b;
+  C.nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;
   float *gx = A.gx + off, *gv = A.gv + off;
   float *gin = W.g + off, *u = W.vnow + off;
   float *cg_r = W.cg_r + off, *cg_p = W.cg_p + off, *cg_ap = W.cg_ap + off, *cg_x = W.cg_x + off;
@@ -277,16 +303,16 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
 #pragma unroll
   for (int k = 0; k < kMaxPrims; k++) dmu_part[k] = 0.f;
   float *dxf = A.d_xfixed ? A.d_xfixed + (size_t) b * 3 * S.Af : nullptr;
+  contact_transpose<THREADS>(S, C, u, false, C.y);       // y = (I + dr_df)^T u*
   for (int i = tid; i < N; i += THREADS) {
     f3 ui = ld3(u, i, N);
     const float m = S.mass[i];
-    f3 w = mk(0, 0, 0);
+    f3 w = ld3(C.y, i, N) - ui;
     const int prim = C.rec_prim[i];
     if (prim >= 0) {
       f3 n = ld3(C.rec_n, i, N);
       f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * m;
       const int grp = S.prims[prim].group;
-      w = dri_dfi_T(n, d, C.mu[grp], ui);
       const float contrib = dot(dri_dmu(n, d, C.mu[grp]), ui) * h;
 #pragma unroll
       for (int k = 0; k < kMaxPrims; k++) dmu_part[k] += (k == grp) ? contrib : 0.f;

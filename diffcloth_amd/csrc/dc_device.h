@@ -7,6 +7,8 @@
 namespace dc {
 
 constexpr int kMaxPrims = 8;
+constexpr int kMaxLayers = 1020;   // self-contact layers per step (contactSorting: a chain of L contacts takes L layers)
+constexpr int kMetaStride = 1024;  // ints per (slot, rollout): count, nlayers, layer offsets[nlayers + 1]
 
 struct DevPrim {
   int kind, group, rotates, pad;
@@ -38,6 +40,12 @@ struct DevSystem {
   const int2 *ell;
   const int *ell_ptr;           // [ceil(N/64)]
   const int *ell_w;             // [ceil(N/64)] width of the chunk
+  // self-collision (Simulation.cpp:194-220, 225-373): collision radii, connected-pair table (share a triangle)
+  const float *radii;           // [N]
+  const int *conn_ptr;          // [N+1]
+  const int *conn_idx;          // sorted neighbours incl. self
+  float max_radii;
+  int self_cap;                 // capacity of the per-rollout self-contact list
   float h, k_att, gx, gy, gz;
   int contact_enabled, self_enabled, pad1;
   DevPrim prims[kMaxPrims];
@@ -54,6 +62,22 @@ struct DevWork {
   float *cg_r, *cg_p, *cg_ap, *cg_x;   // [B][3][N] each
   float *corner;   // [B][3][NC] per-constraint-corner contributions
   float4 *ap4;     // [B][N] per-vertex float4 scratch of the resident PCG (A p, one 16-byte access per vertex)
+  // self-collision detection / layering scratch (k_self_detect)
+  int *sd_cell, *sd_order;      // [B][N]
+  float *sd_sx;                 // [B][3][N] positions in cell-sorted order
+  int2 *sd_rawpair;             // [B][cap]
+  float4 *sd_rawn;              // [B][cap]
+  int *sd_tmp;                  // [B][16 * cap] serial layering structures
+};
+
+// Self contacts of one record, per rollout b: pair[b*cap + k] = (particleId1 < particleId2), nrm = contact normal,
+// dvec = d of the last friction evaluation (SelfCollisionInformation::d), meta[b*64 + ...] = {count, nlayers,
+// layer_offset[0..nlayers]} with the contacts stored layer by layer.
+struct SelfRec {
+  int2 *pair;
+  float4 *nrm;
+  float4 *dvec;
+  int *meta;
 };
 
 struct FwdArgs {
@@ -65,6 +89,7 @@ struct FwdArgs {
   const float *mu;              // [B][ngroups]
   const float *fu;              // [B][3] uniform extra force or nullptr
   dc_step_stats *stats;         // [B]
+  SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
 };
@@ -73,6 +98,7 @@ struct BwdArgs {
   const float *x_new;           // slot k [B][3][N]
   const float *rec_f, *rec_n;   // record k
   const int *rec_prim;
+  SelfRec self;                 // record k
   const float *mu;
   float *gx, *gv;               // carried gradient, in: dL_dxnew/dL_dvnew, out: dL_dx/dL_dv   [B][3][N]
   const float *ix, *iv;         // dL_dxinit / dL_dvinit or nullptr
@@ -87,6 +113,7 @@ struct BwdArgs {
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 // LDS/register-resident variant (dc_forward_res.hip); returns false when N is too large for it.
 bool launch_pd_step_resident(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st, int variant);
+void launch_self_detect(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);
 void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, hipStream_t st);
 void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, hipStream_t st);

@@ -200,4 +200,65 @@ __device__ __forceinline__ int block_pcg(const DevSystem &S, float *cg_r, float 
   return it;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Self contacts: the layers of Simulation::contactSorting applied in sequence (Gauss-Seidel over layers, contacts
+// of one layer are vertex-disjoint and run in parallel).
+// ---------------------------------------------------------------------------------------------------
+constexpr float kClothMu = 0.1f;    // clothFrictionalCoeff, hard-coded in the reference (Simulation.cpp:666, :729)
+
+// calculateDryFrictionVector, self part (Simulation.cpp:655-678): r += k * friction(d), d = (f+r)_A/m_A - (f+r)_B/m_B.
+// f, r are the rollout's planar [3][N] arrays in global memory; stores d per contact. Call with all threads; the
+// caller must have synchronised after writing f / r, this function ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ void self_friction_layers(const DevSystem &S, const SelfRec &R, int b, const float *f, float *r) {
+  const int cap = S.self_cap, N = S.N;
+  const int *meta = R.meta + (size_t) b * kMetaStride;
+  const int nl = meta[1];
+  const int2 *pair = R.pair + (size_t) b * cap;
+  const float4 *nrm = R.nrm + (size_t) b * cap;
+  float4 *dvec = R.dvec + (size_t) b * cap;
+  for (int l = 0; l < nl; l++) {
+    const int k1 = meta[2 + l + 1];
+    for (int k = meta[2 + l] + threadIdx.x; k < k1; k += THREADS) {
+      const int2 ab = pair[k];
+      const float4 n4 = nrm[k];
+      const f3 n = mk(n4.x, n4.y, n4.z);
+      const float mA = S.mass[ab.x], mB = S.mass[ab.y];
+      f3 rA = ld3(r, ab.x, N), rB = ld3(r, ab.y, N);
+      f3 d = (ld3(f, ab.x, N) + rA) * (1.0f / mA) - (ld3(f, ab.y, N) + rB) * (1.0f / mB);
+      dvec[k] = make_float4(d.x, d.y, d.z, 0.f);
+      f3 ri = dry_friction(n, d, kClothMu) * ((mA * mB) / (mA + mB));
+      st3(r, ab.x, N, rA + ri);
+      st3(r, ab.y, N, rB - ri);
+    }
+    __syncthreads();
+  }
+}
+
+// z <- (I + J_0)^T ... (I + J_L)^T z for the self layers (calculatedr_df, Simulation.cpp:713-760, transposed):
+// per contact (A,B): g = k D^T (z_A - z_B), z_A += g / m_A, z_B -= g / m_B, D = dri_dfi(n, d, 0.1).
+// z is the rollout's planar [3][N] array in global memory. Ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec &R, int b, float *z) {
+  const int cap = S.self_cap, N = S.N;
+  const int *meta = R.meta + (size_t) b * kMetaStride;
+  const int nl = meta[1];
+  const int2 *pair = R.pair + (size_t) b * cap;
+  const float4 *nrm = R.nrm + (size_t) b * cap;
+  const float4 *dvec = R.dvec + (size_t) b * cap;
+  for (int l = nl - 1; l >= 0; l--) {
+    const int k1 = meta[2 + l + 1];
+    for (int k = meta[2 + l] + threadIdx.x; k < k1; k += THREADS) {
+      const int2 ab = pair[k];
+      const float4 n4 = nrm[k], d4 = dvec[k];
+      const float mA = S.mass[ab.x], mB = S.mass[ab.y];
+      f3 zA = ld3(z, ab.x, N), zB = ld3(z, ab.y, N);
+      f3 g = dri_dfi_T(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * ((mA * mB) / (mA + mB));
+      st3(z, ab.x, N, zA + g * (1.0f / mA));
+      st3(z, ab.y, N, zB - g * (1.0f / mB));
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace dc

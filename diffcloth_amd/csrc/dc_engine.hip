@@ -31,6 +31,10 @@ struct dc_ctx {
   std::vector<void *> batch_allocs;
   float *X = nullptr, *V = nullptr, *F = nullptr, *R = nullptr, *NRM = nullptr;   // [(tape+1)][B][3][N]
   int *PRIM = nullptr;                                                            // [(tape+1)][B][N]
+  int2 *SC_pair = nullptr;          // [(tape+1)][B][cap] self contacts per record
+  float4 *SC_nrm = nullptr, *SC_d = nullptr;
+  int *SC_meta = nullptr;           // [(tape+1)][B][kMetaStride]
+  int self_cap = 0;
   float *xf_cur = nullptr;          // [B][3][Af]
   float *mu = nullptr, *fu = nullptr;
   bool fu_set = false;
@@ -117,11 +121,15 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.rec_prim = c->PRIM + sp * (slot + 1);
   A.x_fixed = c->xf_cur; A.mu = c->mu; A.fu = c->fu_set ? c->fu : nullptr;
   A.stats = c->fstats + (size_t) c->B * (slot + 1);
+  {
+    const size_t sc = (size_t) c->B * c->self_cap * (slot + 1), sm = (size_t) c->B * kMetaStride * (slot + 1);
+    A.self.pair = c->SC_pair + sc; A.self.nrm = c->SC_nrm + sc; A.self.dvec = c->SC_d + sc; A.self.meta = c->SC_meta + sm;
+  }
   A.fwd_tol = (float) c->params.forward_tol;
   A.cg_tol = (float) (c->params.cg_rel_tol > 0 ? c->params.cg_rel_tol : 1e-4);
   A.pd_cap = pd_cap(c);
   A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
-  A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 40;
+  A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   return A;
 }
 BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
@@ -129,6 +137,10 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   BwdArgs A;
   A.x_new = c->X + se * slot; A.rec_f = c->F + se * slot; A.rec_n = c->NRM + se * slot;
   A.rec_prim = c->PRIM + sp * slot; A.mu = c->mu;
+  {
+    const size_t sc = (size_t) c->B * c->self_cap * slot, sm = (size_t) c->B * kMetaStride * slot;
+    A.self.pair = c->SC_pair + sc; A.self.nrm = c->SC_nrm + sc; A.self.dvec = c->SC_d + sc; A.self.meta = c->SC_meta + sm;
+  }
   A.gx = c->GX; A.gv = c->GV;
   A.ix = with_init ? c->IX : nullptr; A.iv = with_init ? c->IV : nullptr;
   A.d_xfixed = c->DXF; A.d_mu = c->DMU; A.stats = c->bstats + (size_t) c->B * slot;
@@ -140,7 +152,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.is_start = is_start; A.clip = c->params.gradient_clipping;
   A.mode = c->params.adjoint_mode;
   A.rel_tol = (float) (c->params.adjoint_rel_tol > 0 ? c->params.adjoint_rel_tol : 1e-6);
-  A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 40;
+  A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   return A;
 }
 
@@ -157,8 +169,9 @@ void dc_default_params(dc_params *p) {
   p->forward_tol = 1e-7; p->backward_tol = 5e-5;                                                        // Simulation.cpp:17-19
   p->gravity_enabled = 1; p->contact_enabled = 1; p->selfcollision_enabled = 0;
   p->gradient_clipping = 1; p->gradient_clipping_threshold = 16.0;                                      // Simulation.h:330-331
-  p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 40;
+  p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 0;
   p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6;
+  p->max_self_contacts = 2048;
 }
 
 int dc_create(int device_id, dc_ctx **out) {
@@ -291,6 +304,15 @@ int dc_build(dc_ctx *c) {
   if ((rc = upload<float>(c, &S.P_val, H.P_val))) return rc;
   if ((rc = upload<int>(c, &S.inc_ptr, H.inc_ptr))) return rc;
   if ((rc = upload<int>(c, &S.inc_idx, H.inc_idx))) return rc;
+  if ((rc = upload<float>(c, &S.radii, H.radii))) return rc;
+  if ((rc = upload<int>(c, &S.conn_ptr, H.conn_ptr))) return rc;
+  if ((rc = upload<int>(c, &S.conn_idx, H.conn_idx))) return rc;
+  {
+    double mr = H.radii.empty() ? 0.0 : H.radii[0];
+    for (double r : H.radii) mr = std::max(mr, r);
+    S.max_radii = (float) mr;
+    S.self_cap = p.max_self_contacts > 0 ? p.max_self_contacts : 2048;
+  }
   {  // wave-sliced ELL copy of P for the LDS-resident PCG
     const int nchunks = (N + 63) / 64;
     std::vector<int> eptr(nchunks), ew(nchunks);
@@ -420,6 +442,20 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->W.cg_x, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.corner, (size_t) B * 3 * NC))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.ap4, (size_t) B * N))) return rc;
+  {
+    const int cap = c->S.self_cap;
+    c->self_cap = cap;
+    if ((rc = dev_alloc(c, pool, &c->SC_pair, (size_t) B * cap * slots))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->SC_nrm, (size_t) B * cap * slots))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->SC_d, (size_t) B * cap * slots))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->SC_meta, (size_t) B * kMetaStride * slots))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_cell, (size_t) B * N))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_order, (size_t) B * N))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_sx, se))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_rawpair, (size_t) B * cap))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_rawn, (size_t) B * cap))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_tmp, (size_t) B * 24 * cap))) return rc;
+  }
   if ((rc = dev_alloc(c, pool, &c->xf_cur, (size_t) B * 3 * Af))) return rc;
   if ((rc = dev_alloc(c, pool, &c->mu, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fu, (size_t) B * 3))) return rc;
@@ -504,6 +540,7 @@ int dc_step_forward(dc_ctx *c, int slot, const double *fixed_pts, dc_step_stats 
   if (fixed_pts && Af > 0) {
     if ((rc = h2d_planar(c, fixed_pts, c->xf_cur, Af, 2))) return rc;
   }
+  if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
   launch_pd_step(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
   HIPCHK(c, hipGetLastError());
   if (stats) {
@@ -536,6 +573,31 @@ int dc_get_contacts(dc_ctx *c, int slot, int *prim_group, double *normal) {
   if (prim_group) {
     HIPCHK(c, hipMemcpy(prim_group, c->PRIM + sp * slot, sp * sizeof(int), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < sp; k++) if (prim_group[k] >= 0) prim_group[k] = c->prims[prim_group[k]].group;
+  }
+  return DC_OK;
+}
+
+int dc_get_self_contacts(dc_ctx *c, int slot, int rollout, int cap, int *count, int *num_layers, int *pairs, int *layer, double *normal) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1 || rollout < 0 || rollout >= c->B) return fail(c, DC_ERR_INVALID, "dc_get_self_contacts: bad slot / rollout");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int> meta_v(kMetaStride); int *meta = meta_v.data();
+  HIPCHK(c, hipMemcpy(meta, c->SC_meta + ((size_t) c->B * slot + rollout) * kMetaStride, sizeof(int) * kMetaStride, hipMemcpyDeviceToHost));
+  const int C = meta[0], nl = meta[1];
+  if (count) *count = C;
+  if (num_layers) *num_layers = nl;
+  const int n = std::min(C, cap);
+  if (n <= 0) return DC_OK;
+  const size_t base = ((size_t) c->B * slot + rollout) * c->self_cap;
+  std::vector<int2> pr(n);
+  std::vector<float4> nr(n);
+  HIPCHK(c, hipMemcpy(pr.data(), c->SC_pair + base, sizeof(int2) * n, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(nr.data(), c->SC_nrm + base, sizeof(float4) * n, hipMemcpyDeviceToHost));
+  for (int k = 0; k < n; k++) {
+    if (pairs) { pairs[2 * k] = pr[k].x; pairs[2 * k + 1] = pr[k].y; }
+    if (normal) { normal[3 * k] = nr[k].x; normal[3 * k + 1] = nr[k].y; normal[3 * k + 2] = nr[k].z; }
+    if (layer) { int l = 0; while (l + 1 < nl && k >= meta[2 + l + 1]) l++; layer[k] = l; }
   }
   return DC_OK;
 }
@@ -576,7 +638,10 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-  for (int k = 0; k < nsteps; k++) launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+  for (int k = 0; k < nsteps; k++) {
+    if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+    launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+  }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
   HIPCHK(c, hipGetLastError());
   // kernel-time accounting is resolved lazily in dc_kernel_times / dc_sync

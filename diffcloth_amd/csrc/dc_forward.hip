@@ -58,6 +58,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
   }
   double min_xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
   const int total_contacts = (int) block_sum<THREADS>((double) ncontact, red);
+  const int nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;   // from k_self_detect
   bool improved = false, converged = false, stalled = false;
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
@@ -127,6 +128,18 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
       st3(cg_x, i, N, mk(0, 0, 0));
       part += dot(rhs, rhs) * di;
     }
+    if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
+      __syncthreads();
+      self_friction_layers<THREADS>(S, A.self, b, rec_f, rec_r);
+      part = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        f3 rhs = ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i];
+        const float di = S.dinv[i];
+        st3(cg_r, i, N, rhs);
+        st3(cg_p, i, N, rhs * di);
+        part += dot(rhs, rhs) * di;
+      }
+    }
     const double rz = block_sum<THREADS>((double) part, red);
     // ---- global step: P dv = rhs (Simulation.cpp:1267) ----
     cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red);
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
   if (tid == 0) {
     dc_step_stats s;
     s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
-    s.self_contacts = 0; s.last_xdiff = (float) xdiff;
+    s.self_contacts = nself; s.last_xdiff = (float) xdiff;
     A.stats[b] = s;
   }
 }

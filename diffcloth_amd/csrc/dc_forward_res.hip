@@ -67,6 +67,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
   }
   double min_xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
   const int total_contacts = (int) block_sum<THREADS>((double) ncontact, red);
+  const int nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;   // from k_self_detect
   bool improved = false, converged = false, stalled = false;
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
@@ -132,6 +133,18 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
         ap4[i] = make_float4(rhs.x, rhs.y, rhs.z, 0.f);
       }
       lp[i] = rhs.x * di; lp[NP + i] = rhs.y * di; lp[2 * NP + i] = rhs.z * di;
+    }
+    if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
+      __syncthreads();
+      self_friction_layers<THREADS>(S, A.self, b, rec_f, rec_r);
+      part = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        f3 rhs = ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i];
+        const float di = S.dinv[i];
+        ap4[i] = make_float4(rhs.x, rhs.y, rhs.z, 0.f);
+        lp[i] = rhs.x * di; lp[NP + i] = rhs.y * di; lp[2 * NP + i] = rhs.z * di;
+        part += dot(rhs, rhs) * di;
+      }
     }
     double rz = block_sum<THREADS>((double) part, red);
     // residual and iterate of the PCG live in registers from here to the update (A p goes through a coalesced
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
   if (tid == 0) {
     dc_step_stats s;
     s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
-    s.self_contacts = 0; s.last_xdiff = (float) xdiff;
+    s.self_contacts = nself; s.last_xdiff = (float) xdiff;
     A.stats[b] = s;
   }
   PH_PRINT

@@ -116,8 +116,9 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readonly("convergeIter", &ForwardInformation::convergeIter)
       .def_property_readonly("collisionInfos", [](const ForwardInformation &r) {
         // completeCollisionInfo = ((primitive contacts, self contacts), layers)
-        return py::make_tuple(py::make_tuple(r.primitiveCollisions, std::vector<SelfCollisionInformation>()),
-                              std::vector<std::vector<SelfCollisionInformation>>());
+        std::vector<SelfCollisionInformation> flat;
+        for (auto &l : r.selfCollisionLayers) flat.insert(flat.end(), l.begin(), l.end());
+        return py::make_tuple(py::make_tuple(r.primitiveCollisions, flat), r.selfCollisionLayers);
       });
 
   py::class_<BackwardInformation>(m, "BackwardInformation")

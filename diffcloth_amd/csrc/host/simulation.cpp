@@ -361,6 +361,16 @@ void Simulation::step() {
   check(ctx, dc_get_contacts(ctx, rec.deviceSlot, grp.data(), nrm.data()), "dc_get_contacts");
   for (int i = 0; i < N; i++)
     if (grp[i] >= 0) rec.primitiveCollisions.push_back({grp[i], i, {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}});
+  if (st.self_contacts > 0) {   // layered self contacts of this step (collisionInfos.second)
+    const int cap = st.self_contacts;
+    std::vector<int> pairs(2 * (size_t) cap), layer(cap);
+    VecXd sn(3 * (size_t) cap);
+    int cnt = 0, nl = 0;
+    check(ctx, dc_get_self_contacts(ctx, rec.deviceSlot, 0, cap, &cnt, &nl, pairs.data(), layer.data(), sn.data()), "dc_get_self_contacts");
+    rec.selfCollisionLayers.assign(std::max(nl, 1), {});
+    for (int k = 0; k < std::min(cnt, cap); k++)
+      rec.selfCollisionLayers[layer[k]].push_back({pairs[2 * k], pairs[2 * k + 1], layer[k], {sn[3 * k], sn[3 * k + 1], sn[3 * k + 2]}});
+  }
   rec.converged = st.converged != 0;
   rec.convergeIter = st.pd_iters;
   rec.totalConverged = prev.totalConverged + (rec.converged ? 1 : 0);

@@ -68,11 +68,12 @@ struct Primitive {                // the fields of Primitive.h the Python side r
 };
 
 struct PrimitiveCollisionInformation { int primitiveId = -1, particleId = -1; Vec3d normal = {0, 0, 0}; };   // Simulation.h:39-51
-struct SelfCollisionInformation { int particleId1 = -1, particleId2 = -1; };
+struct SelfCollisionInformation { int particleId1 = -1, particleId2 = -1, layerId = 0; Vec3d normal = {0, 0, 0}; };   // Simulation.h:53-63
 
 struct ForwardInformation {       // Simulation.h:68-100 (hot-path fields)
   VecXd x, v, x_prev, v_prev, f, r, s_n, x_fixedpoints;
   std::vector<PrimitiveCollisionInformation> primitiveCollisions;
+  std::vector<std::vector<SelfCollisionInformation>> selfCollisionLayers;   // collisionInfos.second (contactSorting output)
   int sysMatId = 0;
   double t = 0, windFactor = 0, avgDeformation = 0, maxDeformation = 0;
   bool converged = false;
@@ -124,7 +125,7 @@ class Simulation {
   bool useCustomRLFixedPoint = false;
   bool backwardGradientForceDirectSolver = false;   // :324
   bool printVerbose = false;
-  bool windEnabled = false, contactEnabled = true, selfcollisionEnabled = false, gravityEnabled = true;
+  bool windEnabled = false, contactEnabled = true, selfcollisionEnabled = true, gravityEnabled = true;   // Simulation.cpp:9-16
   Vec3d gravity = {0, -9.8, 0};              // :356
   Vec3d wind = {0.01, 0, 1};                 // :357
   double windNorm = 0.15, windFrequency = 14, windPhase = 0;

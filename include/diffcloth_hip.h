@@ -60,9 +60,12 @@ typedef struct dc_params {
   /* inner block-Jacobi PCG (replaces SimplicialLLT::solve, Simulation.cpp:1267 / :1577) */
   double cg_rel_tol;                /* stop when |r|_{D^-1} <= cg_rel_tol * |r0|_{D^-1}; <=0: 1e-4 */
   int cg_max_iter;                  /* <=0: 500                                                   */
-  /* fp32 floor guard: leave the PD / adjoint loop when the update norm has not improved by 1 % for this many
-   * consecutive iterations (the reference's 1e-9..1e-10 thresholds are below fp32 resolution); the best
-   * iterate is returned and dc_step_stats::converged reads 2.  <=0: 40                                    */
+  /* optional fp32-floor guard, OFF by default (<= 0): leave the PD / adjoint loop when the update norm has set no new
+   * minimum for this many consecutive iterations, return the best iterate and report converged = 2. The scene tables
+   * ask for 1e-9..1e-10, below fp32 resolution for stiff scenes, where the loop otherwise runs to the cap and
+   * reverts to the best iterate exactly as the reference does (Simulation.cpp:1357-1367). It is off by default
+   * because |x_new - x_now| is NOT monotone under contact mode switching: plateaus of > 100 iterations occur in the
+   * reference's own T-shirt run and a short window would stop early there (tests/test_gpu_parity.py, golden rollout). */
   int stall_window;
   /* adjoint solver: 0 = the reference's fixed-point iteration u <- P^-1 (g + dP^T u) (Simulation.cpp:1561-1600)
    * with a direct solve when the cap is hit (:1589-1594); 1 = always the direct solve, i.e. the semantics of
@@ -70,6 +73,7 @@ typedef struct dc_params {
    * block-Jacobi preconditioned BiCGSTAB on (P - dP^T) run to adjoint_rel_tol (relative residual; <=0: 1e-6). */
   int adjoint_mode;
   double adjoint_rel_tol;
+  int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: 2048 */
 } dc_params;
 
 /* Per-rollout statistics of one forward step (ForwardInformation::converged/convergeIter). */
@@ -146,6 +150,12 @@ int dc_step_forward(dc_ctx *ctx, int slot, const double *fixed_pts, dc_step_stat
 int dc_get_record(dc_ctx *ctx, int slot, double *f, double *r);
 /* per-vertex primitive contact of that step: group id or -1 (B*N) and contact normal (B*3N) */
 int dc_get_contacts(dc_ctx *ctx, int slot, int *prim_group, double *normal);
+
+/* layered self contacts of that step for ONE rollout (ForwardInformation::collisionInfos.second, the output of
+ * contactSorting, Simulation.cpp:422-624): pairs (particleId1 < particleId2) in layer order, layer index and normal
+ * per contact; at most `cap` entries are written, *count receives the total.                                  */
+int dc_get_self_contacts(dc_ctx *ctx, int slot, int rollout, int cap, int *count, int *num_layers, int *pairs /*2*cap*/,
+                         int *layer /*cap*/, double *normal /*3*cap*/);
 
 /* Simulation::stepBackward()/stepBackwardNN() (Simulation.cpp:1443-1780) through the step that produced
  * `slot` (forwardInfo_new = record `slot`). Inputs B*3N each; dL_dxinit/dL_dvinit may be NULL (zeros).
