@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "dc_set_primitives", "dc_build", "dc_default_params", "dc_set_solver", "dc_set_flags", "dc_get_counts", "dc_get_system_matrix",
     "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force",
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
-    "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_stats", "dc_sync", "dc_timer_start",
+    "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times",
 ]
 
@@ -264,6 +264,11 @@ class Engine:
         dx = np.zeros((self.B, 3 * self.N)); dv = np.zeros((self.B, 3 * self.N)); dmu = np.zeros((self.B, self.ngroups))
         self._chk(self.lib.dc_get_gradient(self.h, _d(dx), _d(dv), _d(dmu)))
         return dx, dv, dmu
+
+    def get_param_gradients(self, slot):
+        out = np.zeros((self.B, 8))
+        self._chk(self.lib.dc_get_param_gradients(self.h, C.c_int(slot), _d(out)))
+        return dict(dL_dk=out[:, 0:3], dL_ddensity=out[:, 3], sum_dfext=out[:, 4:7])
 
     def get_stats(self, slot):
         f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()

@@ -304,10 +304,54 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   for (int k = 0; k < kMaxPrims; k++) dmu_part[k] = 0.f;
   float *dxf = A.d_xfixed ? A.d_xfixed + (size_t) b * 3 * S.Af : nullptr;
   contact_transpose<THREADS>(S, C, u, false, C.y);       // y = (I + dr_df)^T u*
+  // parameter gradients of this step (Simulation.cpp:1672-1764), all of the form  <y, d(rhs)/d(theta)>:
+  //   pacc[0..2]  sum over the elements of one type of  y . A^T (p(x_new) - A x_new)   -> dL/dk_type = h^2 / k * pacc
+  //   pacc[3]     density term (:1672-1679, adddr_dd = false)
+  //   pacc[4..6]  h^2 * sum_i y_i  (dL_dfext_vec summed, :1702-1764; the host applies the wind chain rule)
+  float pacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (A.d_param) {
+    const int T = S.T, E = S.E;
+    const float *xnew = C.xnew;
+    const float *yv = C.y;
+    for (int t = tid; t < T; t += THREADS) {
+      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+      const float4 D = S.tri_D[t];
+      f3 x0 = ld3(xnew, i0, N);
+      f3 e0 = ld3(xnew, i1, N) - x0, e1 = ld3(xnew, i2, N) - x0;
+      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
+      Polar P = polar3x2(f0, f1);
+      f3 g0 = (P.t0 - f0) * S.tri_w2[t], g1 = (P.t1 - f1) * S.tri_w2[t];
+      f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
+      f3 q0 = ld3(yv, i0, N);
+      pacc[0] += dot(c1, ld3(yv, i1, N) - q0) + dot(c2, ld3(yv, i2, N) - q0);
+    }
+    for (int e = tid; e < E; e += THREADS) {
+      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+      const float4 w = S.bend_w[e];
+      const float2 nw = S.bend_nw[e];
+      f3 x0 = ld3(xnew, i0, N);
+      f3 ev = (ld3(xnew, i1, N) - x0) * w.y + (ld3(xnew, i2, N) - x0) * w.z + (ld3(xnew, i3, N) - x0) * w.w;
+      f3 p = mk(0, 0, 0);
+      if (nw.x > 1e-6f) p = normalized(ev) * nw.x;
+      f3 q0 = ld3(yv, i0, N);
+      f3 ey = (ld3(yv, i1, N) - q0) * w.y + (ld3(yv, i2, N) - q0) * w.z + (ld3(yv, i3, N) - q0) * w.w;
+      pacc[1] += dot((p - ev) * nw.y, ey);
+    }
+  }
+  const f3 grav = mk(S.gx, S.gy, S.gz);
   for (int i = tid; i < N; i += THREADS) {
     f3 ui = ld3(u, i, N);
     const float m = S.mass[i];
     f3 w = ld3(C.y, i, N) - ui;
+    if (A.d_param) {
+      f3 yi = ui + w;
+      const int a = S.att_of_vertex[i];
+      if (a >= 0) pacc[2] += S.k_att * dot(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af) - ld3(C.xnew, i, N), yi);
+      const float ar = m / S.density;
+      f3 xp = ld3(A.x_prev + off, i, N), vp = ld3(A.v_prev + off, i, N);
+      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - ld3(C.xnew, i, N)) + h * dot(w, vp + grav * h));
+      pacc[4] += h2 * yi.x; pacc[5] += h2 * yi.y; pacc[6] += h2 * yi.z;
+    }
     const int prim = C.rec_prim[i];
     if (prim >= 0) {
       f3 n = ld3(C.rec_n, i, N);
@@ -331,6 +375,15 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     for (int k = 0; k < S.ngroups; k++) {
       const double s = block_sum<THREADS>((double) dmu_part[k], red);
       if (tid == 0) A.d_mu[(size_t) b * S.ngroups + k] += (float) s;
+    }
+  }
+  if (A.d_param) {
+    float *dp = A.d_param + (size_t) b * 8;
+    const float scale[7] = {S.k_stretch > 0.f ? h2 / S.k_stretch : 0.f, S.k_bend > 0.f ? h2 / S.k_bend : 0.f,
+                            S.k_att > 0.f ? h2 / S.k_att : 0.f, 1.f, 1.f, 1.f, 1.f};
+    for (int k = 0; k < 7; k++) {
+      const double s = block_sum<THREADS>((double) pacc[k], red);
+      if (tid == 0) dp[k] = (float) (s * scale[k]);
     }
   }
   if (tid == 0) {

@@ -47,6 +47,7 @@ struct DevSystem {
   float max_radii;
   int self_cap;                 // capacity of the per-rollout self-contact list
   float h, k_att, gx, gy, gz;
+  float k_stretch, k_bend, density;
   int contact_enabled, self_enabled, pad1;
   DevPrim prims[kMaxPrims];
   // device-resident copy of this struct: kernels receive THIS pointer and read fields with scalar loads on
@@ -104,6 +105,9 @@ struct BwdArgs {
   const float *ix, *iv;         // dL_dxinit / dL_dvinit or nullptr
   float *d_xfixed;              // [B][3][Af] out (overwritten) or nullptr
   float *d_mu;                  // [B][ngroups] accumulated (+=) or nullptr
+  float *d_param;               // [B][8] per-step parameter gradients (dk_stretch, dk_bend, dk_att, ddensity, h^2 sum y) or nullptr
+  const float *x_fixed;         // [B][3][Af] fixed-point targets used by the step that produced the record
+  const float *x_prev, *v_prev; // slot k-1 state [B][3][N]
   dc_bwd_stats *stats;          // [B]
   float bwd_tol, cg_tol, clip_thr, rel_tol;
   int mode;                     // 0: reference fixed-point iteration (+ direct fallback), 1: direct Krylov solve

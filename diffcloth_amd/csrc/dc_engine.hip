@@ -36,6 +36,8 @@ struct dc_ctx {
   int *SC_meta = nullptr;           // [(tape+1)][B][kMetaStride]
   int self_cap = 0;
   float *xf_cur = nullptr;          // [B][3][Af]
+  float *XF = nullptr;              // [(tape+1)][B][3][Af] fixed-point targets per record
+  float *DPAR = nullptr;            // [(tape+1)][B][8] per-step parameter gradients
   float *mu = nullptr, *fu = nullptr;
   bool fu_set = false;
   float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DXF = nullptr, *DMU = nullptr, *target = nullptr;
@@ -143,7 +145,10 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   }
   A.gx = c->GX; A.gv = c->GV;
   A.ix = with_init ? c->IX : nullptr; A.iv = with_init ? c->IV : nullptr;
-  A.d_xfixed = c->DXF; A.d_mu = c->DMU; A.stats = c->bstats + (size_t) c->B * slot;
+  A.d_xfixed = c->DXF; A.d_mu = c->DMU;
+  A.d_param = c->DPAR + (size_t) c->B * 8 * slot;
+  A.x_fixed = c->XF + (size_t) c->B * 3 * c->S.Af * slot;
+  A.x_prev = c->X + se * (slot - 1); A.v_prev = c->V + se * (slot - 1); A.stats = c->bstats + (size_t) c->B * slot;
   A.bwd_tol = (float) c->params.backward_tol;
   A.cg_tol = (float) (c->params.cg_rel_tol > 0 ? c->params.cg_rel_tol : 1e-4);
   A.clip_thr = (float) c->params.gradient_clipping_threshold;
@@ -341,6 +346,7 @@ int dc_build(dc_ctx *c) {
     if ((rc = upload<int>(c, &S.ell_w, ew))) return rc;
   }
   S.h = (float) p.time_step; S.k_att = (float) p.k_att;
+  S.k_stretch = (float) p.k_stretch; S.k_bend = (float) p.k_bend; S.density = (float) p.density;
   S.gx = p.gravity_enabled ? (float) p.gravity[0] : 0.f;
   S.gy = p.gravity_enabled ? (float) p.gravity[1] : 0.f;
   S.gz = p.gravity_enabled ? (float) p.gravity[2] : 0.f;
@@ -457,6 +463,8 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
     if ((rc = dev_alloc(c, pool, &c->W.sd_tmp, (size_t) B * 24 * cap))) return rc;
   }
   if ((rc = dev_alloc(c, pool, &c->xf_cur, (size_t) B * 3 * Af))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->XF, (size_t) B * 3 * Af * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->DPAR, (size_t) B * 8 * slots))) return rc;
   if ((rc = dev_alloc(c, pool, &c->mu, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fu, (size_t) B * 3))) return rc;
   if ((rc = dev_alloc(c, pool, &c->GX, se))) return rc;
@@ -540,6 +548,7 @@ int dc_step_forward(dc_ctx *c, int slot, const double *fixed_pts, dc_step_stats 
   if (fixed_pts && Af > 0) {
     if ((rc = h2d_planar(c, fixed_pts, c->xf_cur, Af, 2))) return rc;
   }
+  if (Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * Af * (slot + 1), c->xf_cur, sizeof(float) * c->B * 3 * Af, hipMemcpyDeviceToDevice, c->stream));
   if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
   launch_pd_step(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
   HIPCHK(c, hipGetLastError());
@@ -639,6 +648,7 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
   for (int k = 0; k < nsteps; k++) {
+    if (c->S.Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
     if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
     launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
   }
@@ -698,6 +708,17 @@ int dc_get_gradient(dc_ctx *c, double *dL_dx, double *dL_dv, double *dL_dmu) {
     HIPCHK(c, hipMemcpy(dmu.data(), c->DMU, dmu.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < dmu.size(); k++) dL_dmu[k] = dmu[k];
   }
+  return DC_OK;
+}
+
+int dc_get_param_gradients(dc_ctx *c, int slot, double *out) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1 || !out) return fail(c, DC_ERR_INVALID, "dc_get_param_gradients: slot 0 has no record");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<float> v((size_t) c->B * 8);
+  HIPCHK(c, hipMemcpy(v.data(), c->DPAR + (size_t) c->B * 8 * slot, v.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < v.size(); k++) out[k] = v[k];
   return DC_OK;
 }
 

@@ -432,6 +432,27 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
     if (gradient_new.dL_dxfixed_accum.size() == 3 * Af)
       for (size_t k = 0; k < 3 * Af; k++) ret.dL_dxfixed_accum[k] = ret.dL_dxfixed[k] + gradient_new.dL_dxfixed_accum[k];
   }
+  // parameter gradients of this step (Simulation.cpp:1672-1764): the device returns this step's contributions
+  double par[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  check(ctx, dc_get_param_gradients(ctx, fwd.deviceSlot, par), "dc_get_param_gradients");
+  ret.dL_ddensity = gradient_new.dL_ddensity;
+  if (taskInfo.dL_density) ret.dL_ddensity += par[3];
+  ret.dL_dk_pertype = gradient_new.dL_dk_pertype;      // Constraint::ConstraintType order: spring, attachment, triangle, bending
+  const double perType[4] = {0.0, par[2], par[0], par[1]};
+  for (int k = 0; k < 4; k++)
+    if (taskInfo.dL_dk_pertype[k]) ret.dL_dk_pertype[k] = gradient_new.dL_dk_pertype[k] + perType[k];
+  ret.dL_dfext = gradient_new.dL_dfext;
+  if (taskInfo.dL_dfext)                        // :1702-1712
+    for (int d = 0; d < 3; d++) ret.dL_dfext[d] += par[4 + d] * fwd.windFactor;
+  ret.dL_dwind = gradient_new.dL_dwind;
+  if (taskInfo.dL_dfwind) {                     // :1730-1764 (sin wind model without fall-off)
+    const double c = std::cos(windFrequency * fwd.t + windPhase);
+    double tf = 0;
+    for (int d = 0; d < 3; d++) tf += par[4 + d] * wind[d] * windNorm;
+    for (int d = 0; d < 3; d++) ret.dL_dwind[d] += par[4 + d] * fwd.windFactor;
+    ret.dL_dwind[3] += tf * c * 0.5 * fwd.t;
+    ret.dL_dwind[4] += tf * c * 0.5;
+  }
   if (taskInfo.dL_dmu)                          // Simulation.cpp:1622-1632
     for (size_t k = 0; k < taskInfo.mu_primitives.size(); k++) {
       int prim = taskInfo.mu_primitives[k];

@@ -164,6 +164,12 @@ int dc_step_backward(dc_ctx *ctx, int slot, const double *dL_dxnew, const double
                      const double *dL_dxinit, const double *dL_dvinit, int is_start, double *dL_dx,
                      double *dL_dv, double *dL_dxfixed, double *dL_dmu, dc_bwd_stats *stats);
 
+/* Parameter gradients of the LAST backward step through record `slot` (Simulation.cpp:1672-1764), 8 doubles per
+ * rollout: [0..2] this step's contribution to dL/dk of {stretch, bending, attachment} (dL_dk_pertype), [3] to
+ * dL/ddensity (adddr_dd = false), [4..6] h^2 * sum_i ((I + dr_df)^T u*)_i = the summed dL_dfext_vec from which the
+ * caller forms dL_dfext / dL_dwind (multiply by windFactor, cos(...) etc. as :1730-1760), [7] unused.            */
+int dc_get_param_gradients(dc_ctx *ctx, int slot, double *out /*B*8*/);
+
 /* ---- device-resident rollouts (no host copies inside; used by bench.py and batched callers) --------- */
 /* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Asynchronous.   */
 int dc_rollout_forward(dc_ctx *ctx, int slot, int nsteps);

@@ -281,3 +281,43 @@ def test_free_running_tshirt_rollout_tracks_the_reference_golden_frames():
     assert max(errs[:10]) < 2e-5
     assert max(errs) < 1e-4          # measured 1.6e-5 after 40 free-running fp32 steps (file precision is 5e-6)
     assert nself > 0
+
+
+@pytest.mark.parametrize("mu", [0.1, 0.7])
+def test_parameter_gradients_match_oracle(mu):
+    """dL/dk per constraint type, dL/ddensity and dL/dwind of one step (Simulation.cpp:1672-1764) against the
+    oracle, on a draped cloth with attachments, sphere contact and sin wind."""
+    V, F, o, e = build_pair(11, mu=mu, att=(0, 10))
+    wind, norm, freq, phase = (0.2, 0.1, 1.0), 0.3, 14.0, 0.4
+    o.set_wind(True, 2, wind, norm, freq, phase)
+    o.set(atp=1)
+    xf = f32(V[[0, 10]].reshape(-1) + 0.02)
+    x0, v0 = settle(o, V, 50, xf)
+    t_prev = 50 / 180
+    ref = o.step(x0, v0, xf, t_prev)
+    assert ref["nprim"] > 5
+    rng = np.random.default_rng(11)
+    gx = f32(rng.standard_normal(x0.size)); gv = f32(rng.standard_normal(x0.size) * 0.01)
+    rb = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    t = t_prev + 1 / 180
+    wf = (np.sin(freq * t + phase) + 1) / 2
+    e.alloc_batch(1, 1)
+    e.set_state(0, x0, v0)
+    e.set_uniform_force(np.array(wind) * norm * wf)
+    e.step_forward(0, fixed_pts=xf)
+    x1, _ = e.get_state(1)
+    assert np.abs(x1[0] - ref["x"]).max() <= POS_TOL
+    gb = e.step_backward(1, gx, gv, is_start=False)
+    pg = e.get_param_gradients(1)
+    tot = pg["sum_dfext"][0]
+    c = np.cos(freq * t + phase)
+    windForce = np.array(wind) * norm
+    dwind = np.concatenate([tot * wf, [tot @ windForce * c * 0.5 * t, tot @ windForce * c * 0.5]])
+    ek = np.abs(pg["dL_dk"][0] - rb["dL_dk"]) / np.maximum(np.abs(rb["dL_dk"]), 1e-12)
+    ed = abs(pg["dL_ddensity"][0] - rb["dL_ddensity"]) / abs(rb["dL_ddensity"])
+    ew = np.linalg.norm(dwind - rb["dL_dwind"]) / np.linalg.norm(rb["dL_dwind"])
+    print(f"\n[param grads mu={mu}] dL_dk gpu {pg['dL_dk'][0]} ref {rb['dL_dk']} rel {ek}; ddensity gpu {pg['dL_ddensity'][0]:.6e} ref {rb['dL_ddensity']:.6e}"
+          f" rel {ed:.2e}; dwind rel {ew:.2e}")
+    # sums of signed per-element terms: fp32 rounding of the residual A^T(p - A x) (a small difference of O(1)
+    # quantities near equilibrium) bounds these at ~1e-3 relative
+    assert np.all(ek <= 5e-3) and ed <= 1e-3 and ew <= 1e-4
