@@ -40,6 +40,13 @@ struct DevSystem {
   const int2 *ell;
   const int *ell_ptr;           // [ceil(N/64)]
   const int *ell_w;             // [ceil(N/64)] width of the chunk
+  // P once more, symmetrically scaled to unit diagonal (D^-1/2 P D^-1/2) and packed for dc_forward_pk.hip: per
+  // 64-row chunk pk_n[c] 16-byte packets per row (a multiple of 4), packet (s, lane) at pk[pk_ptr[c] + 64 s + lane] =
+  // {v0, v1, v2, d0 | d1 << 10 | d2 << 20}, d = column - row + 512; chunks cover 512 * pk_vpt rows
+  const int4 *pk;
+  const int *pk_ptr, *pk_n;
+  const float *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
+  int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
   // self-collision (Simulation.cpp:194-220, 225-373): collision radii, connected-pair table (share a triangle)
   const float *radii;           // [N]
   const int *conn_ptr;          // [N+1]
@@ -116,6 +123,7 @@ struct BwdArgs {
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 // LDS/register-resident variant (dc_forward_res.hip); returns false when N is too large for it.
+bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 bool launch_pd_step_resident(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st, int variant);
 void launch_self_detect(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);

@@ -183,20 +183,22 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
 
 static int pick_threads_fwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
 
-// DC_FWD_VARIANT (read once): "global" forces this file's global-memory kernel (any N); "0" / "1" select the
-// register/thread shape of the resident kernel (dc_forward_res.hip). Default: resident, shape 0.
+// DC_FWD_VARIANT (read once, development switch): "global" forces this file's global-memory kernel (any N);
+// "0" / "1" force the ELL resident kernel (dc_forward_res.hip) in one of its two thread shapes. Default: the
+// packet resident kernel (dc_forward_pk.hip) when its tables exist, else ELL resident, else global.
 static int fwd_variant() {
-  static int v = -2;
-  if (v == -2) {
+  static int v = -3;
+  if (v == -3) {
     const char *e = getenv("DC_FWD_VARIANT");
-    v = !e ? 0 : (e[0] == 'g' ? -1 : atoi(e));
+    v = !e ? -2 : (e[0] == 'g' ? -1 : atoi(e));
   }
   return v;
 }
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   const int variant = fwd_variant();
-  if (variant >= 0 && launch_pd_step_resident(S, W, A, B, st, variant)) return;
+  if (variant == -2 && launch_pd_step_packet(S, W, A, B, st)) return;
+  if (variant != -1 && launch_pd_step_resident(S, W, A, B, st, variant == 1 ? 1 : 0)) return;
   switch (pick_threads_fwd(S.N)) {
     case 256: hipLaunchKernelGGL(k_pd_step<256>, dim3(B), dim3(256), 0, st, S.self_dev, W, A); break;
     case 512: hipLaunchKernelGGL(k_pd_step<512>, dim3(B), dim3(512), 0, st, S.self_dev, W, A); break;

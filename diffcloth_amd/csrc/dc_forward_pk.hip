@@ -1,0 +1,358 @@
+// CDNA4 (gfx950) forward step, packet-ELL resident variant (N <= 10240, matrix bandwidth <= 511).
+//
+// Same algorithm and per-rollout workgroup ownership as dc_forward.hip / dc_forward_res.hip; the inner Jacobi PCG
+// (>95 % of the sweeps of a step) is restructured around what bounds it on a CU, the 64 B/clk vector-memory pipe
+// that streams the shared matrix, and the register file:
+//   * the PCG runs on the symmetrically scaled system  (D^-1/2 P D^-1/2) xs = D^-1/2 rhs  (unit diagonal): plain CG
+//     on it IS the Jacobi-preconditioned CG on P (same iterates, same r^T D^-1 r stopping rule) but needs no
+//     diagonal / preconditioner traffic inside the loop;
+//   * off-diagonals travel as 16-byte packets {v0, v1, v2, d0 | d1 << 10 | d2 << 20}: three fp32 values and three
+//     10-bit column deltas relative to the row (biased by 512) = 5.33 B per non-zero instead of 8, one
+//     global_load_dwordx4 per three non-zeros, wave-sliced so a wave reads 1 KiB contiguous per instruction;
+//     the next row's packets are in flight while the current row is consumed;
+//   * the search direction p lives in LDS as a float2 (x, y) plane + a float z plane (a neighbour costs one
+//     ds_read_b64 + one ds_read_b32), the residual r and A p in registers, the iterate x in registers for the
+//     first VPT - XL rows of a thread and in the LDS left over by p for the rest: nothing of a CG iteration
+//     touches global memory except the (L2-resident, batch-shared) packet stream.
+// Reference: Simulation::step (Simulation.cpp:1043-1428), global solve :1267 (SimplicialLLT::solve) replaced by
+// this PCG on the correction system (see dc_forward.hip header).
+#include "dc_devlib.h"
+
+namespace dc {
+
+#ifdef DC_PROFILE_PHASES
+#define PH_DECL long long ph_t = clock64(); long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
+#define PH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[phases pk] pd %d cg %d | per PD iter: local %lld vertex %lld pd-update %lld | per CG iter: spmv %lld pAp-red %lld upd+red %lld cycles\n", iters, cg_total, ph_acc[0] / iters, ph_acc[1] / iters, ph_acc[5] / iters, ph_acc[2] / max(cg_total, 1), ph_acc[3] / max(cg_total, 1), ph_acc[4] / max(cg_total, 1));
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_PRINT
+#endif
+
+namespace {
+
+constexpr int PB = 4;   // packets per batch; rows are stored padded to a multiple of PB packets
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// fp32 inside a wave, fp64 across the waves (the CG scalars only steer the iteration; the fixed point of the PD
+// loop does not depend on them)
+template <int THREADS>
+__device__ __forceinline__ double block_sum_f(float v, double *red) {
+  v = wave_sum_f(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = (double) v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; k++) s += red[k];
+  return s;
+}
+
+__device__ __forceinline__ void load_batch(int4 (&e)[PB], const int4 *__restrict__ row, int s0) {
+#pragma unroll
+  for (int j = 0; j < PB; j++) e[j] = row[(s0 + j) * 64];
+}
+
+template <int NP>
+__device__ __forceinline__ void consume(const int4 (&e)[PB], const float *lp, int base, float &ax, float &ay, float &az) {
+  const float2 *lxy = (const float2 *) lp;
+  const float *lz = lp + 2 * NP;
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    const int c0 = base + (e[j].w & 1023), c1 = base + ((e[j].w >> 10) & 1023), c2 = base + ((e[j].w >> 20) & 1023);
+    const float a0 = __int_as_float(e[j].x), a1 = __int_as_float(e[j].y), a2 = __int_as_float(e[j].z);
+    const float2 q0 = lxy[c0], q1 = lxy[c1], q2 = lxy[c2];
+    const float z0 = lz[c0], z1 = lz[c1], z2 = lz[c2];
+    ax = fmaf(a0, q0.x, ax); ay = fmaf(a0, q0.y, ay); az = fmaf(a0, z0, az);
+    ax = fmaf(a1, q1.x, ax); ay = fmaf(a1, q1.y, ay); az = fmaf(a1, z1, az);
+    ax = fmaf(a2, q2.x, ax); ay = fmaf(a2, q2.y, ay); az = fmaf(a2, z2, az);
+  }
+}
+
+}  // namespace
+
+template <int THREADS, int VPT, int XL>
+__global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
+  const DevSystem &S = *Sp;
+  constexpr int NP = THREADS * VPT;
+  constexpr int WAVES = THREADS / 64;
+  constexpr int XR = VPT - XL;
+  extern __shared__ float lp[];          // search direction: float2 (x, y) [NP] then float z [NP]; then x rows [XL][3][THREADS]
+  float *lx = lp + 3 * NP;
+  __shared__ double red[THREADS / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = S.N, T = S.T, E = S.E, NC = S.NC;
+  const size_t off = (size_t) b * 3 * N;
+  const float *xn = A.x_in + off, *vn = A.v_in + off;
+  float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off;
+  float *corner = W.corner + (size_t) b * 3 * NC;
+  float *rec_f = A.rec_f + off, *rec_r = A.rec_r + off, *rec_n = A.rec_n + off;
+  int *rec_prim = A.rec_prim + (size_t) b * N;
+  const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
+  const float *mu = A.mu + (size_t) b * S.ngroups;
+  const float h = S.h;
+  const f3 grav = mk(S.gx, S.gy, S.gz);
+  const f3 fu = A.fu ? mk(A.fu[3 * b], A.fu[3 * b + 1], A.fu[3 * b + 2]) : mk(0, 0, 0);
+
+  // ---- step set-up: s_n, initial guess, contact detection (Simulation.cpp:1097-1160, :1254-1256) ----
+  float part = 0.f;
+  int ncontact = 0;
+  for (int i = tid; i < N; i += THREADS) {
+    const float m = S.mass[i];
+    f3 v = ld3(vn, i, N);
+    f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
+    f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
+    st3(vnow, i, N, v0);
+    st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h
+    part += dot(v0, v0);
+    int prim = -1;
+    f3 nrm = mk(0, 0, 0);
+    if (S.contact_enabled) prim = detect_primitive(S, ld3(xn, i, N), v0, nrm);
+    rec_prim[i] = prim;
+    st3(rec_n, i, N, nrm);
+    ncontact += (prim >= 0);
+  }
+  double min_xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
+  const int total_contacts = (int) block_sum<THREADS>((double) ncontact, red);
+  const int nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;   // from k_self_detect
+  bool improved = false, converged = false, stalled = false;
+  int iters = 0, cg_total = 0, since_progress = 0;
+  double xdiff = 0;
+
+  PH_DECL
+  for (int iter = 0; iter < A.pd_cap; iter++) {
+    // ---- local step: per-element projection residual, written per constraint corner ----
+    for (int t = tid; t < T; t += THREADS) {      // Triangle::project (Triangle.cpp:310-351)
+      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+      const float4 D = S.tri_D[t];
+      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
+      f3 e0 = (ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h;
+      f3 e1 = (ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h;
+      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
+      Polar P = polar3x2(f0, f1);
+      const float s = h * S.tri_w2[t];
+      f3 g0 = (P.t0 - f0) * s, g1 = (P.t1 - f1) * s;
+      f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
+      st3(corner, t, NC, mk(0, 0, 0) - c1 - c2); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
+    }
+    for (int e = tid; e < E; e += THREADS) {      // TriangleBending::project (TriangleBending.cpp:138-151)
+      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+      const float4 w = S.bend_w[e];
+      const float2 nw = S.bend_nw[e];
+      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
+      f3 ev = ((ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h) * w.y;
+      ev = ev + ((ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h) * w.z;
+      ev = ev + ((ld3(xn, i3, N) - x0) + (ld3(vnow, i3, N) - v0) * h) * w.w;
+      f3 p = mk(0, 0, 0);
+      if (nw.x > 1e-6f) p = normalized(ev) * nw.x;
+      f3 d = (p - ev) * (h * nw.y);
+      const int base = 3 * T;
+      st3(corner, base + e, NC, d * w.x); st3(corner, base + E + e, NC, d * w.y);
+      st3(corner, base + 2 * E + e, NC, d * w.z); st3(corner, base + 3 * E + e, NC, d * w.w);
+    }
+    __syncthreads();
+    PH(0)
+    // ---- vertex pass: f, friction r, right-hand side of the correction solve -> registers / LDS ----
+    part = 0.f;
+    for (int i = tid; i < NP; i += THREADS) {
+      f3 rhs = mk(0, 0, 0);
+      float di = 0.f;
+      if (i < N) {
+        f3 f = ld3(g, i, N);
+        const int k1 = S.inc_ptr[i + 1];
+        for (int q = S.inc_ptr[i]; q < k1; q++) f = f + ld3(corner, S.inc_idx[q], NC);
+        f3 v = ld3(vnow, i, N);
+        const int a = S.att_of_vertex[i];
+        if (a >= 0) f = f + ((ld3(xfix, a, S.Af) - ld3(xn, i, N)) - v * h) * (h * S.k_att);   // AttachmentSpring.cpp:25-29
+        const float m = S.mass[i];
+        f3 r = mk(0, 0, 0);
+        const int prim = rec_prim[i];
+        if (prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
+          f3 n = ld3(rec_n, i, N);
+          f3 d = f - prim_vout(S.prims[prim], n) * m;
+          r = dry_friction(n, d, mu[S.prims[prim].group]);
+        }
+        st3(rec_f, i, N, f);
+        st3(rec_r, i, N, r);
+        di = S.sq_dinv[i];
+        rhs = (f + r - v * m) * di;             // scaled residual D^-1/2 rhs
+        part += dot(rhs, rhs);
+      }
+      ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+    }
+    if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
+      __syncthreads();
+      self_friction_layers<THREADS>(S, A.self, b, rec_f, rec_r);
+      part = 0.f;
+      for (int i = tid; i < N; i += THREADS) {
+        f3 rhs = (ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i]) * S.sq_dinv[i];
+        ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+        part += dot(rhs, rhs);
+      }
+    }
+    double rz = block_sum<THREADS>((double) part, red);
+    // residual, A p and (most of) the iterate of the scaled CG live in registers from here to the update
+    float rr[VPT][3], ap[VPT][3], xx[XR > 0 ? XR : 1][3];
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      const int i = tid + k * THREADS;
+      const float2 q = ((const float2 *) lp)[i];
+      rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = lp[2 * NP + i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        if (k < XR) xx[k < XR ? k : 0][c] = 0.f;
+        else lx[((k - XR) * 3 + c) * THREADS + tid] = 0.f;
+      }
+    }
+    PH(1)
+    // ---- global step: Jacobi PCG on P dv = rhs as plain CG on the scaled system, resident in LDS + registers ----
+    if (rz > 1e-300) {
+      const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+      for (int it = 0; it < A.cg_max;) {
+        __syncthreads();
+        float part2 = 0.f;
+        int zs;                               // opaque zero: keeps the per-row addresses out of LICM's reach (they
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zs));   // would be hoisted into ~60 live registers otherwise)
+        const int wz = wv + zs, tz = tid + zs;
+        int4 nxt[PB];
+        load_batch(nxt, S.pk + S.pk_ptr[wz] + lane, 0);
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int chunk = wz + k * WAVES;   // wave-uniform: pk_ptr / pk_n are scalar loads
+          const int i = chunk * 64 + lane;
+          const int np = S.pk_n[chunk];
+          const int4 *row = S.pk + S.pk_ptr[chunk] + lane;
+          int4 cur[PB];
+#pragma unroll
+          for (int j = 0; j < PB; j++) cur[j] = nxt[j];
+          if (k + 1 < VPT) load_batch(nxt, S.pk + S.pk_ptr[chunk + WAVES] + lane, 0);
+          const float2 pxy = ((const float2 *) lp)[i];
+          const float pz = lp[2 * NP + i];
+          float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
+          const int base = i - 512;
+          consume<NP>(cur, lp, base, ax, ay, az);
+          for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
+            load_batch(cur, row, s0);
+            consume<NP>(cur, lp, base, ax, ay, az);
+          }
+          ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
+          part2 += pxy.x * ax + pxy.y * ay + pz * az;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        PH(2)
+        const double pAp = block_sum_f<THREADS>(part2, red);
+        PH(3)
+        const float alpha = (float) (rz / pAp);
+        part2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int i = tz + k * THREADS;
+          const float2 pxy = ((const float2 *) lp)[i];
+          const float pv[3] = {pxy.x, pxy.y, lp[2 * NP + i]};
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            if (k < XR) xx[k < XR ? k : 0][c] = fmaf(alpha, pv[c], xx[k < XR ? k : 0][c]);
+            else lx[((k - XR) * 3 + c) * THREADS + tid] = fmaf(alpha, pv[c], lx[((k - XR) * 3 + c) * THREADS + tid]);
+            rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
+            part2 = fmaf(rr[k][c], rr[k][c], part2);
+          }
+        }
+        const double rz_new = block_sum_f<THREADS>(part2, red);
+        it++; cg_total++;
+        if (!(rz_new > stop)) break;
+        const float beta = (float) (rz_new / rz);
+        rz = rz_new;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int i = tz + k * THREADS;
+          const float2 pxy = ((const float2 *) lp)[i];
+          ((float2 *) lp)[i] = make_float2(fmaf(beta, pxy.x, rr[k][0]), fmaf(beta, pxy.y, rr[k][1]));
+          lp[2 * NP + i] = fmaf(beta, lp[2 * NP + i], rr[k][2]);
+        }
+        PH(4)
+      }
+    }
+    // ---- update + convergence (Simulation.cpp:1268, 1310-1373) ----
+    part = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      const int i = tid + k * THREADS;
+      if (i < N) {
+        float xs[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) xs[c] = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tid];
+        f3 d = mk(xs[0], xs[1], xs[2]) * S.sq_dinv[i];
+        st3(vnow, i, N, ld3(vnow, i, N) + d);
+        part += dot(d, d);
+      }
+    }
+    xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
+    PH(5)
+    iters = iter + 1;
+    converged = xdiff < (double) A.fwd_tol;
+    if (xdiff < min_xdiff) {
+      since_progress = 0;     // any new minimum counts: slow monotone convergence must never look like a stall
+      min_xdiff = xdiff;
+      improved = true;
+      if (!converged)
+        for (int i = tid; i < N; i += THREADS) st3(vbest, i, N, ld3(vnow, i, N));
+    }
+    if (converged) break;
+    if (++since_progress >= A.stall_window) { stalled = true; break; }   // fp32 floor, see dc_forward.hip
+  }
+  // ---- write the new state (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
+  float *xo = A.x_out + off, *vo = A.v_out + off;
+  for (int i = tid; i < N; i += THREADS) {
+    f3 x = ld3(xn, i, N);
+    if (converged) { f3 v = ld3(vnow, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
+    else if (improved) { f3 v = ld3(vbest, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
+    else { st3(vo, i, N, ld3(vn, i, N)); st3(xo, i, N, x); }
+  }
+  if (tid == 0) {
+    dc_step_stats s;
+    s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
+    s.self_contacts = nself; s.last_xdiff = (float) xdiff;
+    A.stats[b] = s;
+  }
+  PH_PRINT
+}
+
+template <int THREADS, int VPT, int XL>
+static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+  const size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+}
+
+// 512 threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).
+bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+  if (!S.pk_ok) return false;
+  switch (S.pk_vpt) {
+    case 1: launch_pk<512, 1, 0>(S, W, A, B, st); break;
+    case 2: launch_pk<512, 2, 0>(S, W, A, B, st); break;
+    case 3: launch_pk<512, 3, 0>(S, W, A, B, st); break;
+    case 4: launch_pk<512, 4, 0>(S, W, A, B, st); break;
+    case 6: launch_pk<512, 6, 0>(S, W, A, B, st); break;
+    case 8: launch_pk<512, 8, 0>(S, W, A, B, st); break;
+    case 10: launch_pk<512, 10, 0>(S, W, A, B, st); break;
+    case 12: launch_pk<512, 12, 0>(S, W, A, B, st); break;
+    case 16: launch_pk<512, 16, 2>(S, W, A, B, st); break;
+    case 20: launch_pk<512, 20, 6>(S, W, A, B, st); break;
+    default: return false;
+  }
+  return true;
+}
+
+}  // namespace dc
