@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libdiffcloth_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-ENGINE_SOURCES = ["dc_forward.hip", "dc_forward_res.hip", "dc_forward_pk.hip", "dc_adjoint.hip", "dc_selfcontact.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp"]
+ENGINE_SOURCES = ["dc_forward.hip", "dc_forward_res.hip", "dc_forward_pk.hip", "dc_adjoint.hip", "dc_selfcontact.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp", "dc_windows.cpp"]
 
 
 def _stale(target, deps):
@@ -24,22 +24,35 @@ def _stale(target, deps):
 
 
 def build_engine(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in ENGINE_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("dc_device.h", "dc_devlib.h", "dc_system.h")] + [os.path.join(ROOT, "include", "diffcloth_hip.h")]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
-           "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-o", LIB]
-    cmd += os.environ.get("DC_CXXFLAGS", "").split()     # e.g. -DDC_PROFILE_PHASES for in-kernel phase timing
-    for s in srcs:
-        if s.endswith(".cpp"):
-            cmd += ["-x", "hip", s]
-        else:
-            cmd += [s]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    """Compiles every source to its own object (in parallel, only the stale ones) and links the shared library."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(ROOT, "include", "diffcloth_hip.h")]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
+             "-I", os.path.join(ROOT, "include")] + os.environ.get("DC_CXXFLAGS", "").split()   # e.g. -DDC_PROFILE_PHASES
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    jobs, objs = [], []
+    for name in ENGINE_SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(objdir, name + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([HIPCC] + flags + ["-c"] + (["-x", "hip"] if name.endswith(".cpp") else []) + [src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+        with open(stamp, "w") as f:
+            f.write(" ".join(flags))
     return LIB
 
 

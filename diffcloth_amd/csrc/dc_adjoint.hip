@@ -15,6 +15,7 @@
 //   mode 1  direct solve (semantics of backwardGradientForceDirectSolver / solveDirect, Simulation.cpp:1431-1440):
 //           block-Jacobi preconditioned BiCGSTAB on K itself, relative residual <= adjoint_rel_tol.
 #include "dc_devlib.h"
+#include "dc_winlib.h"
 
 namespace dc {
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *red) {
 struct AdjCtx {
   const float *xnew, *rec_f, *rec_n, *mu;
   const int *rec_prim;
-  float *y, *corner;
+  float *y, *corner, *lds;
   SelfRec self;
   int nself, b;
 };
@@ -83,8 +84,8 @@ __device__ __forceinline__ void contact_transpose(const DevSystem &S, const AdjC
 // out = K z with z = zin (optionally scaled by D^-1: right preconditioning). Also returns the partial sums
 // of out.d1 and out.out of this thread (d1 may be null). Ends WITHOUT a barrier: callers reduce next.
 template <int THREADS>
-__device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
-                                                 float *out, const float *d1, float &dot1, float &dot2) {
+__device__ __forceinline__ void adjoint_operator_global(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
+                                                        float *out, const float *d1, float &dot1, float &dot2) {
   const int N = S.N, T = S.T, E = S.E, NC = S.NC, tid = threadIdx.x;
   const float h2 = S.h * S.h;
   // __restrict__ + unroll: lets the scheduler overlap the index -> gather -> store chains of neighbouring
@@ -154,16 +155,40 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   }
 }
 
+// Same operator with the element pass inside LDS (element windows, dc_winlib.h): no corner array, no atomics.
+template <int THREADS>
+__device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
+                                                 float *out, const float *d1, float &dot1, float &dot2) {
+  if (!S.win_ok) { adjoint_operator_global<THREADS>(S, C, zin, precond, out, d1, dot1, dot2); return; }
+  const int N = S.N;
+  const float h2 = S.h * S.h;
+  contact_transpose<THREADS>(S, C, zin, precond, C.y);       // y = (I + dr_df)^T z, ends with a barrier
+  float a1 = 0.f, a2 = 0.f;
+  const float *y = C.y;
+  element_windows<THREADS>(S, C.lds, y, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, [&](int i, f3 sum) {
+    f3 z = ld3(zin, i, N);
+    if (precond) z = z * S.dinv[i];
+    f3 o = z * S.mass[i] + sum;
+    if (S.att_of_vertex[i] >= 0) o = o + ld3(y, i, N) * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
+    st3(out, i, N, o);
+    if (d1) a1 += dot(o, ld3(d1, i, N));
+    a2 += dot(o, o);
+  });
+  dot1 = a1; dot2 = a2;
+}
+
 }  // namespace
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
   const DevSystem &S = *Sp;
+  extern __shared__ float dyn_lds[];      // element windows (S.win_lds_bytes)
   __shared__ double red[2 * (THREADS / 64)];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = S.N;
   const size_t off = (size_t) b * 3 * N;
   AdjCtx C;
+  C.lds = dyn_lds;
   C.xnew = A.x_new + off; C.rec_f = A.rec_f + off; C.rec_n = A.rec_n + off;
   C.rec_prim = A.rec_prim + (size_t) b * N;
   C.mu = A.mu + (size_t) b * S.ngroups;
@@ -396,11 +421,22 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
 
 static int pick_threads_bwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
 
+template <int THREADS>
+static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+  const size_t lds = S.win_ok ? (size_t) S.win_lds_bytes : 0;
+  static size_t configured = 0;
+  if (lds > configured) {
+    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_adjoint_step<THREADS>, dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+}
+
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
   switch (pick_threads_bwd(S.N)) {
-    case 256: hipLaunchKernelGGL(k_adjoint_step<256>, dim3(B), dim3(256), 0, st, S.self_dev, W, A); break;
-    case 512: hipLaunchKernelGGL(k_adjoint_step<512>, dim3(B), dim3(512), 0, st, S.self_dev, W, A); break;
-    default: hipLaunchKernelGGL(k_adjoint_step<1024>, dim3(B), dim3(1024), 0, st, S.self_dev, W, A); break;
+    case 256: launch_adj<256>(S, W, A, B, st); break;
+    case 512: launch_adj<512>(S, W, A, B, st); break;
+    default: launch_adj<1024>(S, W, A, B, st); break;
   }
 }
 

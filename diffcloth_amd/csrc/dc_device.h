@@ -47,6 +47,16 @@ struct DevSystem {
   const int *pk_ptr, *pk_n;
   const float *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
+  // element windows (dc_windows.h / dc_winlib.h): the per-constraint passes run window by window inside LDS
+  const int4 *win;              // [2 * nwin]: {v0, v1, lo, vs}, {tri_off, ntri, bend_off, nbend}
+  const int4 *wtri_rec;         // per window-triangle: j0 | j1 << 16, j2, bits(w^2), triangle id
+  const float4 *wtri_D;
+  const int4 *wbend_rec;        // per window-flap: j0 | j1 << 16, j2 | j3 << 16, bits(rest norm), bits(w^2)
+  const float4 *wbend_w;
+  const int4 *winc;             // vertex -> (result vector, coefficient) pair packets, wave-sliced by 64-vertex chunk
+  const int *winc_ptr, *winc_n;
+  int nwin, win_vcap, win_nrcap, win_ok;
+  int win_lds_bytes, pad2;
   // self-collision (Simulation.cpp:194-220, 225-373): collision radii, connected-pair table (share a triangle)
   const float *radii;           // [N]
   const int *conn_ptr;          // [N+1]

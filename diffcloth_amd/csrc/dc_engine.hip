@@ -8,6 +8,7 @@
 #include <vector>
 #include "dc_device.h"
 #include "dc_system.h"
+#include "dc_windows.h"
 
 using namespace dc;
 
@@ -345,6 +346,30 @@ int dc_build(dc_ctx *c) {
     if ((rc = upload<int>(c, &S.ell_ptr, eptr))) return rc;
     if ((rc = upload<int>(c, &S.ell_w, ew))) return rc;
   }
+  {  // element windows: the local step and the adjoint's element pass run inside LDS
+    HostWindows HW;
+    const char *envw = getenv("DC_WINDOWS");       // development switch: DC_WINDOWS=0 keeps the global-memory corner passes
+    S.win_ok = 0;
+    if (!(envw && envw[0] == '0') && HW.build(H, (size_t) 150 * 1024)) {
+      const int *ip; const float *fp;
+      if ((rc = upload<int>(c, &ip, HW.win))) return rc;
+      S.win = (const int4 *) ip;
+      if ((rc = upload<int>(c, &ip, HW.tri_rec))) return rc;
+      S.wtri_rec = (const int4 *) ip;
+      if ((rc = upload<float>(c, &fp, HW.tri_D))) return rc;
+      S.wtri_D = (const float4 *) fp;
+      if ((rc = upload<int>(c, &ip, HW.bend_rec))) return rc;
+      S.wbend_rec = (const int4 *) ip;
+      if ((rc = upload<float>(c, &fp, HW.bend_w))) return rc;
+      S.wbend_w = (const float4 *) fp;
+      if ((rc = upload<int>(c, &ip, HW.inc))) return rc;
+      S.winc = (const int4 *) ip;
+      if ((rc = upload<int>(c, &S.winc_ptr, HW.inc_ptr))) return rc;
+      if ((rc = upload<int>(c, &S.winc_n, HW.inc_n))) return rc;
+      S.nwin = HW.nwin; S.win_vcap = HW.vcap; S.win_nrcap = HW.nrcap; S.win_lds_bytes = (int) HW.lds_bytes;
+      S.win_ok = 1;
+    }
+  }
   {  // packet-ELL copy of the scaled matrix for dc_forward_pk.hip
     static const int allowed[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20};
     const int need = (N + 511) / 512;
@@ -370,7 +395,6 @@ int dc_build(dc_ctx *c) {
         flat.resize(flat.size() + (size_t) 4 * 64 * np, 0);
         for (int l = 0; l < 64; l++) {
           const int r = 64 * ch + l;
-          int e = 0;   // running off-diagonal index of the row
           int kk = r < N ? H.P_ptr[r] : 0;
           const int kend = r < N ? H.P_ptr[r + 1] : 0;
           for (int s = 0; s < np; s++) {
@@ -383,7 +407,7 @@ int dc_build(dc_ctx *c) {
                 const float v = (float) (H.P_val[kk] * sq[r] * sq[col]);
                 std::memcpy(&bits[q], &v, sizeof(int));
                 d = col - r + 512;
-                kk++; e++;
+                kk++;
               }
               wd |= d << (10 * q);
             }

@@ -1,0 +1,163 @@
+#include "dc_windows.h"
+#include <algorithm>
+#include <cstring>
+
+namespace dc {
+
+namespace {
+
+inline int fbits(float v) { int b; std::memcpy(&b, &v, sizeof(int)); return b; }
+
+struct Plan { int nwin = 0, vcap = 0, nrcap = 0; };
+
+// window w of `own` vertices: which elements touch it and which vertex span they cover
+struct WinScan {
+  std::vector<int> tris, bends;
+  int lo = 0, hi = 0;
+};
+
+void scan_window(const HostSystem &H, int v0, int v1, WinScan &s) {
+  s.tris.clear(); s.bends.clear();
+  s.lo = v0; s.hi = v1;
+  auto in = [&](int v) { return v >= v0 && v < v1; };
+  for (int t = 0; t < H.T; t++) {
+    const int *q = &H.tri[3 * t];
+    if (in(q[0]) || in(q[1]) || in(q[2])) {
+      s.tris.push_back(t);
+      for (int k = 0; k < 3; k++) { s.lo = std::min(s.lo, q[k]); s.hi = std::max(s.hi, q[k] + 1); }
+    }
+  }
+  for (int e = 0; e < H.E; e++) {
+    const int *q = &H.bend_v[4 * e];
+    if (in(q[0]) || in(q[1]) || in(q[2]) || in(q[3])) {
+      s.bends.push_back(e);
+      for (int k = 0; k < 4; k++) { s.lo = std::min(s.lo, q[k]); s.hi = std::max(s.hi, q[k] + 1); }
+    }
+  }
+}
+
+// sizing pass for one window size
+Plan plan_for(const HostSystem &H, int own, const std::vector<int> &emin, const std::vector<int> &emax) {
+  Plan p;
+  p.nwin = (H.N + own - 1) / own;
+  for (int w = 0; w < p.nwin; w++) {
+    const int v0 = w * own, v1 = std::min(H.N, v0 + own);
+    int lo = v0, hi = v1, nt = 0, nb = 0;
+    auto in = [&](int v) { return v >= v0 && v < v1; };
+    for (int t = 0; t < H.T; t++) {
+      if (emax[t] < v0 || emin[t] >= v1) continue;
+      const int *q = &H.tri[3 * t];
+      if (in(q[0]) || in(q[1]) || in(q[2])) { nt++; lo = std::min(lo, emin[t]); hi = std::max(hi, emax[t] + 1); }
+    }
+    for (int e = 0; e < H.E; e++) {
+      const int id = H.T + e;
+      if (emax[id] < v0 || emin[id] >= v1) continue;
+      const int *q = &H.bend_v[4 * e];
+      if (in(q[0]) || in(q[1]) || in(q[2]) || in(q[3])) { nb++; lo = std::min(lo, emin[id]); hi = std::max(hi, emax[id] + 1); }
+    }
+    p.vcap = std::max(p.vcap, hi - lo);
+    p.nrcap = std::max(p.nrcap, 2 * nt + nb);
+  }
+  return p;
+}
+
+}  // namespace
+
+bool HostWindows::build(const HostSystem &H, size_t lds_budget) {
+  *this = HostWindows();
+  const int N = H.N, T = H.T, E = H.E;
+  if (N <= 0 || T <= 0) return false;
+  std::vector<int> emin(T + E), emax(T + E);
+  for (int t = 0; t < T; t++) {
+    emin[t] = std::min({H.tri[3 * t], H.tri[3 * t + 1], H.tri[3 * t + 2]});
+    emax[t] = std::max({H.tri[3 * t], H.tri[3 * t + 1], H.tri[3 * t + 2]});
+  }
+  for (int e = 0; e < E; e++) {
+    const int *q = &H.bend_v[4 * e];
+    emin[T + e] = std::min({q[0], q[1], q[2], q[3]});
+    emax[T + e] = std::max({q[0], q[1], q[2], q[3]});
+  }
+  // the fewest windows (fewest barriers) whose LDS footprint fits, balanced; local ids are 16-bit
+  const int kmax = (N + 63) / 64;
+  Plan best;
+  int best_own = 0;
+  for (int nw = 1; nw <= std::min(kmax, 64) && best_own == 0; nw++) {
+    const int k = (kmax + nw - 1) / nw;
+    if (nw > 1 && (kmax + nw - 2) / (nw - 1) == k) continue;      // same window size as the previous candidate
+    Plan p = plan_for(H, 64 * k, emin, emax);
+    const size_t bytes = sizeof(float) * ((size_t) 6 * p.vcap + (size_t) 3 * p.nrcap);
+    if (bytes <= lds_budget && p.vcap <= 65535 && p.nrcap <= 65535) { best = p; best_own = 64 * k; }
+  }
+  if (best_own == 0) return false;
+  own = best_own; nwin = best.nwin; vcap = best.vcap; nrcap = best.nrcap;
+  lds_bytes = sizeof(float) * ((size_t) 6 * vcap + (size_t) 3 * nrcap);
+
+  const int nchunks = (N + 63) / 64;
+  inc_ptr.assign(nchunks, 0); inc_n.assign(nchunks, 0);
+  std::vector<int> tri_local(T), bend_local(E);
+  WinScan s;
+  for (int w = 0; w < nwin; w++) {
+    const int v0 = w * own, v1 = std::min(N, v0 + own);
+    scan_window(H, v0, v1, s);
+    const int ntri = (int) s.tris.size(), nbend = (int) s.bends.size();
+    const int tri_off = (int) (tri_rec.size() / 4), bend_off = (int) (bend_rec.size() / 4);
+    const int d[8] = {v0, v1, s.lo, s.hi - s.lo, tri_off, ntri, bend_off, nbend};
+    win.insert(win.end(), d, d + 8);
+    for (int k = 0; k < ntri; k++) {
+      const int t = s.tris[k];
+      tri_local[t] = k;
+      const int j0 = H.tri[3 * t] - s.lo, j1 = H.tri[3 * t + 1] - s.lo, j2 = H.tri[3 * t + 2] - s.lo;
+      const int r[4] = {j0 | (j1 << 16), j2, fbits((float) H.tri_w2[t]), t};
+      tri_rec.insert(tri_rec.end(), r, r + 4);
+      for (int q = 0; q < 4; q++) tri_D.push_back((float) H.tri_D[4 * t + q]);
+    }
+    for (int k = 0; k < nbend; k++) {
+      const int e = s.bends[k];
+      bend_local[e] = k;
+      const int *q = &H.bend_v[4 * e];
+      const int r[4] = {(q[0] - s.lo) | ((q[1] - s.lo) << 16), (q[2] - s.lo) | ((q[3] - s.lo) << 16), fbits((float) H.bend_n[e]),
+                        fbits((float) H.bend_w2[e])};
+      bend_rec.insert(bend_rec.end(), r, r + 4);
+      for (int c = 0; c < 4; c++) bend_w.push_back((float) H.bend_w[4 * e + c]);
+    }
+    // incidence pairs of the owned vertices, in the corner order of HostSystem::inc_idx
+    for (int ch = v0 / 64; ch < (v1 + 63) / 64; ch++) {
+      std::vector<std::vector<std::pair<int, float>>> rows(64);
+      int width = 0;
+      for (int l = 0; l < 64; l++) {
+        const int v = 64 * ch + l;
+        if (v >= v1) break;
+        for (int k = H.inc_ptr[v]; k < H.inc_ptr[v + 1]; k++) {
+          const int idx = H.inc_idx[k];
+          if (idx < 3 * T) {
+            const int corner = idx / T, t = idx % T;
+            const float Dx = (float) H.tri_D[4 * t], Dy = (float) H.tri_D[4 * t + 1], Dz = (float) H.tri_D[4 * t + 2],
+                        Dw = (float) H.tri_D[4 * t + 3];
+            float a, b;
+            if (corner == 1) { a = Dx; b = Dy; }
+            else if (corner == 2) { a = Dz; b = Dw; }
+            else { a = -(Dx + Dz); b = -(Dy + Dw); }
+            rows[l].push_back({2 * tri_local[t], a});
+            rows[l].push_back({2 * tri_local[t] + 1, b});
+          } else {
+            const int corner = (idx - 3 * T) / E, e = (idx - 3 * T) % E;
+            rows[l].push_back({2 * ntri + bend_local[e], (float) H.bend_w[4 * e + corner]});
+          }
+        }
+        width = std::max(width, (int) rows[l].size());
+      }
+      const int np = std::max(4, ((width + 1) / 2 + 3) / 4 * 4);
+      inc_ptr[ch] = (int) (inc.size() / 4); inc_n[ch] = np;
+      inc.resize(inc.size() + (size_t) 4 * 64 * np, 0);
+      for (int l = 0; l < 64; l++)
+        for (size_t k = 0; k < rows[l].size(); k++) {
+          const size_t o = 4 * ((size_t) inc_ptr[ch] + (size_t) (k / 2) * 64 + l) + 2 * (k % 2);
+          inc[o] = rows[l][k].first; inc[o + 1] = fbits(rows[l][k].second);
+        }
+    }
+  }
+  ok = true;
+  return true;
+}
+
+}  // namespace dc

@@ -1,0 +1,140 @@
+// Device side of the element windows (tables: dc_windows.h): stage -> per-element phase -> per-vertex phase,
+// window by window, entirely in LDS; plus the per-element operators of the forward local step and of the adjoint.
+#pragma once
+#include "dc_devlib.h"
+
+namespace dc {
+
+struct WinLds {
+  float2 *a1xy, *a2xy, *erxy;   // (x, y) planes: input 1, input 2 over the vertex span; element result vectors
+  float *a1z, *a2z, *erz;       // z planes
+};
+
+__device__ __forceinline__ WinLds win_lds(const DevSystem &S, float *lds) {
+  const int vc = S.win_vcap, nr = S.win_nrcap;
+  WinLds L;
+  L.a1xy = (float2 *) lds; L.a2xy = (float2 *) (lds + 2 * vc); L.erxy = (float2 *) (lds + 4 * vc);
+  L.a1z = lds + 4 * vc + 2 * nr; L.a2z = L.a1z + vc; L.erz = L.a2z + vc;
+  return L;
+}
+
+__device__ __forceinline__ f3 ldw(const float2 *xy, const float *z, int j) { const float2 q = xy[j]; return mk(q.x, q.y, z[j]); }
+__device__ __forceinline__ void stw(float2 *xy, float *z, int j, f3 v) { xy[j] = make_float2(v.x, v.y); z[j] = v.z; }
+
+// in1 / in2: planar [3][N] vectors of this rollout in global memory. tri_op(a0,a1,a2, b0,b1,b2, D, w2, r0, r1) and
+// bend_op(a[4], b[4], w, n, w2, res) see the values of in1 (a) and in2 (b) at the element's vertices;
+// vert_op(i, sum) receives sum_corners coef * result for every vertex exactly once. Call with all threads; starts
+// with a barrier (LDS may still be in use by the caller) and ends WITHOUT one.
+template <int THREADS, class TriOp, class BendOp, class VertOp>
+__device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, const float *__restrict__ in1,
+                                                const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
+  const int N = S.N, tid = threadIdx.x, lane = tid & 63;
+  const WinLds L = win_lds(S, lds);
+  for (int w = 0; w < S.nwin; w++) {
+    const int4 d0 = S.win[2 * w], d1 = S.win[2 * w + 1];
+    const int v0 = d0.x, v1 = d0.y, lo = d0.z, vs = d0.w, toff = d1.x, nt = d1.y, boff = d1.z, nb = d1.w;
+    __syncthreads();
+    for (int j = tid; j < vs; j += THREADS) {
+      const int i = lo + j;
+      L.a1xy[j] = make_float2(in1[i], in1[N + i]); L.a1z[j] = in1[2 * N + i];
+      L.a2xy[j] = make_float2(in2[i], in2[N + i]); L.a2z[j] = in2[2 * N + i];
+    }
+    __syncthreads();
+    for (int t = tid; t < nt; t += THREADS) {
+      const int4 r = S.wtri_rec[toff + t];
+      const float4 D = S.wtri_D[toff + t];
+      const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y;
+      f3 r0, r1;
+      tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
+             ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D, __int_as_float(r.z), r0, r1);
+      stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1);
+    }
+    for (int e = tid; e < nb; e += THREADS) {
+      const int4 r = S.wbend_rec[boff + e];
+      const float4 wq = S.wbend_w[boff + e];
+      const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y & 0xffff, j3 = (int) ((unsigned) r.y >> 16);
+      f3 res;
+      bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
+              ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq,
+              __int_as_float(r.z), __int_as_float(r.w), res);
+      stw(L.erxy, L.erz, 2 * nt + e, res);
+    }
+    __syncthreads();
+    for (int i = v0 + tid; i < v1; i += THREADS) {
+      const int ch = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
+      const int np = S.winc_n[ch];
+      const int4 *row = S.winc + S.winc_ptr[ch] + lane;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (int s0 = 0; s0 < np; s0 += 4) {
+        int4 e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = row[(s0 + j) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float2 qa = L.erxy[e[j].x], qb = L.erxy[e[j].z];
+          const float za = L.erz[e[j].x], zb = L.erz[e[j].z];
+          const float ca = __int_as_float(e[j].y), cb = __int_as_float(e[j].w);
+          sx = fmaf(ca, qa.x, sx); sy = fmaf(ca, qa.y, sy); sz = fmaf(ca, za, sz);
+          sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
+        }
+      }
+      vert_op(i, mk(sx, sy, sz));
+    }
+  }
+}
+
+// ---- forward local step: a = x_n, b = v (current iterate); x = x_n + h v, edges formed as differences first ----
+struct FwdTriOp {   // Triangle::project (Triangle.cpp:310-351): columns of h w^2 (T - F)
+  float h;
+  __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float w2, f3 &r0, f3 &r1) const {
+    f3 e0 = (x1 - x0) + (v1 - v0) * h, e1 = (x2 - x0) + (v2 - v0) * h;
+    f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
+    Polar P = polar3x2(f0, f1);
+    const float s = h * w2;
+    r0 = (P.t0 - f0) * s; r1 = (P.t1 - f1) * s;
+  }
+};
+struct FwdBendOp {  // TriangleBending::project (TriangleBending.cpp:138-151)
+  float h;
+  __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 x3, f3 v0, f3 v1, f3 v2, f3 v3, float4 w, float n, float w2, f3 &res) const {
+    f3 ev = ((x1 - x0) + (v1 - v0) * h) * w.y;
+    ev = ev + ((x2 - x0) + (v2 - v0) * h) * w.z;
+    ev = ev + ((x3 - x0) + (v3 - v0) * h) * w.w;
+    f3 p = mk(0, 0, 0);
+    if (n > 1e-6f) p = normalized(ev) * n;
+    res = (p - ev) * (h * w2);
+  }
+};
+
+// ---- adjoint: a = y, b = x_new; h^2 w^2 (A - dp/dx)^T A y per element ----
+struct AdjTriOp {   // Triangle::projectToManifoldBackward (Triangle.cpp:354-451) in closed form
+  float h2;
+  __device__ __forceinline__ void operator()(f3 q0, f3 q1, f3 q2, f3 x0, f3 x1, f3 x2, float4 D, float w2, f3 &r0, f3 &r1) const {
+    f3 e0 = x1 - x0, e1 = x2 - x0;
+    Polar P = polar3x2(e0 * D.x + e1 * D.z, e0 * D.y + e1 * D.w);
+    f3 d0 = q1 - q0, d1 = q2 - q0;
+    f3 y0 = d0 * D.x + d1 * D.z, y1 = d0 * D.y + d1 * D.w;
+    const float c = (dot(P.t1, y0) - dot(P.t0, y1)) / P.trS;
+    f3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
+    z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
+    z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
+    const float s = h2 * w2;
+    r0 = (y0 - (P.t1 * c + z0)) * s; r1 = (y1 - (z1 - P.t0 * c)) * s;
+  }
+};
+struct AdjBendOp {  // TriangleBending::backwardGradient (TriangleBending.cpp:154-172)
+  float h2;
+  __device__ __forceinline__ void operator()(f3 q0, f3 q1, f3 q2, f3 q3, f3 x0, f3 x1, f3 x2, f3 x3, float4 w, float n, float w2, f3 &res) const {
+    f3 ey = (q1 - q0) * w.y + (q2 - q0) * w.z + (q3 - q0) * w.w;
+    res = ey;
+    if (n > 1e-6f) {
+      f3 ev = (x1 - x0) * w.y + (x2 - x0) * w.z + (x3 - x0) * w.w;
+      const float en = sqrtf(dot(ev, ev));
+      f3 eh = ev * (1.0f / en);
+      res = ey - (ey - eh * dot(eh, ey)) * (n / en);
+    }
+    res = res * (h2 * w2);
+  }
+};
+
+}  // namespace dc
