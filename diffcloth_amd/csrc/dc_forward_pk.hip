@@ -17,6 +17,8 @@
 // Reference: Simulation::step (Simulation.cpp:1043-1428), global solve :1267 (SimplicialLLT::solve) replaced by
 // this PCG on the correction system (see dc_forward.hip header).
 #include "dc_devlib.h"
+#include "dc_winlib.h"
+#include <algorithm>
 
 namespace dc {
 
@@ -129,64 +131,74 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
 
   PH_DECL
   for (int iter = 0; iter < A.pd_cap; iter++) {
-    // ---- local step: per-element projection residual, written per constraint corner ----
-    for (int t = tid; t < T; t += THREADS) {      // Triangle::project (Triangle.cpp:310-351)
-      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
-      const float4 D = S.tri_D[t];
-      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
-      f3 e0 = (ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h;
-      f3 e1 = (ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h;
-      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
-      Polar P = polar3x2(f0, f1);
-      const float s = h * S.tri_w2[t];
-      f3 g0 = (P.t0 - f0) * s, g1 = (P.t1 - f1) * s;
-      f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
-      st3(corner, t, NC, mk(0, 0, 0) - c1 - c2); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
-    }
-    for (int e = tid; e < E; e += THREADS) {      // TriangleBending::project (TriangleBending.cpp:138-151)
-      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
-      const float4 w = S.bend_w[e];
-      const float2 nw = S.bend_nw[e];
-      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
-      f3 ev = ((ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h) * w.y;
-      ev = ev + ((ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h) * w.z;
-      ev = ev + ((ld3(xn, i3, N) - x0) + (ld3(vnow, i3, N) - v0) * h) * w.w;
-      f3 p = mk(0, 0, 0);
-      if (nw.x > 1e-6f) p = normalized(ev) * nw.x;
-      f3 d = (p - ev) * (h * nw.y);
-      const int base = 3 * T;
-      st3(corner, base + e, NC, d * w.x); st3(corner, base + E + e, NC, d * w.y);
-      st3(corner, base + 2 * E + e, NC, d * w.z); st3(corner, base + 3 * E + e, NC, d * w.w);
-    }
-    __syncthreads();
-    PH(0)
-    // ---- vertex pass: f, friction r, right-hand side of the correction solve -> registers / LDS ----
-    part = 0.f;
-    for (int i = tid; i < NP; i += THREADS) {
-      f3 rhs = mk(0, 0, 0);
-      float di = 0.f;
-      if (i < N) {
-        f3 f = ld3(g, i, N);
-        const int k1 = S.inc_ptr[i + 1];
-        for (int q = S.inc_ptr[i]; q < k1; q++) f = f + ld3(corner, S.inc_idx[q], NC);
-        f3 v = ld3(vnow, i, N);
-        const int a = S.att_of_vertex[i];
-        if (a >= 0) f = f + ((ld3(xfix, a, S.Af) - ld3(xn, i, N)) - v * h) * (h * S.k_att);   // AttachmentSpring.cpp:25-29
-        const float m = S.mass[i];
-        f3 r = mk(0, 0, 0);
-        const int prim = rec_prim[i];
-        if (prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
-          f3 n = ld3(rec_n, i, N);
-          f3 d = f - prim_vout(S.prims[prim], n) * m;
-          r = dry_friction(n, d, mu[S.prims[prim].group]);
-        }
-        st3(rec_f, i, N, f);
-        st3(rec_r, i, N, r);
-        di = S.sq_dinv[i];
-        rhs = (f + r - v * m) * di;             // scaled residual D^-1/2 rhs
-        part += dot(rhs, rhs);
+    // per-vertex part of the step given the summed element forces of the vertex: f, friction r, scaled right-hand
+    // side of the correction solve
+    auto vertex_body = [&](int i, f3 fint) -> f3 {
+      f3 f = ld3(g, i, N) + fint;
+      f3 v = ld3(vnow, i, N);
+      const int a = S.att_of_vertex[i];
+      if (a >= 0) f = f + ((ld3(xfix, a, S.Af) - ld3(xn, i, N)) - v * h) * (h * S.k_att);   // AttachmentSpring.cpp:25-29
+      const float m = S.mass[i];
+      f3 r = mk(0, 0, 0);
+      const int prim = rec_prim[i];
+      if (prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
+        f3 n = ld3(rec_n, i, N);
+        f3 d = f - prim_vout(S.prims[prim], n) * m;
+        r = dry_friction(n, d, mu[S.prims[prim].group]);
       }
-      ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+      st3(rec_f, i, N, f);
+      st3(rec_r, i, N, r);
+      return (f + r - v * m) * S.sq_dinv[i];       // scaled residual D^-1/2 rhs
+    };
+    part = 0.f;
+    if (S.win_ok) {
+      // ---- local step + vertex pass, window by window inside LDS (dc_winlib.h) ----
+      float *scr = W.cg_r + off;
+      element_windows<THREADS>(S, lp, xn, vnow, FwdTriOp{h}, FwdBendOp{h}, [&](int i, f3 sum) {
+        f3 rhs = vertex_body(i, sum);
+        st3(scr, i, N, rhs);
+        part += dot(rhs, rhs);
+      });
+      __syncthreads();
+      PH(0)
+      for (int i = tid; i < NP; i += THREADS) {
+        f3 rhs = (i < N) ? ld3(scr, i, N) : mk(0, 0, 0);
+        ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+      }
+    } else {
+      // ---- local step: per-element projection residual, written per constraint corner (global memory) ----
+      for (int t = tid; t < T; t += THREADS) {      // Triangle::project (Triangle.cpp:310-351)
+        const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+        f3 r0, r1;
+        const float4 D = S.tri_D[t];
+        FwdTriOp{h}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N), D, S.tri_w2[t], r0, r1);
+        f3 c1 = r0 * D.x + r1 * D.y, c2 = r0 * D.z + r1 * D.w;
+        st3(corner, t, NC, mk(0, 0, 0) - c1 - c2); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
+      }
+      for (int e = tid; e < E; e += THREADS) {      // TriangleBending::project (TriangleBending.cpp:138-151)
+        const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+        const float4 w = S.bend_w[e];
+        const float2 nw = S.bend_nw[e];
+        f3 d;
+        FwdBendOp{h}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(xn, i3, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N),
+                     ld3(vnow, i3, N), w, nw.x, nw.y, d);
+        const int base = 3 * T;
+        st3(corner, base + e, NC, d * w.x); st3(corner, base + E + e, NC, d * w.y);
+        st3(corner, base + 2 * E + e, NC, d * w.z); st3(corner, base + 3 * E + e, NC, d * w.w);
+      }
+      __syncthreads();
+      PH(0)
+      for (int i = tid; i < NP; i += THREADS) {
+        f3 rhs = mk(0, 0, 0);
+        if (i < N) {
+          f3 fint = mk(0, 0, 0);
+          const int k1 = S.inc_ptr[i + 1];
+          for (int q = S.inc_ptr[i]; q < k1; q++) fint = fint + ld3(corner, S.inc_idx[q], NC);
+          rhs = vertex_body(i, fint);
+          part += dot(rhs, rhs);
+        }
+        ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+      }
     }
     if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
       __syncthreads();
@@ -327,11 +339,12 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
 
 template <int THREADS, int VPT, int XL>
 static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
-  const size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
+  size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
+  if (S.win_ok) lds = std::max(lds, (size_t) S.win_lds_bytes);
+  static size_t configured = 0;
+  if (lds > configured) {
     (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    configured = true;
+    configured = lds;
   }
   hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
