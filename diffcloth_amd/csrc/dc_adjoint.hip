@@ -19,6 +19,16 @@
 
 namespace dc {
 
+#ifdef DC_PROFILE_PHASES
+#define PH_DECL long long ph_t = clock64(); long long ph_acc[4] = {0, 0, 0, 0};
+#define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
+#define PH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[phases adj] iters %d | per iter: operator(x2) %lld vector-ops %lld | setup %lld final %lld cycles\n", iters, ph_acc[1] / max(iters, 1), ph_acc[2] / max(iters, 1), ph_acc[0], ph_acc[3]);
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_PRINT
+#endif
+
 namespace {
 
 // two simultaneous workgroup sums
@@ -72,10 +82,28 @@ __device__ __forceinline__ void contact_transpose(const DevSystem &S, const AdjC
       st3(y, i, N, z + contact_JT(S, C, i, z));
     }
   } else {
-    for (int i = tid; i < N; i += THREADS) {
-      f3 z = ld3(zin, i, N);
-      if (precond) z = z * S.dinv[i];
-      st3(y, i, N, z + contact_JT(S, C, i, z));
+    constexpr int VB = 4;
+    for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+      f3 zq[VB], nq[VB], fq[VB];
+      int pr[VB];
+      float mq[VB];
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int ic = min(i0 + j * THREADS, N - 1);
+        zq[j] = ld3(zin, ic, N);
+        if (precond) zq[j] = zq[j] * S.dinv[ic];
+        pr[j] = C.rec_prim[ic]; nq[j] = ld3(C.rec_n, ic, N); fq[j] = ld3(C.rec_f, ic, N); mq[j] = S.mass[ic];
+      }
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int i = i0 + j * THREADS;
+        f3 w = mk(0, 0, 0);
+        if (pr[j] >= 0) {
+          f3 d = fq[j] - prim_vout(S.prims[pr[j]], nq[j]) * mq[j];
+          w = dri_dfi_T(nq[j], d, C.mu[S.prims[pr[j]].group], zq[j]);
+        }
+        if (i < N) st3(y, i, N, zq[j] + w);
+      }
     }
   }
   __syncthreads();
@@ -156,10 +184,10 @@ __device__ __forceinline__ void adjoint_operator_global(const DevSystem &S, cons
 }
 
 // Same operator with the element pass inside LDS (element windows, dc_winlib.h): no corner array, no atomics.
-template <int THREADS>
+template <int THREADS, bool WIN>
 __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
                                                  float *out, const float *d1, float &dot1, float &dot2) {
-  if (!S.win_ok) { adjoint_operator_global<THREADS>(S, C, zin, precond, out, d1, dot1, dot2); return; }
+  if constexpr (!WIN) { adjoint_operator_global<THREADS>(S, C, zin, precond, out, d1, dot1, dot2); return; }
   const int N = S.N;
   const float h2 = S.h * S.h;
   contact_transpose<THREADS>(S, C, zin, precond, C.y);       // y = (I + dr_df)^T z, ends with a barrier
@@ -179,7 +207,7 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
 
 }  // namespace
 
-template <int THREADS>
+template <int THREADS, bool WIN>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
   const DevSystem &S = *Sp;
   extern __shared__ float dyn_lds[];      // element windows (S.win_lds_bytes)
@@ -211,6 +239,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     st3(gin, i, N, ld3(gx, i, N) * gscale);
     st3(u, i, N, mk(0, 0, 0));
   }
+  PH_DECL
   int status = 0;          // 1 converged, 2 stalled at the fp32 floor, 0 cap hit
   int iters = 0, cg_total = 0, used_direct = 0;
   double udiff = 0;
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     int since_progress = 0;
     for (int it = 0; it < A.it_cap; it++) {
       float d1, d2;
-      adjoint_operator<THREADS>(S, C, u, false, cg_ap, nullptr, d1, d2);
+      adjoint_operator<THREADS, WIN>(S, C, u, false, cg_ap, nullptr, d1, d2);
       part = 0.f;
       for (int i = tid; i < N; i += THREADS) {
         f3 r = ld3(gin, i, N) - ld3(cg_ap, i, N);
@@ -255,9 +284,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   if (need_direct && gnorm > 0) {
     // ---- block-Jacobi preconditioned BiCGSTAB on K u = g, starting from the current u ----
     used_direct = 1;
+    constexpr int VB = 4;
+    PH(0)
     float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = gin;
     float d1, d2;
-    adjoint_operator<THREADS>(S, C, u, false, v, nullptr, d1, d2);
+    adjoint_operator<THREADS, WIN>(S, C, u, false, v, nullptr, d1, d2);
     part = 0.f;
     for (int i = tid; i < N; i += THREADS) {
       f3 q = ld3(gin, i, N) - ld3(v, i, N);
@@ -273,16 +304,25 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
     for (int k = 0; k < kcap && status == 0; k++) {
       // v = K D^-1 p ;  alpha = rho / (rhat . v)
-      adjoint_operator<THREADS>(S, C, p, true, v, rhat, d1, d2);
+      PH(2)
+      adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
       double rv = block_sum<THREADS>((double) d1, red);
+      PH(1)
       if (!(fabs(rv) > 1e-300)) { status = 2; break; }
       const float alpha = (float) (rho / rv);
       // s = r - alpha v  (in place)
+      // (vector updates: VB vertices of a thread per round, all loads issued before the first store)
       part = 0.f;
-      for (int i = tid; i < N; i += THREADS) {
-        f3 s = ld3(r, i, N) - ld3(v, i, N) * alpha;
-        st3(r, i, N, s);
-        part += dot(s, s);
+      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+        f3 rq[VB], vq[VB];
+#pragma unroll
+        for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); vq[j] = ld3(v, ic, N); }
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int i = i0 + j * THREADS;
+          f3 s = rq[j] - vq[j] * alpha;
+          if (i < N) { st3(r, i, N, s); part += dot(s, s); }
+        }
       }
       double ss = block_sum<THREADS>((double) part, red);
       iters++;
@@ -291,21 +331,34 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
         rr = ss; status = 1; break;
       }
       // t = K D^-1 s ;  omega = (t . s) / (t . t)
-      adjoint_operator<THREADS>(S, C, r, true, t, r, d1, d2);
+      PH(2)
+      adjoint_operator<THREADS, WIN>(S, C, r, true, t, r, d1, d2);
       double ts = (double) d1, tt = (double) d2;
       block_sum2<THREADS>(ts, tt, red);
+      PH(1)
       if (!(tt > 1e-300)) { status = 2; break; }
       const float omega = (float) (ts / tt);
       // u += alpha D^-1 p + omega D^-1 s ;  r = s - omega t ;  rho_new = rhat . r
       float pa = 0.f, pb = 0.f;
-      for (int i = tid; i < N; i += THREADS) {
-        const float di = S.dinv[i];
-        f3 s = ld3(r, i, N);
-        st3(u, i, N, ld3(u, i, N) + (ld3(p, i, N) * alpha + s * omega) * di);
-        f3 rn = s - ld3(t, i, N) * omega;
-        st3(r, i, N, rn);
-        pa += dot(rn, ld3(rhat, i, N));
-        pb += dot(rn, rn);
+      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB];
+        float dq[VB];
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int ic = min(i0 + j * THREADS, N - 1);
+          dq[j] = S.dinv[ic]; sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); pq[j] = ld3(p, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
+        }
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int i = i0 + j * THREADS;
+          f3 rn = sq[j] - tq[j] * omega;
+          if (i < N) {
+            st3(u, i, N, uq[j] + (pq[j] * alpha + sq[j] * omega) * dq[j]);
+            st3(r, i, N, rn);
+            pa += dot(rn, hq[j]);
+            pb += dot(rn, rn);
+          }
+        }
       }
       double rho_new = (double) pa;
       rr = (double) pb;
@@ -317,12 +370,22 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));
       rho = rho_new;
       // p = r + beta (p - omega v)
-      for (int i = tid; i < N; i += THREADS) st3(p, i, N, ld3(r, i, N) + (ld3(p, i, N) - ld3(v, i, N) * omega) * beta);
+      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+        f3 rq[VB], pq[VB], vq[VB];
+#pragma unroll
+        for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); pq[j] = ld3(p, ic, N); vq[j] = ld3(v, ic, N); }
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int i = i0 + j * THREADS;
+          if (i < N) st3(p, i, N, rq[j] + (pq[j] - vq[j] * omega) * beta);
+        }
+      }
       __syncthreads();
     }
     udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual
   }
   __syncthreads();
+  PH(2)
   // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650) ----
   float dmu_part[kMaxPrims];
 #pragma unroll
@@ -417,19 +480,22 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     s.used_direct = used_direct; s.last_udiff = (float) udiff;
     A.stats[b] = s;
   }
+  PH(3)
+  PH_PRINT
 }
 
 static int pick_threads_bwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
 
 template <int THREADS>
 static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
-  const size_t lds = S.win_ok ? (size_t) S.win_lds_bytes : 0;
+  if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
+  const size_t lds = (size_t) S.win_lds_bytes;
   static size_t configured = 0;
   if (lds > configured) {
-    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     configured = lds;
   }
-  hipLaunchKernelGGL(k_adjoint_step<THREADS>, dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_adjoint_step<THREADS, true>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {

@@ -47,12 +47,22 @@ struct Polar {
   f3 t0, t1;
   float i00, i01, i11, trS;   // S^-1 (symmetric) and trace(S)
 };
+// The per-element passes are bound by the fp32 VALU rate (not by memory): the 1-ulp hardware square root /
+// reciprocal (v_sqrt_f32, v_rcp_f32, v_rsq_f32) replace the ~12-instruction IEEE expansions of sqrtf and '/'.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ f3 normalized_fast(f3 a) {
+  float n2 = dot(a, a);
+  return n2 > 0.f ? a * fast_rsqrt(n2) : a;
+}
+
 __device__ __forceinline__ Polar polar3x2(f3 f0, f3 f1) {
   float a = dot(f0, f0), b = dot(f0, f1), c = dot(f1, f1);
   float det = fmaxf(a * c - b * b, 1e-30f);
-  float s = sqrtf(det);
-  float t = sqrtf(a + c + 2.f * s);
-  float inv = 1.0f / (t * s);
+  float s = fast_sqrt(det);
+  float t = fast_sqrt(a + c + 2.f * s);
+  float inv = fast_rcp(t * s);
   Polar P;
   P.i00 = (c + s) * inv; P.i01 = -b * inv; P.i11 = (a + s) * inv; P.trS = t;
   P.t0 = f0 * P.i00 + f1 * P.i01;

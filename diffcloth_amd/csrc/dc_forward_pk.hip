@@ -293,17 +293,28 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       }
     }
     // ---- update + convergence (Simulation.cpp:1268, 1310-1373) ----
+    // all loads first (clamped index, no divergence), then the arithmetic, then the stores: one memory round trip
+    // instead of VPT dependent ones; the new iterate stays in registers for the best-iterate copy below
     part = 0.f;
+    float vv[VPT][3];
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      const int i = min(tid + k * THREADS, N - 1);
+      const float sq = S.sq_dinv[i];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float xs = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tid];
+        vv[k][c] = vnow[c * N + i];
+        ap[k][c] = xs * sq;                 // delta v (A p is dead here)
+      }
+    }
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
       const int i = tid + k * THREADS;
-      if (i < N) {
-        float xs[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) xs[c] = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tid];
-        f3 d = mk(xs[0], xs[1], xs[2]) * S.sq_dinv[i];
-        st3(vnow, i, N, ld3(vnow, i, N) + d);
-        part += dot(d, d);
+      for (int c = 0; c < 3; c++) {
+        vv[k][c] += ap[k][c];
+        if (i < N) { vnow[c * N + i] = vv[k][c]; part = fmaf(ap[k][c], ap[k][c], part); }
       }
     }
     xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
@@ -314,8 +325,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       since_progress = 0;     // any new minimum counts: slow monotone convergence must never look like a stall
       min_xdiff = xdiff;
       improved = true;
-      if (!converged)
-        for (int i = tid; i < N; i += THREADS) st3(vbest, i, N, ld3(vnow, i, N));
+      if (!converged) {
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int i = tid + k * THREADS;
+          if (i < N) { vbest[i] = vv[k][0]; vbest[N + i] = vv[k][1]; vbest[2 * N + i] = vv[k][2]; }
+        }
+      }
     }
     if (converged) break;
     if (++since_progress >= A.stall_window) { stalled = true; break; }   // fp32 floor, see dc_forward.hip

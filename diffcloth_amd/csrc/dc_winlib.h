@@ -40,35 +40,64 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
       L.a2xy[j] = make_float2(in2[i], in2[N + i]); L.a2z[j] = in2[2 * N + i];
     }
     __syncthreads();
-    for (int t = tid; t < nt; t += THREADS) {
-      const int4 r = S.wtri_rec[toff + t];
-      const float4 D = S.wtri_D[toff + t];
-      const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y;
-      f3 r0, r1;
-      tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
-             ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D, __int_as_float(r.z), r0, r1);
-      stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1);
+    // per-element phase: EB elements of a thread at a time, their records loaded up front (clamped index, no
+    // divergence) so that EB L2 round trips and EB gather -> math chains overlap instead of queueing up
+    constexpr int EB = 4;
+    for (int t0 = tid; t0 < nt + tid; t0 += EB * THREADS) {
+      int4 r[EB];
+      float4 D[EB];
+#pragma unroll
+      for (int j = 0; j < EB; j++) {
+        const int t = min(t0 + j * THREADS, nt - 1);
+        r[j] = S.wtri_rec[toff + t]; D[j] = S.wtri_D[toff + t];
+      }
+#pragma unroll
+      for (int j = 0; j < EB; j++) {
+        const int t = t0 + j * THREADS;
+        const int j0 = r[j].x & 0xffff, j1 = (int) ((unsigned) r[j].x >> 16), j2 = r[j].y;
+        f3 r0, r1;
+        tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
+               ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D[j], __int_as_float(r[j].z), r0, r1);
+        if (t < nt) { stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1); }
+      }
     }
-    for (int e = tid; e < nb; e += THREADS) {
-      const int4 r = S.wbend_rec[boff + e];
-      const float4 wq = S.wbend_w[boff + e];
-      const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y & 0xffff, j3 = (int) ((unsigned) r.y >> 16);
-      f3 res;
-      bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
-              ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq,
-              __int_as_float(r.z), __int_as_float(r.w), res);
-      stw(L.erxy, L.erz, 2 * nt + e, res);
+    for (int e0 = tid; e0 < nb + tid; e0 += EB * THREADS) {
+      int4 r[EB];
+      float4 wq[EB];
+#pragma unroll
+      for (int j = 0; j < EB; j++) {
+        const int e = min(e0 + j * THREADS, nb - 1);
+        r[j] = S.wbend_rec[boff + e]; wq[j] = S.wbend_w[boff + e];
+      }
+#pragma unroll
+      for (int j = 0; j < EB; j++) {
+        const int e = e0 + j * THREADS;
+        const int j0 = r[j].x & 0xffff, j1 = (int) ((unsigned) r[j].x >> 16), j2 = r[j].y & 0xffff, j3 = (int) ((unsigned) r[j].y >> 16);
+        f3 res;
+        bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
+                ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq[j],
+                __int_as_float(r[j].z), __int_as_float(r[j].w), res);
+        if (e < nb) stw(L.erxy, L.erz, 2 * nt + e, res);
+      }
     }
     __syncthreads();
+    // per-vertex phase: the next batch of (vector, coefficient) packets is in flight while this one is summed
     for (int i = v0 + tid; i < v1; i += THREADS) {
       const int ch = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
       const int np = S.winc_n[ch];
       const int4 *row = S.winc + S.winc_ptr[ch] + lane;
       float sx = 0.f, sy = 0.f, sz = 0.f;
+      int4 nxt[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) nxt[j] = row[j * 64];
       for (int s0 = 0; s0 < np; s0 += 4) {
         int4 e[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = row[(s0 + j) * 64];
+        for (int j = 0; j < 4; j++) e[j] = nxt[j];
+        if (s0 + 4 < np) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) nxt[j] = row[(s0 + 4 + j) * 64];
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const float2 qa = L.erxy[e[j].x], qb = L.erxy[e[j].z];
@@ -101,7 +130,7 @@ struct FwdBendOp {  // TriangleBending::project (TriangleBending.cpp:138-151)
     ev = ev + ((x2 - x0) + (v2 - v0) * h) * w.z;
     ev = ev + ((x3 - x0) + (v3 - v0) * h) * w.w;
     f3 p = mk(0, 0, 0);
-    if (n > 1e-6f) p = normalized(ev) * n;
+    if (n > 1e-6f) p = normalized_fast(ev) * n;
     res = (p - ev) * (h * w2);
   }
 };
@@ -114,7 +143,7 @@ struct AdjTriOp {   // Triangle::projectToManifoldBackward (Triangle.cpp:354-451
     Polar P = polar3x2(e0 * D.x + e1 * D.z, e0 * D.y + e1 * D.w);
     f3 d0 = q1 - q0, d1 = q2 - q0;
     f3 y0 = d0 * D.x + d1 * D.z, y1 = d0 * D.y + d1 * D.w;
-    const float c = (dot(P.t1, y0) - dot(P.t0, y1)) / P.trS;
+    const float c = (dot(P.t1, y0) - dot(P.t0, y1)) * fast_rcp(P.trS);
     f3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
     z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
     z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
@@ -129,9 +158,9 @@ struct AdjBendOp {  // TriangleBending::backwardGradient (TriangleBending.cpp:15
     res = ey;
     if (n > 1e-6f) {
       f3 ev = (x1 - x0) * w.y + (x2 - x0) * w.z + (x3 - x0) * w.w;
-      const float en = sqrtf(dot(ev, ev));
-      f3 eh = ev * (1.0f / en);
-      res = ey - (ey - eh * dot(eh, ey)) * (n / en);
+      const float ien = fast_rsqrt(dot(ev, ev));
+      f3 eh = ev * ien;
+      res = ey - (ey - eh * dot(eh, ey)) * (n * ien);
     }
     res = res * (h2 * w2);
   }
