@@ -6,22 +6,22 @@ namespace dc {
 // ---------------------------------------------------------------------------------------------------
 // layout conversion at the boundary: host float64 xyz-interleaved  <->  device float32 planar
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_f64i_to_f32p(const double *__restrict__ src, float *__restrict__ dst, int n, long total) {
+__global__ void k_f64i_to_f32p(const double *__restrict__ src, float *__restrict__ dst, int n, long total, const int *__restrict__ user_of) {
   long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   long b = t / n;
   int i = (int) (t - b * n);
-  const double *s = src + (b * n + i) * 3;
+  const double *s = src + (b * n + (user_of ? user_of[i] : i)) * 3;     // device vertex i <- caller's vertex user_of[i]
   float *d = dst + b * 3 * n;
   d[i] = (float) s[0]; d[n + i] = (float) s[1]; d[2 * n + i] = (float) s[2];
 }
-__global__ void k_f32p_to_f64i(const float *__restrict__ src, double *__restrict__ dst, int n, long total) {
+__global__ void k_f32p_to_f64i(const float *__restrict__ src, double *__restrict__ dst, int n, long total, const int *__restrict__ user_of) {
   long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   long b = t / n;
   int i = (int) (t - b * n);
   const float *s = src + b * 3 * n;
-  double *d = dst + (b * n + i) * 3;
+  double *d = dst + (b * n + (user_of ? user_of[i] : i)) * 3;
   d[0] = s[i]; d[1] = s[n + i]; d[2] = s[2 * n + i];
 }
 __global__ void k_seed_gradient(const float *__restrict__ x, const float *__restrict__ target, float *__restrict__ gx,
@@ -33,15 +33,15 @@ __global__ void k_seed_gradient(const float *__restrict__ x, const float *__rest
   gv[t] = 0.f;
 }
 
-void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, hipStream_t st) {
+void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, const int *user_of, hipStream_t st) {
   long total = (long) B * n;
   if (total == 0) return;
-  hipLaunchKernelGGL(k_f64i_to_f32p, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total);
+  hipLaunchKernelGGL(k_f64i_to_f32p, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total, user_of);
 }
-void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, hipStream_t st) {
+void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, const int *user_of, hipStream_t st) {
   long total = (long) B * n;
   if (total == 0) return;
-  hipLaunchKernelGGL(k_f32p_to_f64i, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total);
+  hipLaunchKernelGGL(k_f32p_to_f64i, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total, user_of);
 }
 void launch_seed_gradient(const float *x, const float *target, float *gx, float *gv, int B, int N, float scale, hipStream_t st) {
   long total = (long) B * 3 * N;

@@ -47,6 +47,9 @@ struct DevSystem {
   const int *pk_ptr, *pk_n;
   const float *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
+  // vertex renumbering (bandwidth reduction, dc_engine.hip): device index <-> caller's index; null = identity
+  const int *user_of;           // [N] device -> caller
+  const int *dev_of;            // [N] caller -> device
   // element windows (dc_windows.h / dc_winlib.h): the per-constraint passes run window by window inside LDS
   const int4 *win;              // [2 * nwin]: {v0, v1, lo, vs}, {tri_off, ntri, bend_off, nbend}
   const int4 *wtri_rec;         // per window-triangle: j0 | j1 << 16, j2, bits(w^2), triangle id
@@ -137,8 +140,8 @@ bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &
 bool launch_pd_step_resident(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st, int variant);
 void launch_self_detect(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);
-void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, hipStream_t st);
-void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, hipStream_t st);
+void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, const int *user_of, hipStream_t st);
+void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, const int *user_of, hipStream_t st);
 void launch_seed_gradient(const float *x, const float *target, float *gx, float *gv, int B, int N, float scale, hipStream_t st);
 
 }  // namespace dc

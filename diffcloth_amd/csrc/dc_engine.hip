@@ -23,6 +23,10 @@ struct dc_ctx {
   std::vector<int> group_of_prim;
   int ngroups = 0;
   bool mesh_set = false, built = false;
+  // vertex renumbering on the device (empty = identity): user_of[device index] = caller's index, dev_of = inverse
+  std::vector<int> user_of, dev_of;
+  std::vector<int> att_user;        // attachment vertices in the caller's numbering
+  const int *d_user_of = nullptr;   // device copy of user_of (null = identity)
 
   DevSystem S;
   std::vector<void *> table_allocs;
@@ -98,12 +102,12 @@ int pd_cap(const dc_ctx *c) {
 int h2d_planar(dc_ctx *c, const double *src, float *dst, int n_per_rollout, int which_stage) {
   size_t elems = (size_t) c->B * 3 * n_per_rollout;
   HIPCHK(c, hipMemcpyAsync(c->stage[which_stage], src, elems * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  launch_f64i_to_f32p(c->stage[which_stage], dst, c->B, n_per_rollout, c->stream);
+  launch_f64i_to_f32p(c->stage[which_stage], dst, c->B, n_per_rollout, n_per_rollout == c->host.N ? c->d_user_of : nullptr, c->stream);
   return DC_OK;
 }
 int d2h_planar(dc_ctx *c, const float *src, double *dst, int n_per_rollout, int which_stage) {
   size_t elems = (size_t) c->B * 3 * n_per_rollout;
-  launch_f32p_to_f64i(src, c->stage[which_stage], c->B, n_per_rollout, c->stream);
+  launch_f32p_to_f64i(src, c->stage[which_stage], c->B, n_per_rollout, n_per_rollout == c->host.N ? c->d_user_of : nullptr, c->stream);
   HIPCHK(c, hipMemcpyAsync(dst, c->stage[which_stage], elems * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return DC_OK;
 }
@@ -226,14 +230,33 @@ const char *dc_last_error(const dc_ctx *c) { return c ? c->err.c_str() : "null c
 int dc_set_mesh(dc_ctx *c, int n, const double *pos, int t, const int *tris) {
   if (!c) return DC_ERR_INVALID;
   c->built = false;
+  c->user_of.clear(); c->dev_of.clear();
   if (!c->host.set_mesh(n, pos, t, tris)) { c->mesh_set = false; return fail(c, DC_ERR_TOPOLOGY, c->host.error); }
+  // Renumber the vertices on the device when the caller's numbering couples far-apart indices (typical of
+  // modelling-tool exports): the packet-ELL matrix (|i - j| <= 511 over two rings) and the element windows need
+  // locality. DC_RENUMBER=0 / 1 forces it off / on (development switch).
+  const char *env = getenv("DC_RENUMBER");
+  const bool want = env ? env[0] == '1' : 2 * mesh_bandwidth(t, tris) > 511;
+  if (want) {
+    std::vector<int> order = rcm_order(n, t, tris);
+    std::vector<int> inv(n);
+    for (int k = 0; k < n; k++) inv[order[k]] = k;
+    std::vector<int> tri2(3 * (size_t) t);
+    for (size_t k = 0; k < tri2.size(); k++) tri2[k] = inv[tris[k]];
+    if (2 * mesh_bandwidth(t, tri2.data()) < 2 * mesh_bandwidth(t, tris) || env) {
+      std::vector<double> pos2(3 * (size_t) n);
+      for (int k = 0; k < n; k++) for (int d = 0; d < 3; d++) pos2[3 * (size_t) k + d] = pos[3 * (size_t) order[k] + d];
+      if (!c->host.set_mesh(n, pos2.data(), t, tri2.data())) { c->mesh_set = false; return fail(c, DC_ERR_TOPOLOGY, c->host.error); }
+      c->user_of = order; c->dev_of = inv;
+    }
+  }
   c->mesh_set = true;
   return DC_OK;
 }
 
 int dc_set_attachments(dc_ctx *c, int count, const int *vertex) {
   if (!c || count < 0 || (count > 0 && !vertex)) return fail(c, DC_ERR_INVALID, "dc_set_attachments: bad arguments");
-  c->host.att_vertex.assign(vertex, vertex + count);
+  c->att_user.assign(vertex, vertex + count);
   c->built = false;
   return DC_OK;
 }
@@ -268,6 +291,11 @@ int dc_build(dc_ctx *c) {
   if (!c->mesh_set) return fail(c, DC_ERR_STATE, "dc_build: dc_set_mesh has not been called");
   const dc_params &p = c->params;
   HostSystem &H = c->host;
+  H.att_vertex = c->att_user;
+  for (int &a : H.att_vertex) {
+    if (a < 0 || a >= H.N) return fail(c, DC_ERR_INVALID, "dc_build: attachment vertex out of range");
+    if (!c->dev_of.empty()) a = c->dev_of[a];
+  }
   if (!H.build_numerics(p.time_step, p.density, p.k_stretch, p.k_bend, p.k_att)) return fail(c, DC_ERR_TOPOLOGY, H.error);
   if (c->host_only) { c->built = true; return DC_OK; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -277,6 +305,13 @@ int dc_build(dc_ctx *c) {
   std::memset(&S, 0, sizeof(S));
   const int N = H.N, T = H.T, E = H.E, Af = (int) H.att_vertex.size();
   S.N = N; S.T = T; S.E = E; S.Af = Af; S.NC = 3 * T + 4 * E;
+  S.user_of = nullptr; S.dev_of = nullptr; c->d_user_of = nullptr;
+  if (!c->user_of.empty()) {
+    int rcp;
+    if ((rcp = upload<int>(c, &S.user_of, c->user_of))) return rcp;
+    if ((rcp = upload<int>(c, &S.dev_of, c->dev_of))) return rcp;
+    c->d_user_of = S.user_of;
+  }
   // planar index tables
   std::vector<int> triv(3 * (size_t) T), bendv(4 * (size_t) E);
   for (int t = 0; t < T; t++) for (int k = 0; k < 3; k++) triv[(size_t) k * T + t] = H.tri[3 * t + k];
@@ -485,17 +520,35 @@ int dc_get_counts(const dc_ctx *c, int *out6) {
 }
 int dc_get_system_matrix(const dc_ctx *c, int *row_ptr, int *col, double *val) {
   if (!c || !c->built) return DC_ERR_STATE;
-  std::memcpy(row_ptr, c->host.P_ptr.data(), sizeof(int) * c->host.P_ptr.size());
-  std::memcpy(col, c->host.P_col.data(), sizeof(int) * c->host.P_col.size());
-  std::memcpy(val, c->host.P_val.data(), sizeof(double) * c->host.P_val.size());
+  const HostSystem &H = c->host;
+  if (c->user_of.empty()) {
+    std::memcpy(row_ptr, H.P_ptr.data(), sizeof(int) * H.P_ptr.size());
+    std::memcpy(col, H.P_col.data(), sizeof(int) * H.P_col.size());
+    std::memcpy(val, H.P_val.data(), sizeof(double) * H.P_val.size());
+    return DC_OK;
+  }
+  // back to the caller's numbering: row u = device row dev_of[u], columns relabelled and sorted
+  row_ptr[0] = 0;
+  std::vector<std::pair<int, double>> row;
+  for (int u = 0; u < H.N; u++) {
+    const int i = c->dev_of[u];
+    row.clear();
+    for (int k = H.P_ptr[i]; k < H.P_ptr[i + 1]; k++) row.push_back({c->user_of[H.P_col[k]], H.P_val[k]});
+    std::sort(row.begin(), row.end());
+    for (size_t k = 0; k < row.size(); k++) { col[row_ptr[u] + k] = row[k].first; val[row_ptr[u] + k] = row[k].second; }
+    row_ptr[u + 1] = row_ptr[u] + (int) row.size();
+  }
   return DC_OK;
 }
 int dc_get_vertex_data(const dc_ctx *c, double *mass, double *area, double *radii) {
   if (!c || !c->built) return DC_ERR_STATE;
   const int N = c->host.N;
-  if (mass) std::memcpy(mass, c->host.mass.data(), sizeof(double) * N);
-  if (area) std::memcpy(area, c->host.area.data(), sizeof(double) * N);
-  if (radii) std::memcpy(radii, c->host.radii.data(), sizeof(double) * N);
+  for (int i = 0; i < N; i++) {
+    const int u = c->user_of.empty() ? i : c->user_of[i];
+    if (mass) mass[u] = c->host.mass[i];
+    if (area) area[u] = c->host.area[i];
+    if (radii) radii[u] = c->host.radii[i];
+  }
   return DC_OK;
 }
 
@@ -659,8 +712,14 @@ int dc_get_contacts(dc_ctx *c, int slot, int *prim_group, double *normal) {
   if (normal && (rc = d2h_planar(c, c->NRM + se * slot, normal, c->host.N, 0))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (prim_group) {
-    HIPCHK(c, hipMemcpy(prim_group, c->PRIM + sp * slot, sp * sizeof(int), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < sp; k++) if (prim_group[k] >= 0) prim_group[k] = c->prims[prim_group[k]].group;
+    std::vector<int> dev(sp);
+    HIPCHK(c, hipMemcpy(dev.data(), c->PRIM + sp * slot, sp * sizeof(int), hipMemcpyDeviceToHost));
+    const int N = c->host.N;
+    for (int b = 0; b < c->B; b++)
+      for (int i = 0; i < N; i++) {
+        const int g = dev[(size_t) b * N + i];
+        prim_group[(size_t) b * N + (c->user_of.empty() ? i : c->user_of[i])] = g >= 0 ? c->prims[g].group : g;
+      }
   }
   return DC_OK;
 }
@@ -683,7 +742,10 @@ int dc_get_self_contacts(dc_ctx *c, int slot, int rollout, int cap, int *count, 
   HIPCHK(c, hipMemcpy(pr.data(), c->SC_pair + base, sizeof(int2) * n, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(nr.data(), c->SC_nrm + base, sizeof(float4) * n, hipMemcpyDeviceToHost));
   for (int k = 0; k < n; k++) {
-    if (pairs) { pairs[2 * k] = pr[k].x; pairs[2 * k + 1] = pr[k].y; }
+    if (pairs) {
+      pairs[2 * k] = c->user_of.empty() ? pr[k].x : c->user_of[pr[k].x];
+      pairs[2 * k + 1] = c->user_of.empty() ? pr[k].y : c->user_of[pr[k].y];
+    }
     if (normal) { normal[3 * k] = nr[k].x; normal[3 * k + 1] = nr[k].y; normal[3 * k + 2] = nr[k].z; }
     if (layer) { int l = 0; while (l + 1 < nl && k >= meta[2 + l + 1]) l++; layer[k] = l; }
   }
@@ -748,7 +810,8 @@ int dc_seed_gradient(dc_ctx *c, int slot, const double *target, double scale_x) 
   const int N = c->host.N;
   std::vector<float> t(3 * (size_t) N);
   for (int i = 0; i < N; i++)
-    for (int d = 0; d < 3; d++) t[(size_t) d * N + i] = (float) (target ? target[3 * i + d] : c->host.rest[3 * i + d]);
+    for (int d = 0; d < 3; d++)
+      t[(size_t) d * N + i] = (float) (target ? target[3 * (size_t) (c->user_of.empty() ? i : c->user_of[i]) + d] : c->host.rest[3 * i + d]);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->target, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
   launch_seed_gradient(c->X + slot_elems(c) * slot, c->target, c->GX, c->GV, c->B, N, (float) scale_x, c->stream);

@@ -59,7 +59,7 @@ __device__ __forceinline__ bool connected(const DevSystem &S, int i, int j) {   
 // Simulation::contactSorting (Simulation.cpp:422-624), serial. Contacts are given sorted by (p1, p2).
 // tmp layout (ints): ids[2C] | adj_ptr[2C+1] | adj_other[2C] | adj_contact[2C] | deg[2C] | frontier[2C] | newf[2C] |
 //                    involved[2C] | layer[C] | alive[C]
-__device__ void contact_sorting_serial(int C, const int2 *pair, const int *rec_prim, int *tmp, int cap, int *meta, int *layer_out) {
+__device__ void contact_sorting_serial(int C, const int2 *pair, const int *rec_prim, const int *dev_of, int *tmp, int cap, int *meta, int *layer_out) {
   int *ids = tmp, *adj_ptr = ids + 2 * cap, *adj_other = adj_ptr + 2 * cap + 1, *adj_contact = adj_other + 2 * cap;
   int *deg = adj_contact + 2 * cap, *frontier = deg + 2 * cap, *newf = frontier + 2 * cap, *involved = newf + 2 * cap;
   int *layer = involved + 2 * cap, *alive = layer + cap;
@@ -90,7 +90,7 @@ __device__ void contact_sorting_serial(int C, const int2 *pair, const int *rec_p
   for (int m = 0; m < M; m++) { frontier[m] = 0; newf[m] = 0; involved[m] = 0; }
   int processed = 0, maxLayer = 0, nfront = 0;
   // primitive contacts go into the first layer: they seed the frontier when they also have self contacts
-  for (int m = 0; m < M; m++) if (rec_prim[ids[m]] >= 0 && deg[m] > 0) { frontier[m] = 1; nfront++; }
+  for (int m = 0; m < M; m++) if (rec_prim[dev_of ? dev_of[ids[m]] : ids[m]] >= 0 && deg[m] > 0) { frontier[m] = 1; nfront++; }
   auto first_alive = [&](int m) { for (int o = adj_ptr[m]; o < adj_ptr[m + 1]; o++) if (alive[adj_contact[o]]) return o; return -1; };
   // lonely pairs (O-O) -> layer 0
   for (int m = 0; m < M; m++) {
@@ -177,7 +177,11 @@ __global__ __launch_bounds__(THREADS) void k_self_detect(const DevSystem *__rest
     return;
   }
   // ---- 1. bounding box / longest axis / cells (Simulation.cpp:283-300) ----
-  f3 p0 = ld3(xn, 0, N) + v_guess(0) * h;        // particles[0].pos at this point of the reference == s_n[0]
+  // ids: the contact list, its order and the layering follow the CALLER's vertex numbering (the reference's
+  // std::map / id1 < id2 conventions), whatever the device numbering is
+  const int *user_of = S.user_of, *dev_of = S.dev_of;
+  const int i_first = dev_of ? dev_of[0] : 0;
+  f3 p0 = ld3(xn, i_first, N) + v_guess(i_first) * h;        // particles[0].pos at this point of the reference == s_n[0]
   float mx[3] = {p0.x, p0.y, p0.z}, mn[3] = {p0.x, p0.y, p0.z};
   float vmax2 = 0.f;
   for (int i = tid; i < N; i += THREADS) {
@@ -242,9 +246,10 @@ __global__ __launch_bounds__(THREADS) void k_self_detect(const DevSystem *__rest
       // the reference calls isSelfCollision(particles[p1], particles[p2]) with p1 from the lower cell; the test is
       // symmetric and the normal is oriented from id2 to id1, so the call order does not matter
       f3 nrm;
-      if (!self_collision(ri + S.radii[j], xi, ld3(sx, s2, N), vi, v_guess(j), h, i, j, nrm)) continue;
+      const int ui = user_of ? user_of[i] : i, uj = user_of ? user_of[j] : j;
+      if (!self_collision(ri + S.radii[j], xi, ld3(sx, s2, N), vi, v_guess(j), h, ui, uj, nrm)) continue;
       int k = atomicAdd(&s_count, 1);
-      if (k < cap) { raw[k] = make_int2(min(i, j), max(i, j)); rawn[k] = make_float4(nrm.x, nrm.y, nrm.z, 0.f); }
+      if (k < cap) { raw[k] = make_int2(min(ui, uj), max(ui, uj)); rawn[k] = make_float4(nrm.x, nrm.y, nrm.z, 0.f); }
     }
   }
   __syncthreads();
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(THREADS) void k_self_detect(const DevSystem *__rest
   __syncthreads();
   // ---- 5. layering (serial, thread 0) then a stable partition by layer ----
   int *layer_of = tmp + 19 * cap;
-  if (tid == 0) contact_sorting_serial(C, spair, A.rec_prim + (size_t) b * N, tmp, cap, meta, layer_of);
+  if (tid == 0) contact_sorting_serial(C, spair, A.rec_prim + (size_t) b * N, dev_of, tmp, cap, meta, layer_of);
   __syncthreads();
   // position inside the layer = number of earlier (sorted) contacts of the same layer
   for (int k = tid; k < C; k += THREADS) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(THREADS) void k_self_detect(const DevSystem *__rest
     int pos = 0;
     for (int q = 0; q < k; q++) pos += (layer_of[q] == l) ? 1 : 0;
     const int dst = meta[2 + l] + pos;
-    opair[dst] = spair[k];
+    opair[dst] = dev_of ? make_int2(dev_of[spair[k].x], dev_of[spair[k].y]) : spair[k];   // stored in device numbering
     rawn[dst] = onrm[k];                         // raw buffer reused as the destination of the normals
   }
   __syncthreads();

@@ -173,4 +173,64 @@ bool HostSystem::build_numerics(double h, double density, double k_stretch, doub
   return true;
 }
 
+int mesh_bandwidth(int t, const int *tris) {
+  int bw = 0;
+  for (int k = 0; k < t; k++)
+    for (int a = 0; a < 3; a++) bw = std::max(bw, std::abs(tris[3 * k + a] - tris[3 * k + (a + 1) % 3]));
+  return bw;
+}
+
+std::vector<int> rcm_order(int n, int t, const int *tris) {
+  std::vector<std::vector<int>> adj(n);
+  for (int k = 0; k < t; k++)
+    for (int a = 0; a < 3; a++) {
+      const int u = tris[3 * k + a], v = tris[3 * k + (a + 1) % 3];
+      adj[u].push_back(v); adj[v].push_back(u);
+    }
+  for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  auto by_degree = [&](int a, int b) { return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b; };
+  for (auto &a : adj) std::sort(a.begin(), a.end(), by_degree);
+  std::vector<int> order, level(n, -1);
+  std::vector<char> done(n, 0);
+  order.reserve(n);
+  // breadth-first levels from `root` over the not-yet-ordered vertices; returns the last vertex reached
+  auto bfs_far = [&](int root, int &depth) {
+    std::vector<int> q{root};
+    std::vector<int> seen{root};
+    level[root] = 0;
+    size_t head = 0;
+    int last = root;
+    while (head < q.size()) {
+      const int u = q[head++];
+      last = u;
+      for (int v : adj[u]) if (!done[v] && level[v] < 0) { level[v] = level[u] + 1; q.push_back(v); seen.push_back(v); }
+    }
+    depth = level[last];
+    // among the deepest level prefer the smallest degree (George-Liu pseudo-peripheral heuristic)
+    for (int v : seen) if (level[v] == depth && by_degree(v, last)) last = v;
+    for (int v : seen) level[v] = -1;
+    return last;
+  };
+  for (int seed = 0; seed < n; seed++) {
+    if (done[seed]) continue;
+    int root = seed, depth = -1;
+    for (int it = 0; it < 8; it++) {           // walk to a pseudo-peripheral vertex of this component
+      int d;
+      const int far = bfs_far(root, d);
+      if (d <= depth) break;
+      depth = d; root = far;
+    }
+    std::vector<int> q{root};
+    done[root] = 1;
+    size_t head = 0;
+    while (head < q.size()) {
+      const int u = q[head++];
+      order.push_back(u);
+      for (int v : adj[u]) if (!done[v]) { done[v] = 1; q.push_back(v); }
+    }
+  }
+  std::reverse(order.begin(), order.end());
+  return order;
+}
+
 }  // namespace dc

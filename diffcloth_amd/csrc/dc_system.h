@@ -55,4 +55,11 @@ struct HostSystem {
   int rows() const { return 6 * T + 3 * E + 3 * (int) att_vertex.size(); }
 };
 
+// Reverse Cuthill-McKee ordering of the vertex graph of a triangle mesh: order[new] = old. Used to renumber the
+// vertices on the device when the caller's numbering has a large bandwidth (the packet-ELL matrix format and the
+// element windows need |i - j| of coupled vertices to be small).
+std::vector<int> rcm_order(int n, int t, const int *tris);
+// max |i - j| over the edges of the mesh
+int mesh_bandwidth(int t, const int *tris);
+
 }  // namespace dc

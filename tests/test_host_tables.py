@@ -34,8 +34,12 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.dc_params) == 8 * 5 + 24 + 16 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 
 
+@pytest.mark.parametrize("renumber", [False, True])
 @pytest.mark.parametrize("shape", [(6, 5), (13, 13), (4, 9)])
-def test_system_tables_match_oracle(shape):
+def test_system_tables_match_oracle(shape, renumber, monkeypatch):
+    """`renumber`: the engine's internal bandwidth-reducing vertex renumbering (reverse Cuthill-McKee) must be
+    invisible at the C-ABI: matrices and per-vertex tables come back in the caller's numbering."""
+    monkeypatch.setenv("DC_RENUMBER", "1" if renumber else "0")
     nx, ny = shape
     V, F = meshes.grid_cloth(nx, ny, 4.5, 3.5, "DOWN")
     rng = np.random.default_rng(5)
