@@ -14,6 +14,7 @@
 //           cap is reached it falls back to the direct solve, as the reference does with SparseLU (:1589-1594);
 //   mode 1  direct solve (semantics of backwardGradientForceDirectSolver / solveDirect, Simulation.cpp:1431-1440):
 //           block-Jacobi preconditioned BiCGSTAB on K itself, relative residual <= adjoint_rel_tol.
+#define DC_KERNEL_TU
 #include "dc_devlib.h"
 #include "dc_winlib.h"
 

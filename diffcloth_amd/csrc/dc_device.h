@@ -10,6 +10,18 @@ constexpr int kMaxPrims = 8;
 constexpr int kMaxLayers = 1020;   // self-contact layers per step (contactSorting: a chain of L contacts takes L layers)
 constexpr int kMetaStride = 1024;  // ints per (slot, rollout): count, nlayers, layer offsets[nlayers + 1]
 
+// Table pointers of DevSystem carry the GLOBAL address space in device code: the struct itself lives in global memory
+// and is read through a pointer, so the compiler cannot infer the address space of the pointers stored in it and would
+// emit FLAT loads (which also tick the LDS counter and so serialise against every LDS wait) and vector loads for
+// wave-uniform table entries instead of global / scalar loads.
+// (only in the kernel translation units, which define DC_KERNEL_TU before including this header: the host code of
+// dc_engine.hip is parsed in the device pass too and assigns plain pointers)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DC_KERNEL_TU)
+#define DC_G __attribute__((address_space(1)))
+#else
+#define DC_G
+#endif
+
 struct DevPrim {
   int kind, group, rotates, pad;
   float cx, cy, cz, radius;
@@ -20,50 +32,52 @@ struct DevPrim {
 struct DevSystem {
   int N, T, E, Af, NC;          // NC = 3T + 4E constraint corners
   int nprim, ngroups, pad0;
-  const int *tri_v;             // [3][T]
-  const float4 *tri_D;          // [T]  inv_deltaUV (d00,d01,d10,d11)
-  const float *tri_w2;          // [T]  area * k_stretch
-  const int *bend_v;            // [4][E]
-  const float4 *bend_w;         // [E]  cotan weights
-  const float2 *bend_nw;        // [E]  (rest norm n, weight^2)
-  const int *att_vertex;        // [Af]
-  const int *att_of_vertex;     // [N]  fixed-point index or -1
-  const float *mass;            // [N]
-  const float *dinv;            // [N]  1 / P_ii  (block-Jacobi preconditioner; blocks are scalar * I3)
-  const int *P_ptr;             // [N+1]
-  const int *P_col;             // [nnz]
-  const float *P_val;           // [nnz]
-  const int *inc_ptr;           // [N+1] vertex -> constraint corners
-  const int *inc_idx;
+  const int DC_G *tri_v;             // [3][T]
+  const float4 DC_G *tri_D;          // [T]  inv_deltaUV (d00,d01,d10,d11)
+  const float DC_G *tri_w2;          // [T]  area * k_stretch
+  const int DC_G *bend_v;            // [4][E]
+  const float4 DC_G *bend_w;         // [E]  cotan weights
+  const float2 DC_G *bend_nw;        // [E]  (rest norm n, weight^2)
+  const int DC_G *att_vertex;        // [Af]
+  const int DC_G *att_of_vertex;     // [N]  fixed-point index or -1
+  const float DC_G *mass;            // [N]
+  const float DC_G *dinv;            // [N]  1 / P_ii  (block-Jacobi preconditioner; blocks are scalar * I3)
+  const int DC_G *P_ptr;             // [N+1]
+  const int DC_G *P_col;             // [nnz]
+  const float DC_G *P_val;           // [nnz]
+  const int DC_G *inc_ptr;           // [N+1] vertex -> constraint corners
+  const int DC_G *inc_idx;
   // P again, in wave-sliced ELL for the resident PCG: chunk c = rows 64c..64c+63, entry (s, lane) at
   // ell[ell_ptr[c] + 64 s + lane] = (column, float bits of the value); padded entries are (row, 0.0f)
-  const int2 *ell;
-  const int *ell_ptr;           // [ceil(N/64)]
-  const int *ell_w;             // [ceil(N/64)] width of the chunk
+  const int2 DC_G *ell;
+  const int DC_G *ell_ptr;           // [ceil(N/64)]
+  const int DC_G *ell_w;             // [ceil(N/64)] width of the chunk
   // P once more, symmetrically scaled to unit diagonal (D^-1/2 P D^-1/2) and packed for dc_forward_pk.hip: per
   // 64-row chunk pk_n[c] 16-byte packets per row (a multiple of 4), packet (s, lane) at pk[pk_ptr[c] + 64 s + lane] =
   // {v0, v1, v2, d0 | d1 << 10 | d2 << 20}, d = column - row + 512; chunks cover 512 * pk_vpt rows
-  const int4 *pk;
-  const int *pk_ptr, *pk_n;
-  const float *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
+  const int4 DC_G *pk;
+  const int DC_G *pk_ptr;
+  const int DC_G *pk_n;
+  const float DC_G *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
   // vertex renumbering (bandwidth reduction, dc_engine.hip): device index <-> caller's index; null = identity
-  const int *user_of;           // [N] device -> caller
-  const int *dev_of;            // [N] caller -> device
+  const int DC_G *user_of;           // [N] device -> caller
+  const int DC_G *dev_of;            // [N] caller -> device
   // element windows (dc_windows.h / dc_winlib.h): the per-constraint passes run window by window inside LDS
-  const int4 *win;              // [2 * nwin]: {v0, v1, lo, vs}, {tri_off, ntri, bend_off, nbend}
-  const int4 *wtri_rec;         // per window-triangle: j0 | j1 << 16, j2, bits(w^2), triangle id
-  const float4 *wtri_D;
-  const int4 *wbend_rec;        // per window-flap: j0 | j1 << 16, j2 | j3 << 16, bits(rest norm), bits(w^2)
-  const float4 *wbend_w;
-  const int4 *winc;             // vertex -> (result vector, coefficient) pair packets, wave-sliced by 64-vertex chunk
-  const int *winc_ptr, *winc_n;
+  const int4 DC_G *win;              // [2 * nwin]: {v0, v1, lo, vs}, {tri_off, ntri, bend_off, nbend}
+  const int4 DC_G *wtri_rec;         // per window-triangle: j0 | j1 << 16, j2, bits(w^2), triangle id
+  const float4 DC_G *wtri_D;
+  const int4 DC_G *wbend_rec;        // per window-flap: j0 | j1 << 16, j2 | j3 << 16, bits(rest norm), bits(w^2)
+  const float4 DC_G *wbend_w;
+  const int4 DC_G *winc;             // vertex -> (result vector, coefficient) pair packets, wave-sliced by 64-vertex chunk
+  const int DC_G *winc_ptr;
+  const int DC_G *winc_n;
   int nwin, win_vcap, win_nrcap, win_ok;
   int win_lds_bytes, pad2;
   // self-collision (Simulation.cpp:194-220, 225-373): collision radii, connected-pair table (share a triangle)
-  const float *radii;           // [N]
-  const int *conn_ptr;          // [N+1]
-  const int *conn_idx;          // sorted neighbours incl. self
+  const float DC_G *radii;           // [N]
+  const int DC_G *conn_ptr;          // [N+1]
+  const int DC_G *conn_idx;          // sorted neighbours incl. self
   float max_radii;
   int self_cap;                 // capacity of the per-rollout self-contact list
   float h, k_att, gx, gy, gz;

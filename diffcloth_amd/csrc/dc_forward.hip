@@ -12,6 +12,7 @@
 // so the constraint residual p - A x is evaluated per element in fp32 without cancellation against P x_n,
 // and the global solve is a PCG for the *correction*, warm-started for free.
 #include <cstdlib>
+#define DC_KERNEL_TU
 #include "dc_devlib.h"
 
 namespace dc {

@@ -16,6 +16,7 @@
 //     touches global memory except the (L2-resident, batch-shared) packet stream.
 // Reference: Simulation::step (Simulation.cpp:1043-1428), global solve :1267 (SimplicialLLT::solve) replaced by
 // this PCG on the correction system (see dc_forward.hip header).
+#define DC_KERNEL_TU
 #include "dc_devlib.h"
 #include "dc_winlib.h"
 #include <algorithm>

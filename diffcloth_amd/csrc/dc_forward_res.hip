@@ -8,6 +8,7 @@
 //     neighbours' p are gathered from LDS,
 // so a CG iteration touches no HBM at all. Reference: Simulation::step (Simulation.cpp:1043-1428), global solve
 // :1267 (SimplicialLLT::solve) replaced by this PCG on the correction system (see dc_forward.hip header).
+#define DC_KERNEL_TU
 #include "dc_devlib.h"
 
 namespace dc {

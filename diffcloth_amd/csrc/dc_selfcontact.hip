@@ -11,6 +11,7 @@
 //   4. pairs sorted by (id1, id2) -> deterministic, independent of atomic order (the reference's order depends on
 //      OpenMP timing; only the order inside a layer could differ, which does not change r)
 //   5. greedy layering, executed by ONE thread exactly as the reference's std::map / std::set code does
+#define DC_KERNEL_TU
 #include "dc_devlib.h"
 
 namespace dc {
