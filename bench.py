@@ -58,7 +58,7 @@ def rollout_inputs(V, ids):
     return X, MU
 
 
-def cpu_baseline(args, V, F, center, x0, mu, steps):
+def cpu_baseline(args, V, F, center, x0, v0, mu, steps, gscale):
     """Reference algorithm (fp64 oracle port, OpenMP at the reference's sites) on the host cores, one rollout."""
     import orc
     threads = args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 32)
@@ -66,21 +66,22 @@ def cpu_baseline(args, V, F, center, x0, mu, steps):
                    bwd_tol=args.bwd_tol, selfcollision=False, gradient_clipping=True, threads=threads)
     o.add_sphere(center, 2.0, float(mu))
     o.build()
-    x = x0.copy(); v = np.zeros_like(x)
+    x = x0.copy(); v = v0.copy()
     t0 = time.perf_counter()
     recs = []
     for s in range(steps):
         out = o.step(x, v)
         recs.append(out)
         x, v = out["x"], out["v"]
-    gx = x - V.reshape(-1); gv = np.zeros_like(gx)
+    gx = gscale * (x - V.reshape(-1)); gv = np.zeros_like(gx)
     for s in reversed(range(steps)):
-        b = o.step_backward(recs[s]["id"], gx, gv, is_start=(s == 0), direct=False)
+        b = o.step_backward(recs[s]["id"], gx, gv, is_start=False, direct=False)
         gx, gv = b["dL_dx"], b["dL_dv"]
     dt = time.perf_counter() - t0
     return dict(value=steps / dt, unit="rollout-steps/s", cores=threads, kind="port",
-                sample=f"1 rollout x {steps} fwd+bwd steps of the same workload, fp64 oracle (oracle/), "
-                       f"mean PD iters {np.mean([r['iters'] for r in recs]):.0f}")
+                sample=f"rollout 0 of this job from its state after the {args.warmup} warm-up steps, {steps} fwd+bwd steps, fp64 "
+                       f"oracle (oracle/, OpenMP at the reference's sites), mean PD iters {np.mean([r['iters'] for r in recs]):.0f}, "
+                       f"reference adjoint iteration")
 
 
 def main():
@@ -209,7 +210,8 @@ def main():
             "roofline": {"bound": "hbm", **dom, "traffic": None, "kernels": [k_fwd, k_bwd]},
         }
         if world == 1 and args.cpu_steps > 0:
-            out["cpu_baseline"] = cpu_baseline(args, V, F, center, X0[0], MU[0, 0], args.cpu_steps)
+            xw, vw = e.get_state(W)
+            out["cpu_baseline"] = cpu_baseline(args, V, F, center, xw[0], vw[0], MU[0, 0], args.cpu_steps, gscale)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
