@@ -100,6 +100,8 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readonly("particleId2", &SelfCollisionInformation::particleId2);
 
   py::class_<ForwardInformation>(m, "ForwardInformation")
+      .def_readonly("simDurartionFraction", &ForwardInformation::simDurartionFraction)
+      .def_readonly("splines", &ForwardInformation::splines)
       .def_property_readonly("x", [](const ForwardInformation &r) { return toNp(r.x); })
       .def_property_readonly("v", [](const ForwardInformation &r) { return toNp(r.v); })
       .def_property_readonly("x_prev", [](const ForwardInformation &r) { return toNp(r.x_prev); })
@@ -121,10 +123,38 @@ PYBIND11_MODULE(diffcloth_py, m) {
         return py::make_tuple(py::make_tuple(r.primitiveCollisions, flat), r.selfCollisionLayers);
       });
 
+  py::enum_<Spline::SplineType>(m, "SplineType")
+      .value("ENDPOINT", Spline::ENDPOINT).value("ENDPOINT_AND_UP", Spline::ENDPOINT_AND_UP)
+      .value("ENDPOINT_AND_TANGENTS", Spline::ENDPOINT_AND_TANGENTS);
+  py::class_<Spline>(m, "Spline")
+      .def(py::init([](const VecXd &p0, const VecXd &p1, double yUp, int pFixed, double f0, double f1) {
+             return Spline({p0.at(0), p0.at(1), p0.at(2)}, {p1.at(0), p1.at(1), p1.at(2)}, yUp, pFixed, f0, f1);
+           }), py::arg("p0"), py::arg("p1"), py::arg("yUp"), py::arg("pFixed"), py::arg("startFraction") = 0.0, py::arg("endFraction") = 1.0)
+      .def("addSegment", [](Spline &s, const VecXd &p1, double yUp, double f0, double f1) { s.addSegment({p1.at(0), p1.at(1), p1.at(2)}, yUp, f0, f1); })
+      .def_readwrite("type", &Spline::type)
+      .def_readonly("pFixed", &Spline::pFixed)
+      .def("getParameterNumber", &Spline::getParameterNumber)
+      .def("evalute", [](const Spline &s, double t, int order) { Vec3d q = s.evalute(t, order); return toNp(q); }, py::arg("t"), py::arg("order") = 0)
+      .def("dxfixed_dcontrolPoints", [](const Spline &s, double t) {
+        std::vector<double> J = s.dxfixed_dcontrolPoints(t);
+        const int np = s.getParameterNumber();
+        py::array_t<double> a({3, np});
+        std::memcpy(a.mutable_data(), J.data(), J.size() * sizeof(double));
+        return a;
+      })
+      .def("paramToVector", [](const Spline &s) { return toNp(s.paramToVector()); })
+      .def("updateControlPoints", [](Spline &s, const VecXd &step) { s.updateControlPoints(step); })
+      .def("moveEndPoint", [](Spline &s, int seg, const VecXd &p) { s.moveEndPoint(seg, {p.at(0), p.at(1), p.at(2)}); });
+
   py::class_<BackwardInformation>(m, "BackwardInformation")
       .def_property_readonly("dL_dx", [](const BackwardInformation &b) { return toNp(b.dL_dx); })
       .def_property_readonly("dL_dv", [](const BackwardInformation &b) { return toNp(b.dL_dv); })
       .def_property_readonly("dL_dxfixed", [](const BackwardInformation &b) { return toNp(b.dL_dxfixed); })
+      .def_property_readonly("dL_dsplines", [](const BackwardInformation &b) {          // python_interface.cpp:219
+        py::list sets;
+        for (const auto &set : b.dL_dsplines) { py::list l; for (const VecXd &g : set) l.append(toNp(g)); sets.append(l); }
+        return sets;
+      })
       .def_property_readonly("dL_dfext", [](const BackwardInformation &b) { return toNp(b.dL_dfext); })
       .def_property_readonly("dL_dwind", [](const BackwardInformation &b) { return toNp(b.dL_dwind); })
       .def_readonly("dL_ddensity", &BackwardInformation::dL_ddensity)
@@ -187,6 +217,8 @@ PYBIND11_MODULE(diffcloth_py, m) {
                     [](const Simulation &s) { py::list out; for (auto &g : s.perStepGradient) out.append(toNp(g)); return out; },
                     [](Simulation &s, const std::vector<NpArr> &v) { s.perStepGradient.clear(); for (auto &a : v) s.perStepGradient.push_back(toVec(a)); })
       .def_readwrite("gradientClipping", &Simulation::gradientClipping)
+      .def_readwrite("controlPointSplines", &Simulation::controlPointSplines)    // sysMat[0].controlPointSplines of the reference
+      .def("resetSystemWithSplines", [](Simulation &s, const std::vector<Spline> &c) { s.resetSystem(c); })
       .def_readwrite("gradientClippingThreshold", &Simulation::gradientClippingThreshold)
       .def_readwrite("backwardGradientForceDirectSolver", &Simulation::backwardGradientForceDirectSolver)
       .def_property_readonly("ndof_u", &Simulation::getActionDim)
@@ -194,7 +226,7 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readwrite_static("forwardConvergenceThreshold", &Simulation::forwardConvergenceThreshold)
       .def_readwrite_static("backwardConvergenceThreshold", &Simulation::backwardConvergenceThreshold)
       .def_readwrite_static("assetRoot", &Simulation::assetRoot)
-      .def("resetSystem", &Simulation::resetSystem, "reset the simulation")
+      .def("resetSystem", [](Simulation &s) { s.resetSystem(); }, "reset the simulation")
       .def("step", &Simulation::step, "forward one step")
       .def("getCurrentPosVelocityVec", [](const Simulation &s) { auto p = s.getCurrentPosVelocityVec(); return py::make_tuple(toNp(p.first), toNp(p.second)); }, "get posvel vecs")
       .def("appendPerStepGradient", [](Simulation &s, const NpArr &x) { s.appendPerStepGradient(toVec(x)); }, "append grad", py::arg("x"))

@@ -239,6 +239,61 @@ void Simulation::initScene() {
     }
     default: break;
   }
+  // control-point splines: one per fixed point, start = end = rest position (createAttachments, :2389-2393); the grid
+  // scenes with CORNERS_2_UP lift the two corners to the opposite edge (:2337-2358)
+  controlPointSplines.clear();
+  const size_t Af = attachmentVertices.size();
+  auto restOf = [&](size_t a) { return Vec3d{fixedPointRest[3 * a], fixedPointRest[3 * a + 1], fixedPointRest[3 * a + 2]}; };
+  if (sceneConfig.attachmentPoints == CUSTOM_ARRAY)
+    for (size_t a = 0; a < Af; a++) controlPointSplines.emplace_back(restOf(a), restOf(a), 10, (int) a);
+  else if (!sceneConfig.fabric.isModel && sceneConfig.trajectory == CORNERS_2_UP && Af >= 2) {
+    const int gx = sceneConfig.fabric.gridNumX, gy = sceneConfig.fabric.gridNumY;
+    auto initPos = [&](int i, int j) {        // getInitParticlePos (:1783-1791)
+      const double sx = sceneConfig.fabric.clothDimX / (gx - 1), sy = sceneConfig.fabric.clothDimY / (gy - 1);
+      return Vec3d{j * sy - (gy - 1) / 4.0 * sy, 15 - i * sx, 0};
+    };
+    controlPointSplines.emplace_back(restOf(0), initPos(gy - 1, 0), 8, 0);
+    controlPointSplines.emplace_back(restOf(1), initPos(gy - 1, gx - 1), 8, 1);
+  }
+  // scene-dependent end points (:1994-2052)
+  switch (sceneConfig.trajectory) {
+    case CORNERS_1_WEARHAT:
+    case CORNERS_2_WEARHAT: {
+      if (sceneConfig.primitiveConfig != PLANE_BUST_WEARHAT || primitives.empty() || controlPointSplines.empty()) break;
+      const Primitive &head = primitives[0];
+      Vec3d tr;
+      for (int d = 0; d < 3; d++) tr[d] = head.center[d] - 0.5 * (restShapeMinDim[d] + restShapeMaxDim[d]);
+      tr[1] += head.radius * 0.6;
+      const size_t n = sceneConfig.trajectory == CORNERS_1_WEARHAT ? 1 : std::min<size_t>(2, controlPointSplines.size());
+      for (size_t k = 0; k < n; k++) {
+        Spline &sp = controlPointSplines[k];
+        sp.segments[0].yUp = 15;
+        Vec3d r = restOf(k);
+        sp.moveEndPoint(0, {r[0] + tr[0], r[1] + tr[1], r[2] + tr[2]});
+      }
+      break;
+    }
+    case CORNERS_2_WEARSOCK: {
+      if (sceneConfig.primitiveConfig != FOOT || primitives.empty() || controlPointSplines.size() < 2) break;
+      const Primitive &leg = primitives[0];
+      const Primitive &shin = leg.primitives.back();
+      Vec3d footTop = leg.center;
+      footTop[1] += shin.length + shin.radius * 2;
+      Vec3d sockTop = {0.5 * (restShapeMinDim[0] + restShapeMaxDim[0]), restShapeMaxDim[1], restShapeMinDim[2] + shin.radius};
+      for (Spline &sp : controlPointSplines) {
+        sp.segments[0].yUp = -28;
+        Vec3d r = restOf((size_t) sp.pFixed);
+        sp.moveEndPoint(0, {r[0] + footTop[0] - sockTop[0], r[1] + footTop[1] - sockTop[1], r[2] + footTop[2] - sockTop[2]});
+      }
+      break;
+    }
+    default: break;
+  }
+}
+
+void Simulation::resetSystem(const std::vector<Spline> &controlPoints) {   // Simulation.cpp:2858-2862
+  controlPointSplines = controlPoints;
+  resetSystem();
 }
 
 void Simulation::configureDevice() {
@@ -310,6 +365,91 @@ void Simulation::resetSystem() {
   check(ctx, dc_set_state(ctx, 0, r0.x.data(), r0.v.data()), "dc_set_state");
 }
 
+// ---- Spline (reference Spline.h): cubic Hermite basis h00 p0 + h10 m0 + h01 p1 + h11 m1 on each segment ----
+namespace {
+inline double h00(double t, int o) { return o == 1 ? 6 * t * t - 6 * t : 2 * t * t * t - 3 * t * t + 1; }
+inline double h01(double t, int o) { return o == 1 ? -6 * t * t + 6 * t : -2 * t * t * t + 3 * t * t; }
+inline double h10(double t, int o) { return o == 1 ? 3 * t * t - 4 * t + 1 : t * t * t - 2 * t * t + t; }
+inline double h11(double t, int o) { return o == 1 ? 3 * t * t - 2 * t : t * t * t - t * t; }
+}  // namespace
+
+void Spline::retangent(Segment &seg) {
+  for (int d = 0; d < 3; d++) seg.m0[d] = seg.m1[d] = seg.p1[d] - seg.p0[d];
+  seg.m0[1] += seg.yUp; seg.m1[1] -= seg.yUp;
+}
+Spline::Spline(Vec3d p0, Vec3d p1, double yUp, int pFixed_, double startFraction, double endFraction) : pFixed(pFixed_) {
+  Segment seg;
+  seg.p0 = p0; seg.p1 = p1; seg.yUp = yUp; seg.segId = 0; seg.startFraction = startFraction; seg.endFraction = endFraction;
+  retangent(seg);
+  segments.push_back(seg);
+}
+void Spline::addSegment(Vec3d p1, double yUp, double startFraction, double endFraction) {
+  if (segments.empty()) { std::fprintf(stderr, "WARNING: calling addSegment but spline is empty at the moment, please init spline with a segment\n"); return; }
+  Segment seg;
+  seg.p0 = segments.back().p1; seg.p1 = p1; seg.yUp = yUp; seg.segId = (int) segments.size();
+  seg.startFraction = startFraction; seg.endFraction = endFraction;
+  retangent(seg);
+  segments.push_back(seg);
+}
+void Spline::moveEndPoint(int segId, Vec3d newp1) {
+  Segment &seg = segments.at(segId);
+  seg.p1 = newp1;
+  retangent(seg);
+  if (segId + 1 < (int) segments.size()) { Segment &nx = segments[segId + 1]; nx.p0 = newp1; retangent(nx); }
+}
+const Spline::Segment &Spline::segmentAt(double t) const {
+  for (const Segment &s : segments) if (s.endFraction >= t) return s;
+  return segments.back();
+}
+double Spline::localTime(const Segment &seg, double t) {
+  if (t > seg.endFraction) return 1;
+  if (t < seg.startFraction) return 0;
+  return (t - seg.startFraction) / (seg.endFraction - seg.startFraction);
+}
+Vec3d Spline::evalute(double t, int order) const {
+  t = std::min(std::max(t, 0.0), 1.0);
+  const Segment &seg = segmentAt(t);
+  const double s = localTime(seg, t);
+  Vec3d out;
+  for (int d = 0; d < 3; d++) out[d] = h00(s, order) * seg.p0[d] + h10(s, order) * seg.m0[d] + h01(s, order) * seg.p1[d] + h11(s, order) * seg.m1[d];
+  return out;
+}
+std::vector<double> Spline::dxfixed_dcontrolPoints(double t) const {
+  const int per = parametersPerSegment(type), np = getParameterNumber();
+  std::vector<double> J(3 * (size_t) np, 0.0);
+  const Segment &seg = segmentAt(t);
+  const double s = localTime(seg, t);
+  const int off = per * seg.segId;
+  for (int d = 0; d < 3; d++) {
+    double *row = &J[(size_t) d * np + off];
+    if (type == ENDPOINT_AND_TANGENTS) { row[d] = h01(s, 0); row[3 + d] = h10(s, 0); row[6 + d] = h11(s, 0); }
+    else row[d] = h01(s, 0) + h10(s, 0) + h11(s, 0);          // p1 moves both tangents with it
+  }
+  if (type == ENDPOINT_AND_UP) J[(size_t) 1 * np + off + 3] = h10(s, 0) - h11(s, 0);
+  return J;
+}
+VecXd Spline::paramToVector() const {
+  VecXd out;
+  for (const Segment &seg : segments) {
+    for (int d = 0; d < 3; d++) out.push_back(seg.p1[d]);
+    if (type == ENDPOINT_AND_UP) out.push_back(seg.yUp);
+    if (type == ENDPOINT_AND_TANGENTS) { for (int d = 0; d < 3; d++) out.push_back(seg.m0[d]); for (int d = 0; d < 3; d++) out.push_back(seg.m1[d]); }
+  }
+  return out;
+}
+void Spline::updateControlPoints(const VecXd &step) {
+  const int per = parametersPerSegment(type);
+  if ((int) step.size() != getParameterNumber())
+    std::fprintf(stderr, "WARNING: Updating control points for spline type %d but dimension is %zu instead of %d\n", (int) type, step.size(), getParameterNumber());
+  for (size_t i = 0; i < segments.size() && (i + 1) * per <= step.size(); i++) {
+    Segment &seg = segments[i];
+    const double *q = &step[i * per];
+    for (int d = 0; d < 3; d++) seg.p1[d] += q[d];
+    if (type == ENDPOINT_AND_TANGENTS) { for (int d = 0; d < 3; d++) { seg.m0[d] += q[3 + d]; seg.m1[d] += q[6 + d]; } }
+    else { if (type == ENDPOINT_AND_UP) seg.yUp += q[3]; retangent(seg); }
+  }
+}
+
 double Simulation::windFactorAt(double t) const {   // fillForces (Simulation.cpp:64-87)
   switch (sceneConfig.windConfig) {
     case WIND_SIN: case WIND_SIN_AND_FALLOFF: return (std::sin(windFrequency * t + windPhase) + 1.0) / 2.0;
@@ -318,18 +458,37 @@ double Simulation::windFactorAt(double t) const {   // fillForces (Simulation.cp
   }
 }
 
-// stepFixPoints (Simulation.cpp:964-1018): PER_STEP (RL action), dress twirl, otherwise the points stay put
-// (the cubic-Hermite spline trajectories of Spline.h are a host-side next-tier item).
-VecXd Simulation::fixedPointTargets(double) {
+// stepFixPoints (Simulation.cpp:964-1018)
+VecXd Simulation::fixedPointTargets(double t) {
   const size_t Af = attachmentVertices.size();
-  if (sceneConfig.trajectory == PER_STEP_TRAJECTORY && rlFixedPointPos.size() == 3 * Af) fixedPointCur = rlFixedPointPos;
-  else if (sceneConfig.trajectory == TRAJECTORY_DRESS_TWIRL) {
-    Mat3 R = axisAngle({0, 1, 0}, 0.02);
-    for (size_t a = 0; a < Af; a++) {
-      Vec3d c = {restShapeMidPoint[0], fixedPointCur[3 * a + 1], restShapeMidPoint[2]};
-      Vec3d rel = {fixedPointCur[3 * a] - c[0], 0.0, fixedPointCur[3 * a + 2] - c[2]};
-      Vec3d q = rotv(R, rel);
-      fixedPointCur[3 * a] = q[0] + c[0]; fixedPointCur[3 * a + 2] = q[2] + c[2];
+  switch (sceneConfig.trajectory) {
+    case NO_TRAJECTORY: break;
+    case PER_STEP_TRAJECTORY:
+      if (rlFixedPointPos.size() == 3 * Af) fixedPointCur = rlFixedPointPos;
+      break;
+    case FIXED_POINT_TRAJECTORY: {
+      const size_t k = forwardRecords.size() - 1;
+      if (k < fixedPointTrajectory.size() && fixedPointTrajectory[k].size() == 3 * Af) fixedPointCur = fixedPointTrajectory[k];
+      break;
+    }
+    case TRAJECTORY_DRESS_TWIRL: {
+      Mat3 R = axisAngle({0, 1, 0}, 0.02);
+      for (size_t a = 0; a < Af; a++) {
+        Vec3d c = {restShapeMidPoint[0], fixedPointCur[3 * a + 1], restShapeMidPoint[2]};
+        Vec3d rel = {fixedPointCur[3 * a] - c[0], 0.0, fixedPointCur[3 * a + 2] - c[2]};
+        Vec3d q = rotv(R, rel);
+        fixedPointCur[3 * a] = q[0] + c[0]; fixedPointCur[3 * a + 2] = q[2] + c[2];
+      }
+      break;
+    }
+    default: {     // spline-driven trajectories (CORNERS_2_UP, CORNERS_*_WEARHAT, CORNERS_2_WEARSOCK)
+      const double frac = t / (sceneConfig.timeStep * sceneConfig.stepNum);
+      for (const Spline &s : controlPointSplines)
+        if (s.pFixed >= 0 && (size_t) s.pFixed < Af) {
+          Vec3d q = s.evalute(frac);
+          for (int d = 0; d < 3; d++) fixedPointCur[3 * (size_t) s.pFixed + d] = q[d];
+        }
+      break;
     }
   }
   return fixedPointCur;
@@ -351,6 +510,8 @@ void Simulation::step() {
     check(ctx, dc_set_uniform_force(ctx, f), "dc_set_uniform_force");
   } else check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
   rec.x_fixedpoints = fixedPointTargets(rec.t);
+  rec.simDurartionFraction = rec.t / (sceneConfig.timeStep * sceneConfig.stepNum);
+  rec.splines = controlPointSplines;
   dc_step_stats st;
   check(ctx, dc_step_forward(ctx, prev.deviceSlot, rec.x_fixedpoints.empty() ? nullptr : rec.x_fixedpoints.data(), &st), "dc_step_forward");
   rec.x.resize(3 * (size_t) N); rec.v.resize(3 * (size_t) N); rec.f.resize(3 * (size_t) N); rec.r.resize(3 * (size_t) N);
@@ -431,6 +592,21 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
     if (fwd.stepIdx == 1) std::reverse(perStepGradient.begin(), perStepGradient.end());
     if (gradient_new.dL_dxfixed_accum.size() == 3 * Af)
       for (size_t k = 0; k < 3 * Af; k++) ret.dL_dxfixed_accum[k] = ret.dL_dxfixed[k] + gradient_new.dL_dxfixed_accum[k];
+    // spline parameters (:1658-1669): dL_dspline += (dx_fixed/dparams)^T dL_dx_fixed of the driven point
+    ret.dL_dsplines = gradient_new.dL_dsplines;
+    if (ret.dL_dsplines.empty()) ret.dL_dsplines.assign(1, {});
+    if (ret.dL_dsplines[0].size() != controlPointSplines.size()) {
+      ret.dL_dsplines[0].clear();
+      for (const Spline &sp : controlPointSplines) ret.dL_dsplines[0].push_back(VecXd(sp.getParameterNumber(), 0.0));
+    }
+    for (size_t k = 0; k < controlPointSplines.size(); k++) {
+      const Spline &sp = controlPointSplines[k];
+      if (sp.pFixed < 0 || (size_t) sp.pFixed >= Af) continue;
+      const int np = sp.getParameterNumber();
+      std::vector<double> J = sp.dxfixed_dcontrolPoints(fwd.simDurartionFraction);
+      for (int q = 0; q < np; q++)
+        for (int d = 0; d < 3; d++) ret.dL_dsplines[0][k][q] += J[(size_t) d * np + q] * dxf[3 * (size_t) sp.pFixed + d];
+    }
   }
   // parameter gradients of this step (Simulation.cpp:1672-1764): the device returns this step's contributions
   double par[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -67,6 +67,36 @@ struct Primitive {                // the fields of Primitive.h the Python side r
   VecXd getPointVec() const { return VecXd(center.begin(), center.end()); }
 };
 
+// Trajectory of one fixed point: piecewise cubic Hermite curve over the simulated time span (reference Spline.h).
+// Parameters per segment: ENDPOINT p1 (tangents follow as m0 = p1 - p0 + yUp e_y, m1 = p1 - p0 - yUp e_y),
+// ENDPOINT_AND_UP (p1, yUp), ENDPOINT_AND_TANGENTS (p1, m0, m1).
+struct Spline {
+  enum SplineType { ENDPOINT, ENDPOINT_AND_UP, ENDPOINT_AND_TANGENTS };
+  struct Segment {
+    Vec3d p0 = {0, 0, 0}, m0 = {0, 0, 0}, p1 = {0, 0, 0}, m1 = {0, 0, 0};
+    double yUp = 8, startFraction = 0, endFraction = 1;
+    int segId = 0;
+  };
+  std::vector<Segment> segments;
+  int pFixed = 0;                 // index of the fixed point this curve drives
+  SplineType type = ENDPOINT;
+
+  Spline() {}
+  Spline(Vec3d p0, Vec3d p1, double yUp, int pFixed, double startFraction = 0.0, double endFraction = 1.0);
+  static int parametersPerSegment(SplineType t) { return t == ENDPOINT ? 3 : (t == ENDPOINT_AND_UP ? 4 : 9); }
+  int getParameterNumber() const { return parametersPerSegment(type) * (int) segments.size(); }
+  void addSegment(Vec3d p1, double yUp, double startFraction, double endFraction);
+  void moveEndPoint(int segId, Vec3d newp1);
+  Vec3d evalute(double t, int order = 0) const;                 // (sic) position, or d/ds for order 1, at simulation fraction t
+  std::vector<double> dxfixed_dcontrolPoints(double t) const;   // 3 x getParameterNumber(), row-major
+  VecXd paramToVector() const;
+  void updateControlPoints(const VecXd &step);
+ private:
+  const Segment &segmentAt(double t) const;
+  static double localTime(const Segment &seg, double t);
+  static void retangent(Segment &seg);
+};
+
 struct PrimitiveCollisionInformation { int primitiveId = -1, particleId = -1; Vec3d normal = {0, 0, 0}; };   // Simulation.h:39-51
 struct SelfCollisionInformation { int particleId1 = -1, particleId2 = -1, layerId = 0; Vec3d normal = {0, 0, 0}; };   // Simulation.h:53-63
 
@@ -79,6 +109,8 @@ struct ForwardInformation {       // Simulation.h:68-100 (hot-path fields)
   bool converged = false;
   int convergeIter = 0, totalConverged = 0, cumulateIter = 0, stepIdx = 0;
   double loss = 0;
+  double simDurartionFraction = 0;   // (sic) t / (timeStep * stepNum), the spline parameter of this step
+  std::vector<Spline> splines;
   int deviceSlot = 0;             // tape slot of libdiffcloth_hip holding this record
 };
 
@@ -89,6 +121,7 @@ struct BackwardInformation {      // Simulation.h:136-162 (hot-path fields)
   double dL_ddensity = 0;
   std::array<double, 4> dL_dk_pertype = {0, 0, 0, 0};
   std::vector<std::pair<int, double>> dL_dmu;
+  std::vector<std::vector<VecXd>> dL_dsplines;   // [attachment set][spline] -> gradient w.r.t. the spline parameters
   double loss = 0;
   long long totalRuntime = 0;
   bool converged = false;
@@ -131,6 +164,8 @@ class Simulation {
   double windNorm = 0.15, windFrequency = 14, windPhase = 0;
   Vec3d restShapeMinDim = {0, 0, 0}, restShapeMaxDim = {0, 0, 0}, restShapeMidPoint = {0, 0, 0};
   VecXd rlFixedPointPos;
+  std::vector<Spline> controlPointSplines;   // sysMat[0].controlPointSplines
+  std::vector<VecXd> fixedPointTrajectory;   // FIXED_POINT_TRAJECTORY: targets per step
 
   ~Simulation();
   static Simulation *createSystem(SceneConfiguration sceneConfig, Vec3d center, bool runBackward = true);
@@ -139,6 +174,7 @@ class Simulation {
                                           bool runBackward = true);
 
   void resetSystem();
+  void resetSystem(const std::vector<Spline> &controlPoints);   // Simulation.cpp:2858-2862
   void step();
   void stepNN(int idx, const VecXd &x, const VecXd &v, const VecXd &fixedPointPos);
   BackwardInformation stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,

@@ -83,3 +83,51 @@ def test_stepNN_and_stepBackwardNN_like_functional_py(hat):
     back2 = sim.stepBackwardNN(helper.taskInfo, z, z, new, False, gx, gv)
     np.testing.assert_allclose(back2.dL_dx, gx + gv / cfg["h"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(back2.dL_dv, gv, rtol=1e-6, atol=1e-12)
+
+
+def test_spline_driven_step_and_spline_gradients(hat):
+    """Simulation::step() with the scene's own trajectory (CORNERS_2_WEARHAT: one cubic Hermite curve per clip, end point =
+    rest + (head - hat) translation, yUp 15 — Simulation.cpp:1996-2017) and dL_dsplines of stepBackward (:1658-1669)."""
+    d, _, o, P, F, cfg = hat
+    V, _ = scenes.load_mesh("hat")
+    sim = d.makeSimFromMesh("wear_hat", V.reshape(-1), F.reshape(-1).tolist())   # fresh: stepNN switches a sim to PER_STEP for good
+    helper = d.makeOptimizeHelperWithSim("wear_hat", sim)
+    d.Simulation.forwardConvergenceThreshold = 1e-6
+    sim.gradientClipping = False
+    sim.backwardGradientForceDirectSolver = True
+    sim.resetSystem()
+    splines = sim.controlPointSplines
+    assert len(splines) == 2 and [s.pFixed for s in splines] == [0, 1]
+    rest_fp = P[cfg["attachments"]]
+    head = np.asarray(sim.primitives[0].center)
+    tr = head + np.array([0, 2.1 * 0.6, 0]) - 0.5 * (P.min(axis=0) + P.max(axis=0))
+    for k, s in enumerate(splines):
+        np.testing.assert_allclose(s.evalute(0.0), rest_fp[k], atol=1e-12)
+        np.testing.assert_allclose(s.evalute(1.0), rest_fp[k] + tr, atol=1e-12)
+    S = 3
+    for step in range(S):
+        sim.step()
+        rec = sim.getStateInfo()
+        frac = (step + 1) * 0.01 / (0.01 * 400)
+        assert abs(rec.simDurartionFraction - frac) < 1e-15
+        want = np.concatenate([s.evalute(frac) for s in splines])
+        np.testing.assert_allclose(rec.x_fixedpoints, want, atol=1e-12)
+    # backward sweep with a linear loss on the final positions
+    rng = np.random.default_rng(2)
+    gx = f32(rng.standard_normal(3 * 579) * 1e-2); gv = np.zeros_like(gx)
+    z = np.zeros_like(gx)
+    back = None
+    expect = [np.zeros(3), np.zeros(3)]
+    for step in reversed(range(1, S + 1)):
+        rec = sim.getPastStateInfo(step)
+        if back is None:
+            back = sim.stepBackwardNN(helper.taskInfo, gx, gv, rec, step == 1, z, z)
+        else:
+            back = sim.stepBackward(helper.taskInfo, back, rec, step == 1, z, z)
+        for k, s in enumerate(splines):
+            expect[k] = expect[k] + s.dxfixed_dcontrolPoints(rec.simDurartionFraction).T @ back.dL_dxfixed[3 * k:3 * k + 3]
+    got = back.dL_dsplines
+    assert len(got) == 1 and len(got[0]) == 2
+    for k in range(2):
+        assert np.linalg.norm(expect[k]) > 0
+        np.testing.assert_allclose(got[0][k], expect[k], rtol=1e-12, atol=1e-18)

@@ -51,3 +51,39 @@ def test_no_cpu_fallback_without_a_device():
     V, F = scenes.load_mesh("hat")
     with pytest.raises(Exception, match="no CPU path"):
         d.makeSimFromMesh("wear_hat", V.reshape(-1), F.reshape(-1).tolist())
+
+
+def test_spline_trajectory_math():
+    """Cubic Hermite fixed-point trajectories (reference Spline.h): end-point interpolation, multi-segment lookup, and
+    dxfixed_dcontrolPoints against finite differences of evalute() for the three parameterisations."""
+    d = pytest.importorskip("diffcloth_py")
+    import numpy as np
+    rng = np.random.default_rng(0)
+    p0, p1, p2 = rng.standard_normal(3), rng.standard_normal(3), rng.standard_normal(3)
+    for typ, nper in ((d.SplineType.ENDPOINT, 3), (d.SplineType.ENDPOINT_AND_UP, 4), (d.SplineType.ENDPOINT_AND_TANGENTS, 9)):
+        s = d.Spline(p0, p1, 8.0, 1, 0.0, 0.5)
+        s.addSegment(p2, 3.0, 0.5, 1.0)
+        s.type = typ
+        assert s.getParameterNumber() == 2 * nper and s.pFixed == 1
+        np.testing.assert_allclose(s.evalute(0.0), p0, atol=1e-14)
+        np.testing.assert_allclose(s.evalute(0.5), p1, atol=1e-14)
+        np.testing.assert_allclose(s.evalute(1.0), p2, atol=1e-14)
+        np.testing.assert_allclose(s.evalute(1.7), p2, atol=1e-14)          # clamped
+        for t in (0.13, 0.41, 0.77):
+            J = s.dxfixed_dcontrolPoints(t)
+            assert J.shape == (3, 2 * nper)
+            seg = 0 if t <= 0.5 else 1
+            for q in range(2 * nper):
+                if q // nper != seg:
+                    assert np.all(J[:, q] == 0)          # the reference differentiates the active segment only
+                    continue
+                e = np.zeros(2 * nper); e[q] = 1e-6
+                sp = d.Spline(p0, p1, 8.0, 1, 0.0, 0.5); sp.addSegment(p2, 3.0, 0.5, 1.0); sp.type = typ
+                sm = d.Spline(p0, p1, 8.0, 1, 0.0, 0.5); sm.addSegment(p2, 3.0, 0.5, 1.0); sm.type = typ
+                sp.updateControlPoints(e); sm.updateControlPoints(-e)
+                fd = (sp.evalute(t) - sm.evalute(t)) / 2e-6
+                np.testing.assert_allclose(J[:, q], fd, atol=1e-6)
+    # first-order evaluation = derivative w.r.t. the local spline time
+    s = d.Spline(p0, p1, 8.0, 0)
+    fd = (s.evalute(0.3 + 1e-6) - s.evalute(0.3 - 1e-6)) / 2e-6
+    np.testing.assert_allclose(s.evalute(0.3, 1), fd, atol=1e-6)
