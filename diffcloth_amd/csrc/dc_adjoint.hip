@@ -191,18 +191,28 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   if constexpr (!WIN) { adjoint_operator_global<THREADS>(S, C, zin, precond, out, d1, dot1, dot2); return; }
   const int N = S.N;
   const float h2 = S.h * S.h;
-  contact_transpose<THREADS>(S, C, zin, precond, C.y);       // y = (I + dr_df)^T z, ends with a barrier
   float a1 = 0.f, a2 = 0.f;
-  const float *y = C.y;
-  element_windows<THREADS>(S, C.lds, y, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, [&](int i, f3 sum) {
+  auto vert = [&](int i, f3 sum, f3 yi) {
     f3 z = ld3(zin, i, N);
     if (precond) z = z * S.dinv[i];
     f3 o = z * S.mass[i] + sum;
-    if (S.att_of_vertex[i] >= 0) o = o + ld3(y, i, N) * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
+    if (S.att_of_vertex[i] >= 0) o = o + yi * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
     st3(out, i, N, o);
     if (d1) a1 += dot(o, ld3(d1, i, N));
     a2 += dot(o, o);
-  });
+  };
+  if (C.nself > 0) {
+    // layered self contacts couple vertices: y = (I + dr_df)^T z is formed in global memory first
+    contact_transpose<THREADS>(S, C, zin, precond, C.y);     // ends with a barrier
+    element_windows<THREADS>(S, C.lds, StagePlanar{C.y, N}, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
+  } else {
+    // primitive contacts only: dr_df is block diagonal, y_i is formed per vertex while the window is staged
+    element_windows<THREADS>(S, C.lds, [&](int i) {
+      f3 z = ld3(zin, i, N);
+      if (precond) z = z * S.dinv[i];
+      return z + contact_JT(S, C, i, z);
+    }, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
+  }
   dot1 = a1; dot2 = a2;
 }
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     if (S.win_ok) {
       // ---- local step + vertex pass, window by window inside LDS (dc_winlib.h) ----
       float *scr = W.cg_r + off;
-      element_windows<THREADS>(S, lp, xn, vnow, FwdTriOp{h}, FwdBendOp{h}, [&](int i, f3 sum) {
+      element_windows<THREADS>(S, lp, StagePlanar{xn, N}, vnow, FwdTriOp{h}, FwdBendOp{h}, [&](int i, f3 sum, f3) {
         f3 rhs = vertex_body(i, sum);
         st3(scr, i, N, rhs);
         part += dot(rhs, rhs);

@@ -21,12 +21,14 @@ __device__ __forceinline__ WinLds win_lds(const DevSystem &S, float *lds) {
 __device__ __forceinline__ f3 ldw(const float2 *xy, const float *z, int j) { const float2 q = xy[j]; return mk(q.x, q.y, z[j]); }
 __device__ __forceinline__ void stw(float2 *xy, float *z, int j, f3 v) { xy[j] = make_float2(v.x, v.y); z[j] = v.z; }
 
-// in1 / in2: planar [3][N] vectors of this rollout in global memory. tri_op(a0,a1,a2, b0,b1,b2, D, w2, r0, r1) and
-// bend_op(a[4], b[4], w, n, w2, res) see the values of in1 (a) and in2 (b) at the element's vertices;
-// vert_op(i, sum) receives sum_corners coef * result for every vertex exactly once. Call with all threads; starts
-// with a barrier (LDS may still be in use by the caller) and ends WITHOUT one.
-template <int THREADS, class TriOp, class BendOp, class VertOp>
-__device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, const float *__restrict__ in1,
+// Input 1 comes from stage1(i) (a per-vertex function of global data, evaluated while the window is staged: the adjoint
+// forms y = (I + dr_df)^T z there, so y never exists in global memory), input 2 is the planar [3][N] vector in2.
+// tri_op(a0,a1,a2, b0,b1,b2, D, w2, r0, r1) and bend_op(a[4], b[4], w, n, w2, res) see the values of input 1 (a) and
+// input 2 (b) at the element's vertices; vert_op(i, sum, a_i) receives sum_corners coef * result and input 1 at the
+// vertex, for every vertex exactly once. Call with all threads; starts with a barrier (LDS may still be in use by the
+// caller) and ends WITHOUT one.
+template <int THREADS, class Stage1, class TriOp, class BendOp, class VertOp>
+__device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, Stage1 stage1,
                                                 const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
   const int N = S.N, tid = threadIdx.x, lane = tid & 63;
   const WinLds L = win_lds(S, lds);
@@ -36,8 +38,8 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
     __syncthreads();
     for (int j = tid; j < vs; j += THREADS) {
       const int i = lo + j;
-      L.a1xy[j] = make_float2(in1[i], in1[N + i]); L.a1z[j] = in1[2 * N + i];
       L.a2xy[j] = make_float2(in2[i], in2[N + i]); L.a2z[j] = in2[2 * N + i];
+      stw(L.a1xy, L.a1z, j, stage1(i));
     }
     __syncthreads();
     // per-element phase: EB elements of a thread at a time, their records loaded up front (clamped index, no
@@ -107,12 +109,19 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
           sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
         }
       }
-      vert_op(i, mk(sx, sy, sz));
+      vert_op(i, mk(sx, sy, sz), ldw(L.a1xy, L.a1z, i - lo));
     }
   }
 }
 
 // ---- forward local step: a = x_n, b = v (current iterate); x = x_n + h v, edges formed as differences first ----
+// stage1 for a plain planar vector
+struct StagePlanar {
+  const float *v;
+  int N;
+  __device__ __forceinline__ f3 operator()(int i) const { return mk(v[i], v[N + i], v[2 * N + i]); }
+};
+
 struct FwdTriOp {   // Triangle::project (Triangle.cpp:310-351): columns of h w^2 (T - F)
   float h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float w2, f3 &r0, f3 &r1) const {
