@@ -36,14 +36,22 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
     const int4 d0 = S.win[2 * w], d1 = S.win[2 * w + 1];
     const int v0 = d0.x, v1 = d0.y, lo = d0.z, vs = d0.w, toff = d1.x, nt = d1.y, boff = d1.z, nb = d1.w;
     __syncthreads();
-    for (int j = tid; j < vs; j += THREADS) {
-      const int i = lo + j;
-      L.a2xy[j] = make_float2(in2[i], in2[N + i]); L.a2z[j] = in2[2 * N + i];
-      stw(L.a1xy, L.a1z, j, stage1(i));
+    // two span vertices per thread and round (clamped index, no divergence): their global loads overlap
+    for (int j0 = tid; j0 < vs; j0 += 2 * THREADS) {
+      const int jb = j0 + THREADS;
+      const bool vb = jb < vs;
+      const int ia = lo + j0, ib = lo + (vb ? jb : j0);
+      const float2 qa = make_float2(in2[ia], in2[N + ia]), qb = make_float2(in2[ib], in2[N + ib]);
+      const float za = in2[2 * N + ia], zb = in2[2 * N + ib];
+      const f3 sa = stage1(ia), sb = stage1(ib);
+      L.a2xy[j0] = qa; L.a2z[j0] = za;
+      stw(L.a1xy, L.a1z, j0, sa);
+      if (vb) { L.a2xy[jb] = qb; L.a2z[jb] = zb; stw(L.a1xy, L.a1z, jb, sb); }
     }
     __syncthreads();
     // per-element phase: EB elements of a thread at a time, their records loaded up front (clamped index, no
-    // divergence) so that EB L2 round trips and EB gather -> math chains overlap instead of queueing up
+    // divergence) so that EB L2 round trips and EB gather -> math chains overlap instead of queueing up. (A variant with
+    // exactly ceil(n / THREADS) rounds behind wave-uniform branches was 2x slower: the branches end the overlap.)
     constexpr int EB = 4;
     for (int t0 = tid; t0 < nt + tid; t0 += EB * THREADS) {
       int4 r[EB];
@@ -83,28 +91,25 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
       }
     }
     __syncthreads();
-    // per-vertex phase: the next batch of (vector, coefficient) packets is in flight while this one is summed
+    // per-vertex phase
     for (int i = v0 + tid; i < v1; i += THREADS) {
       const int ch = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
       const int np = S.winc_n[ch];
       const int4 *row = S.winc + S.winc_ptr[ch] + lane;
       float sx = 0.f, sy = 0.f, sz = 0.f;
-      int4 nxt[4];
+      // all packets of the vertex in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2 + 12 flaps = 24
+      // pairs); clamped index + masked coefficient instead of divergence, wider rows take another round
+      constexpr int VPB = 12;
+      for (int s0 = 0; s0 < np; s0 += VPB) {
+        int4 e[VPB];
 #pragma unroll
-      for (int j = 0; j < 4; j++) nxt[j] = row[j * 64];
-      for (int s0 = 0; s0 < np; s0 += 4) {
-        int4 e[4];
+        for (int j = 0; j < VPB; j++) e[j] = row[min(s0 + j, np - 1) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; j++) e[j] = nxt[j];
-        if (s0 + 4 < np) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) nxt[j] = row[(s0 + 4 + j) * 64];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < VPB; j++) {
+          const float on = (s0 + j < np) ? 1.f : 0.f;
           const float2 qa = L.erxy[e[j].x], qb = L.erxy[e[j].z];
           const float za = L.erz[e[j].x], zb = L.erz[e[j].z];
-          const float ca = __int_as_float(e[j].y), cb = __int_as_float(e[j].w);
+          const float ca = __int_as_float(e[j].y) * on, cb = __int_as_float(e[j].w) * on;
           sx = fmaf(ca, qa.x, sx); sy = fmaf(ca, qa.y, sy); sz = fmaf(ca, za, sz);
           sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
         }
