@@ -126,12 +126,18 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   double min_xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
   const int total_contacts = (int) block_sum<THREADS>((double) ncontact, red);
   const int nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;   // from k_self_detect
-  bool improved = false, converged = false, stalled = false;
+  bool improved = false, converged = false, stalled = false, best_is_current = false;
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
 
   PH_DECL
   for (int iter = 0; iter < A.pd_cap; iter++) {
+    // opaque zero, refreshed per PD iteration: the per-row indices of the unrolled loops below are loop invariant, and
+    // LICM would hoist ~20 rows x several arrays of them out of the PD loop into registers that do not exist (357
+    // dwords spilled at the loop head and reloaded in every phase)
+    int zp;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zp));
+    const int tq = tid + zp;
     // per-vertex part of the step given the summed element forces of the vertex: f, friction r, scaled right-hand
     // side of the correction solve
     auto vertex_body = [&](int i, f3 fint) -> f3 {
@@ -162,9 +168,21 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       });
       __syncthreads();
       PH(0)
-      for (int i = tid; i < NP; i += THREADS) {
-        f3 rhs = (i < N) ? ld3(scr, i, N) : mk(0, 0, 0);
-        ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+      for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread (clamped index), then the LDS stores
+        float t[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int i = tq + min(k0 + j, VPT - 1) * THREADS, ic = min(i, N - 1);
+          const float ok = (i < N) ? 1.f : 0.f;
+          t[j][0] = scr[ic] * ok; t[j][1] = scr[N + ic] * ok; t[j][2] = scr[2 * N + ic] * ok;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (k0 + j < VPT) {
+            const int i = tq + (k0 + j) * THREADS;
+            ((float2 *) lp)[i] = make_float2(t[j][0], t[j][1]); lp[2 * NP + i] = t[j][2];
+          }
+        }
       }
     } else {
       // ---- local step: per-element projection residual, written per constraint corner (global memory) ----
@@ -216,13 +234,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     float rr[VPT][3], ap[VPT][3], xx[XR > 0 ? XR : 1][3];
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
-      const int i = tid + k * THREADS;
+      const int i = tq + k * THREADS;
       const float2 q = ((const float2 *) lp)[i];
       rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = lp[2 * NP + i];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         if (k < XR) xx[k < XR ? k : 0][c] = 0.f;
-        else lx[((k - XR) * 3 + c) * THREADS + tid] = 0.f;
+        else lx[((k - XR) * 3 + c) * THREADS + tq] = 0.f;
       }
     }
     PH(1)
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             if (k < XR) xx[k < XR ? k : 0][c] = fmaf(alpha, pv[c], xx[k < XR ? k : 0][c]);
-            else lx[((k - XR) * 3 + c) * THREADS + tid] = fmaf(alpha, pv[c], lx[((k - XR) * 3 + c) * THREADS + tid]);
+            else lx[((k - XR) * 3 + c) * THREADS + tz] = fmaf(alpha, pv[c], lx[((k - XR) * 3 + c) * THREADS + tz]);
             rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
             part2 = fmaf(rr[k][c], rr[k][c], part2);
           }
@@ -294,29 +312,35 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       }
     }
     // ---- update + convergence (Simulation.cpp:1268, 1310-1373) ----
-    // all loads first (clamped index, no divergence), then the arithmetic, then the stores: one memory round trip
-    // instead of VPT dependent ones; the new iterate stays in registers for the best-iterate copy below
+    // rows in groups of 4: loads (clamped index, no divergence), arithmetic, stores; delta v replaces A p in its
+    // registers and stays there for the best-iterate bookkeeping below
     part = 0.f;
-    float vv[VPT][3];
 #pragma unroll
-    for (int k = 0; k < VPT; k++) {
-      const int i = min(tid + k * THREADS, N - 1);
-      const float sq = S.sq_dinv[i];
+    for (int k0 = 0; k0 < VPT; k0 += 4) {
+      float vq[4][3], sq[4];
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const float xs = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tid];
-        vv[k][c] = vnow[c * N + i];
-        ap[k][c] = xs * sq;                 // delta v (A p is dead here)
+      for (int j = 0; j < 4; j++) {
+        if (k0 + j < VPT) {
+          const int i = min(tq + (k0 + j) * THREADS, N - 1);
+          sq[j] = S.sq_dinv[i];
+#pragma unroll
+          for (int c = 0; c < 3; c++) vq[j][c] = vnow[c * N + i];
+        }
       }
-    }
 #pragma unroll
-    for (int k = 0; k < VPT; k++) {
-      const int i = tid + k * THREADS;
+      for (int j = 0; j < 4; j++) {
+        if (k0 + j < VPT) {
+          const int k = k0 + j;
+          const int i = tq + k * THREADS;
 #pragma unroll
-      for (int c = 0; c < 3; c++) {
-        vv[k][c] += ap[k][c];
-        if (i < N) { vnow[c * N + i] = vv[k][c]; part = fmaf(ap[k][c], ap[k][c], part); }
+          for (int c = 0; c < 3; c++) {
+            const float xs = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tq];
+            ap[k][c] = xs * sq[j];             // delta v (A p is dead here)
+            if (i < N) { vnow[c * N + i] = vq[j][c] + ap[k][c]; part = fmaf(ap[k][c], ap[k][c], part); }
+          }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
     PH(5)
@@ -326,12 +350,14 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       since_progress = 0;     // any new minimum counts: slow monotone convergence must never look like a stall
       min_xdiff = xdiff;
       improved = true;
-      if (!converged) {
+      best_is_current = true;            // the best iterate is v itself: nothing to copy while the run keeps improving
+    } else if (best_is_current) {
+      // first non-improving iteration after a minimum: the best iterate is the previous one = v - delta (delta is still in registers)
+      best_is_current = false;
 #pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int i = tid + k * THREADS;
-          if (i < N) { vbest[i] = vv[k][0]; vbest[N + i] = vv[k][1]; vbest[2 * N + i] = vv[k][2]; }
-        }
+      for (int k = 0; k < VPT; k++) {
+        const int i = tq + k * THREADS;
+        if (i < N) { vbest[i] = vnow[i] - ap[k][0]; vbest[N + i] = vnow[N + i] - ap[k][1]; vbest[2 * N + i] = vnow[2 * N + i] - ap[k][2]; }
       }
     }
     if (converged) break;
@@ -342,7 +368,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   for (int i = tid; i < N; i += THREADS) {
     f3 x = ld3(xn, i, N);
     if (converged) { f3 v = ld3(vnow, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
-    else if (improved) { f3 v = ld3(vbest, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
+    else if (improved) { f3 v = ld3(best_is_current ? vnow : vbest, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
     else { st3(vo, i, N, ld3(vn, i, N)); st3(xo, i, N, x); }
   }
   if (tid == 0) {

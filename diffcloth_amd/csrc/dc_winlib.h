@@ -91,30 +91,53 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
       }
     }
     __syncthreads();
-    // per-vertex phase
-    for (int i = v0 + tid; i < v1; i += THREADS) {
-      const int ch = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
-      const int np = S.winc_n[ch];
-      const int4 *row = S.winc + S.winc_ptr[ch] + lane;
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-      // all packets of the vertex in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2 + 12 flaps = 24
-      // pairs); clamped index + masked coefficient instead of divergence, wider rows take another round
-      constexpr int VPB = 12;
-      for (int s0 = 0; s0 < np; s0 += VPB) {
-        int4 e[VPB];
+    // per-vertex phase. All packets of a vertex travel in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2
+    // + 12 flaps = 24 pairs); clamped index + masked coefficient instead of divergence, wider rows take another round.
+    // With fewer threads than owned vertices (512-thread kernels) a thread handles two vertices at once so that the
+    // table loads of both rounds overlap.
+    constexpr int VPB = 12;
+    constexpr bool PAIR = THREADS < 1024;
+    auto gather = [&](const int4 (&e)[VPB], int s0, int np, float &sx, float &sy, float &sz) {
 #pragma unroll
-        for (int j = 0; j < VPB; j++) e[j] = row[min(s0 + j, np - 1) * 64];
-#pragma unroll
-        for (int j = 0; j < VPB; j++) {
-          const float on = (s0 + j < np) ? 1.f : 0.f;
-          const float2 qa = L.erxy[e[j].x], qb = L.erxy[e[j].z];
-          const float za = L.erz[e[j].x], zb = L.erz[e[j].z];
-          const float ca = __int_as_float(e[j].y) * on, cb = __int_as_float(e[j].w) * on;
-          sx = fmaf(ca, qa.x, sx); sy = fmaf(ca, qa.y, sy); sz = fmaf(ca, za, sz);
-          sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
-        }
+      for (int j = 0; j < VPB; j++) {
+        const float on = (s0 + j < np) ? 1.f : 0.f;
+        const float2 qa = L.erxy[e[j].x], qb = L.erxy[e[j].z];
+        const float za = L.erz[e[j].x], zb = L.erz[e[j].z];
+        const float ca = __int_as_float(e[j].y) * on, cb = __int_as_float(e[j].w) * on;
+        sx = fmaf(ca, qa.x, sx); sy = fmaf(ca, qa.y, sy); sz = fmaf(ca, za, sz);
+        sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
       }
-      vert_op(i, mk(sx, sy, sz), ldw(L.a1xy, L.a1z, i - lo));
+    };
+    for (int i = v0 + tid; i < v1; i += (PAIR ? 2 : 1) * THREADS) {
+      const int cha = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
+      const int npa = S.winc_n[cha];
+      const int4 DC_G *rowa = S.winc + S.winc_ptr[cha] + lane;
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      if constexpr (PAIR) {
+        const int ib = i + THREADS;
+        const bool vb = ib < v1;
+        const int chb = __builtin_amdgcn_readfirstlane((vb ? ib : i) >> 6);
+        const int npb = S.winc_n[chb];
+        const int4 DC_G *rowb = S.winc + S.winc_ptr[chb] + lane;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        for (int s0 = 0; s0 < max(npa, npb); s0 += VPB) {
+          int4 ea[VPB], eb[VPB];
+#pragma unroll
+          for (int j = 0; j < VPB; j++) { ea[j] = rowa[min(s0 + j, npa - 1) * 64]; eb[j] = rowb[min(s0 + j, npb - 1) * 64]; }
+          gather(ea, s0, npa, ax, ay, az);
+          gather(eb, s0, npb, bx, by, bz);
+        }
+        vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
+        if (vb) vert_op(ib, mk(bx, by, bz), ldw(L.a1xy, L.a1z, ib - lo));
+      } else {
+        for (int s0 = 0; s0 < npa; s0 += VPB) {
+          int4 ea[VPB];
+#pragma unroll
+          for (int j = 0; j < VPB; j++) ea[j] = rowa[min(s0 + j, npa - 1) * 64];
+          gather(ea, s0, npa, ax, ay, az);
+        }
+        vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
+      }
     }
   }
 }
