@@ -18,8 +18,10 @@ constexpr int kMetaStride = 1024;  // ints per (slot, rollout): count, nlayers, 
 // dc_engine.hip is parsed in the device pass too and assigns plain pointers)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DC_KERNEL_TU)
 #define DC_G __attribute__((address_space(1)))
+#define DC_C __attribute__((address_space(4)))   // constant address space: wave-uniform entries become scalar loads
 #else
 #define DC_G
+#define DC_C
 #endif
 
 struct DevPrim {
@@ -56,22 +58,22 @@ struct DevSystem {
   // 64-row chunk pk_n[c] 16-byte packets per row (a multiple of 4), packet (s, lane) at pk[pk_ptr[c] + 64 s + lane] =
   // {v0, v1, v2, d0 | d1 << 10 | d2 << 20}, d = column - row + 512; chunks cover 512 * pk_vpt rows
   const int4 DC_G *pk;
-  const int DC_G *pk_ptr;
-  const int DC_G *pk_n;
+  const int DC_C *pk_ptr;
+  const int DC_C *pk_n;
   const float DC_G *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
   // vertex renumbering (bandwidth reduction, dc_engine.hip): device index <-> caller's index; null = identity
   const int DC_G *user_of;           // [N] device -> caller
   const int DC_G *dev_of;            // [N] caller -> device
   // element windows (dc_windows.h / dc_winlib.h): the per-constraint passes run window by window inside LDS
-  const int4 DC_G *win;              // [2 * nwin]: {v0, v1, lo, vs}, {tri_off, ntri, bend_off, nbend}
+  const int4 DC_C *win;              // [2 * nwin]: {v0, v1, lo, vs}, {tri_off, ntri, bend_off, nbend}
   const int4 DC_G *wtri_rec;         // per window-triangle: j0 | j1 << 16, j2, bits(w^2), triangle id
   const float4 DC_G *wtri_D;
   const int4 DC_G *wbend_rec;        // per window-flap: j0 | j1 << 16, j2 | j3 << 16, bits(rest norm), bits(w^2)
   const float4 DC_G *wbend_w;
   const int4 DC_G *winc;             // vertex -> (result vector, coefficient) pair packets, wave-sliced by 64-vertex chunk
-  const int DC_G *winc_ptr;
-  const int DC_G *winc_n;
+  const int DC_C *winc_ptr;
+  const int DC_C *winc_n;
   int nwin, win_vcap, win_nrcap, win_ok;
   int win_lds_bytes, pad2;
   // self-collision (Simulation.cpp:194-220, 225-373): collision radii, connected-pair table (share a triangle)
