@@ -226,6 +226,19 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = S.N;
   const size_t off = (size_t) b * 3 * N;
+  // A.nsteps consecutive steps of the backward sweep of this rollout in one launch (dc_rollout_backward): step s
+  // differentiates tape slot k - s; the carried gradient stays in gx / gv. Rollouts are independent, so none of them has
+  // to wait for the slowest one after every step.
+  for (int step = 0; step < A.nsteps; step++) {
+  if (step > 0) {
+    __syncthreads();
+    A.x_new -= A.slot_state; A.rec_f -= A.slot_state; A.rec_n -= A.slot_state; A.rec_prim -= A.slot_prim;
+    A.x_prev -= A.slot_state; A.v_prev -= A.slot_state;
+    A.self.pair -= A.slot_self; A.self.nrm -= A.slot_self; A.self.dvec -= A.slot_self; A.self.meta -= A.slot_meta;
+    if (A.d_param) A.d_param -= A.slot_param;
+    A.x_fixed -= A.slot_xf; A.stats -= A.slot_stats;
+    A.is_start = (A.slot - step == 1) ? 1 : 0;            // isStart: Simulation.cpp:3947
+  }
   AdjCtx C;
   C.lds = dyn_lds;
   C.xnew = A.x_new + off; C.rec_f = A.rec_f + off; C.rec_n = A.rec_n + off;
@@ -493,6 +506,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   }
   PH(3)
   PH_PRINT
+  }   // step
 }
 
 static int pick_threads_bwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }

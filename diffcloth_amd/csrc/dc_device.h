@@ -129,6 +129,9 @@ struct FwdArgs {
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
+  // several consecutive steps in one launch (packet kernel only): step s uses tape slot k + s
+  int nsteps;
+  size_t slot_state, slot_prim, slot_stats;     // slot strides of the [B][3][N] arrays, the [B][N] array, the stats
 };
 
 struct BwdArgs {
@@ -148,10 +151,14 @@ struct BwdArgs {
   float bwd_tol, cg_tol, clip_thr, rel_tol;
   int mode;                     // 0: reference fixed-point iteration (+ direct fallback), 1: direct Krylov solve
   int it_cap, cg_max, is_start, clip, stall_window;
+  // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
+  int nsteps, slot;
+  size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements)
 };
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 // LDS/register-resident variant (dc_forward_res.hip); returns false when N is too large for it.
+bool pd_step_fusable(const DevSystem &S);   // launch_pd_step would take the packet kernel, which honours FwdArgs::nsteps
 bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
 bool launch_pd_step_resident(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st, int variant);
 void launch_self_detect(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);

@@ -137,6 +137,7 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.pd_cap = pd_cap(c);
   A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
+  A.nsteps = 1; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
   return A;
 }
 BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
@@ -163,6 +164,9 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.mode = c->params.adjoint_mode;
   A.rel_tol = (float) (c->params.adjoint_rel_tol > 0 ? c->params.adjoint_rel_tol : 1e-6);
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
+  A.nsteps = 1; A.slot = slot;
+  A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
+  A.slot_param = (size_t) c->B * 8; A.slot_xf = (size_t) c->B * 3 * c->S.Af; A.slot_stats = (size_t) c->B;
   return A;
 }
 
@@ -788,10 +792,22 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-  for (int k = 0; k < nsteps; k++) {
-    if (c->S.Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
-    if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
-    launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+  const bool self_on = c->S.contact_enabled && c->S.self_enabled;
+  static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
+  if (!self_on && fuse_ok && nsteps > 1 && pd_step_fusable(c->S)) {
+    // no per-step detection launch needed: all steps of a rollout run inside ONE launch, so a rollout never waits for
+    // the slowest rollout of the batch between steps
+    for (int k = 0; k < nsteps && c->S.Af > 0; k++)
+      HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
+    FwdArgs A = fwd_args(c, slot);
+    A.nsteps = nsteps;
+    launch_pd_step(c->S, c->W, A, c->B, c->stream);
+  } else {
+    for (int k = 0; k < nsteps; k++) {
+      if (c->S.Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
+      if (self_on) launch_self_detect(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+      launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+    }
   }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
   HIPCHK(c, hipGetLastError());
@@ -825,9 +841,16 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   if (slot - nsteps + 1 < 1) return fail(c, DC_ERR_INVALID, "dc_rollout_backward: would run past slot 1");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
-  for (int k = 0; k < nsteps; k++) {
-    const int s = slot - k;
-    launch_adjoint_step(c->S, c->W, bwd_args(c, s, s == 1, false), c->B, c->stream);   // isStart: Simulation.cpp:3947
+  static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
+  if (fuse_ok && nsteps > 1) {
+    BwdArgs A = bwd_args(c, slot, slot == 1, false);
+    A.nsteps = nsteps;                       // the whole sweep of a rollout in one launch
+    launch_adjoint_step(c->S, c->W, A, c->B, c->stream);
+  } else {
+    for (int k = 0; k < nsteps; k++) {
+      const int s = slot - k;
+      launch_adjoint_step(c->S, c->W, bwd_args(c, s, s == 1, false), c->B, c->stream);   // isStart: Simulation.cpp:3947
+    }
   }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
   HIPCHK(c, hipGetLastError());

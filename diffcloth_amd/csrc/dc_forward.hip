@@ -196,6 +196,8 @@ static int fwd_variant() {
   return v;
 }
 
+bool pd_step_fusable(const DevSystem &S) { return fwd_variant() == -2 && S.pk_ok && S.pk_vpt > 0; }
+
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   const int variant = fwd_variant();
   if (variant == -2 && launch_pd_step_packet(S, W, A, B, st)) return;

@@ -94,12 +94,18 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = S.N, T = S.T, E = S.E, NC = S.NC;
   const size_t off = (size_t) b * 3 * N;
-  const float *xn = A.x_in + off, *vn = A.v_in + off;
   float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off;
   float *corner = W.corner + (size_t) b * 3 * NC;
-  float *rec_f = A.rec_f + off, *rec_r = A.rec_r + off, *rec_n = A.rec_n + off;
-  int *rec_prim = A.rec_prim + (size_t) b * N;
   const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
+  // A.nsteps consecutive time steps of this rollout in one launch (dc_rollout_forward without self-collision): rollouts
+  // are independent, so nothing forces them to wait for the slowest one after every step. Step s reads tape slot k + s
+  // and writes slot k + s + 1 (slot strides: A.slot_state floats, A.slot_prim ints, A.slot_stats entries).
+  for (int step = 0; step < A.nsteps; step++) {
+  if (step > 0) __syncthreads();              // the previous step's state written by the whole workgroup
+  const size_t so = (size_t) step * A.slot_state;
+  const float *xn = A.x_in + off + so, *vn = A.v_in + off + so;
+  float *rec_f = A.rec_f + off + so, *rec_r = A.rec_r + off + so, *rec_n = A.rec_n + off + so;
+  int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
   const float *mu = A.mu + (size_t) b * S.ngroups;
   const float h = S.h;
   const f3 grav = mk(S.gx, S.gy, S.gz);
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     if (++since_progress >= A.stall_window) { stalled = true; break; }   // fp32 floor, see dc_forward.hip
   }
   // ---- write the new state (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
-  float *xo = A.x_out + off, *vo = A.v_out + off;
+  float *xo = A.x_out + off + so, *vo = A.v_out + off + so;
   for (int i = tid; i < N; i += THREADS) {
     f3 x = ld3(xn, i, N);
     if (converged) { f3 v = ld3(vnow, i, N); st3(vo, i, N, v); st3(xo, i, N, x + v * h); }
@@ -375,9 +381,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     dc_step_stats s;
     s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
     s.self_contacts = nself; s.last_xdiff = (float) xdiff;
-    A.stats[b] = s;
+    A.stats[b + (size_t) step * A.slot_stats] = s;
   }
   PH_PRINT
+  }   // step
 }
 
 template <int THREADS, int VPT, int XL>

@@ -218,6 +218,14 @@ def test_rollout_on_device_equals_stepwise_calls():
     assert np.isfinite(dx).all() and np.isfinite(dv).all() and np.abs(dx).max() > 0
     kt = e.kernel_times()
     assert kt["fwd_launches"] == S and kt["bwd_launches"] == S and kt["fwd_ms"] > 0
+    # the fused backward sweep (all steps of a rollout in one launch) against step-by-step calls through the host boundary
+    xS, _ = e.get_state(S)
+    gx = f32(xS - f32(V.reshape(-1))[None, :]); gv = np.zeros_like(gx)       # dc_seed_gradient(S, rest, 1.0) on the host
+    for s in range(S, 0, -1):
+        out = e.step_backward(s, gx, gv, is_start=(s == 1))
+        gx, gv = out["dL_dx"], out["dL_dv"]
+    np.testing.assert_allclose(dx, gx, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(dv, gv, rtol=1e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("mu", [0.1, 0.7])
