@@ -178,9 +178,11 @@ def main():
         bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b) * N
 
     def kernel_entry(name, nbytes, ms, launches):
+        # one launch = the K timed steps of all B rollouts (dc_rollout_* runs a rollout's steps inside one launch)
         gbs = nbytes / max(ms * 1e-3, 1e-12) / 1e9
         return {"kernel": name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": nbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1)}
+                "algorithmic_bytes_per_launch": nbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                "steps_per_launch": K / max(launches, 1), "ms_per_step": ms / K}
     k_fwd = kernel_entry("k_pd_step_pk", bytes_fwd, kt["fwd_ms"], kt["fwd_launches"])
     k_bwd = kernel_entry("k_adjoint_step", bytes_bwd, kt["bwd_ms"], kt["bwd_launches"])
     dom = k_fwd if kt["fwd_ms"] >= kt["bwd_ms"] else k_bwd

@@ -794,7 +794,8 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
   const bool self_on = c->S.contact_enabled && c->S.self_enabled;
   static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
-  if (!self_on && fuse_ok && nsteps > 1 && pd_step_fusable(c->S)) {
+  const bool fused = !self_on && fuse_ok && nsteps > 1 && pd_step_fusable(c->S);
+  if (fused) {
     // no per-step detection launch needed: all steps of a rollout run inside ONE launch, so a rollout never waits for
     // the slowest rollout of the batch between steps
     for (int k = 0; k < nsteps && c->S.Af > 0; k++)
@@ -815,7 +816,7 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventSynchronize(c->ev_b));
   float ms = 0;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-  c->fwd_ms += ms; c->fwd_launches += nsteps;
+  c->fwd_ms += ms; c->fwd_launches += fused ? 1 : nsteps;
   return DC_OK;
 }
 
@@ -857,7 +858,7 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventSynchronize(c->ev_b));
   float ms = 0;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-  c->bwd_ms += ms; c->bwd_launches += nsteps;
+  c->bwd_ms += ms; c->bwd_launches += (fuse_ok && nsteps > 1) ? 1 : nsteps;
   return DC_OK;
 }
 

@@ -186,7 +186,8 @@ int dc_sync(dc_ctx *ctx);
 int dc_timer_start(dc_ctx *ctx);
 int dc_timer_stop(dc_ctx *ctx, float *ms);
 /* accumulated device time (ms) and launch count of the forward / backward step kernels since the last
- * reset, measured with HIP events on the context's stream; used by bench.py's roofline block.          */
+ * reset, measured with HIP events on the context's stream; used by bench.py's roofline block. A dc_rollout_* call
+ * may run all its time steps in ONE launch (every rollout advances on its own), so launches <= steps.            */
 int dc_kernel_times(dc_ctx *ctx, float *fwd_ms, int *fwd_launches, float *bwd_ms, int *bwd_launches, int reset);
 
 #ifdef __cplusplus

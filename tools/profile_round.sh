@@ -8,10 +8,10 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o x --output-format csv -- python $R/bench.py > $OUT/bench_under_rocprof.log 2>&1
-tail -1 $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
+grep metric $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o x --output-format csv -- python $R/bench.py --steps 3 --warmup 5 --cpu-steps 0 > $OUT/pmc_$C.log 2>&1
 done
 python $R/bench.py > $OUT/bench_plain.log 2>&1
-tail -1 $OUT/bench_plain.log > $OUT/bench_line.json
+grep metric $OUT/bench_plain.log > $OUT/bench_line.json
 ls -R $OUT | head -30
