@@ -3,7 +3,7 @@
 
 Workload: synthetic 100x100 grid cloth (N = 10 000 vertices, T = 19 602 triangles,
 E = 29 205 bending flaps) of the reference's `sphereFabric` (k_stretch 150, k_bend 1e-5, density 0.3, 4.5 x 4.5)
-dropped on the `rotatingSphereScene` sphere (r = 2, Signorini–Coulomb contact), h = 1/180, 256 independent
+dropped on the `rotatingSphereScene` sphere (r = 2, Signorini–Coulomb contact, self-collision on), h = 1/180, 256 independent
 rollouts per GPU (per-rollout start offset and friction coefficient, seed = global rollout id).
 One "step" = one forward time step (Simulation::step) + one backward step (Simulation::stepBackward) of all
 rollouts of the job; `value` = rollout-steps per second over the whole job = B_total * K / t.
@@ -40,7 +40,7 @@ def make_engine(device, args, V, F, center):
     e.set_mesh(V, F)
     e.set_params(time_step=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_tol=args.fwd_tol,
                  backward_tol=args.bwd_tol, cg_rel_tol=args.cg_tol, cg_max_iter=args.cg_max,
-                 gradient_clipping=1, selfcollision_enabled=0, adjoint_mode=args.adjoint_mode,
+                 gradient_clipping=1, selfcollision_enabled=args.selfcollision, adjoint_mode=args.adjoint_mode,
                  adjoint_rel_tol=args.adjoint_rel_tol)
     e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=center, radius=2.0, mu=0.9)])
     e.build()
@@ -63,7 +63,7 @@ def cpu_baseline(args, V, F, center, x0, v0, mu, steps, gscale):
     import orc
     threads = args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 32)
     o = orc.Oracle(V, F, h=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, fwd_tol=args.fwd_tol,
-                   bwd_tol=args.bwd_tol, selfcollision=False, gradient_clipping=True, threads=threads)
+                   bwd_tol=args.bwd_tol, selfcollision=bool(args.selfcollision), gradient_clipping=True, threads=threads)
     o.add_sphere(center, 2.0, float(mu))
     o.build()
     x = x0.copy(); v = v0.copy()
@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--adjoint-mode", dest="adjoint_mode", type=int, default=1,
                     help="1: direct adjoint solve (reference's solveDirect semantics); 0: reference fixed-point iteration")
     ap.add_argument("--adjoint-rel-tol", dest="adjoint_rel_tol", type=float, default=1e-6)
+    ap.add_argument("--selfcollision", type=int, default=1,
+                    help="self-collision detection + layered self friction (the reference's default: selfcollisionEnabled = true); 0 = off")
     ap.add_argument("--cpu-steps", type=int, default=2, help="steps of the CPU baseline sample (0 disables)")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0: min(host cores, 32), the fastest setting measured on the MI355X host)")
@@ -159,11 +161,12 @@ def main():
 
     kt = e.kernel_times()
     # iteration statistics of the timed steps (needed for the algorithmic-byte count)
-    pd = cg_f = adj = cg_b = 0.0
+    pd = cg_f = adj = cg_b = selfc = 0.0
     conv = 0
     for s in range(W + 1, W + K + 1):
         fs, bs = e.get_stats(s)
         pd += fs["pd_iters"].sum(); cg_f += fs["cg_iters"].sum(); conv += int((fs["converged"] > 0).sum())
+        selfc += fs["self_contacts"].sum()
         adj += bs["adjoint_iters"].sum(); cg_b += bs["cg_iters"].sum()
     N = e.N
     # Algorithmic bytes (fp32, per rollout; DESIGN.md "Roofline model"): what ONE streaming pass per vector sweep
@@ -198,10 +201,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C4 grid {args.grid}x{args.grid} cloth (N={N}, T={e.T}, E={e.E}) on sphere r=2, "
-                                   f"h=1/{round(1 / args.h)}, primitive Signorini-Coulomb contact",
+                                   f"h=1/{round(1 / args.h)}, primitive Signorini-Coulomb contact" + (" + self-collision" if args.selfcollision else ""),
                        "rollouts_per_gpu": B, "rollouts_total": world * B, "fwd_tol": args.fwd_tol,
                        "bwd_tol": args.bwd_tol, "cg_rel_tol": args.cg_tol, "adjoint_mode": args.adjoint_mode,
-                       "adjoint_rel_tol": args.adjoint_rel_tol,
+                       "adjoint_rel_tol": args.adjoint_rel_tol, "selfcollision": bool(args.selfcollision), "mean_self_contacts_per_step": selfc / (B * K),
                        "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
                        "mean_adjoint_iters_per_step": adj / (B * K), "converged_fraction": conv / (B * K),
                        "batch_steps_per_s": world * K / dt, "gradients_finite": finite,

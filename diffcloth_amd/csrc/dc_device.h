@@ -130,8 +130,9 @@ struct FwdArgs {
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
   // several consecutive steps in one launch (packet kernel only): step s uses tape slot k + s
-  int nsteps;
+  int nsteps, inline_detect;    // inline_detect: run the self-collision detection of every step inside the kernel
   size_t slot_state, slot_prim, slot_stats;     // slot strides of the [B][3][N] arrays, the [B][N] array, the stats
+  size_t slot_self, slot_meta;                  // ... of the self-contact lists and their meta blocks
 };
 
 struct BwdArgs {

@@ -137,7 +137,8 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.pd_cap = pd_cap(c);
   A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
-  A.nsteps = 1; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
+  A.nsteps = 1; A.inline_detect = 0; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
+  A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   return A;
 }
 BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
@@ -794,14 +795,14 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
   const bool self_on = c->S.contact_enabled && c->S.self_enabled;
   static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
-  const bool fused = !self_on && fuse_ok && nsteps > 1 && pd_step_fusable(c->S);
+  const bool fused = fuse_ok && nsteps > 1 && pd_step_fusable(c->S);
   if (fused) {
-    // no per-step detection launch needed: all steps of a rollout run inside ONE launch, so a rollout never waits for
-    // the slowest rollout of the batch between steps
+    // all steps of a rollout run inside ONE launch (self-collision detection inlined per step), so a rollout never waits
+    // for the slowest rollout of the batch between steps
     for (int k = 0; k < nsteps && c->S.Af > 0; k++)
       HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
     FwdArgs A = fwd_args(c, slot);
-    A.nsteps = nsteps;
+    A.nsteps = nsteps; A.inline_detect = self_on ? 1 : 0;
     launch_pd_step(c->S, c->W, A, c->B, c->stream);
   } else {
     for (int k = 0; k < nsteps; k++) {

@@ -19,6 +19,7 @@
 #define DC_KERNEL_TU
 #include "dc_devlib.h"
 #include "dc_winlib.h"
+#include "dc_selflib.h"
 #include <algorithm>
 
 namespace dc {
@@ -106,6 +107,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   const float *xn = A.x_in + off + so, *vn = A.v_in + off + so;
   float *rec_f = A.rec_f + off + so, *rec_r = A.rec_r + off + so, *rec_n = A.rec_n + off + so;
   int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
+  SelfRec srec = A.self;                      // self contacts of this step's record
+  srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
+  srec.meta += (size_t) step * A.slot_meta;
+  if (A.inline_detect) {                      // fused sweeps: detection + layering of this step run here (dc_selflib.h)
+    self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, (int *) lp);
+    __syncthreads();
+  }
   const float *mu = A.mu + (size_t) b * S.ngroups;
   const float h = S.h;
   const f3 grav = mk(S.gx, S.gy, S.gz);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   }
   double min_xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
   const int total_contacts = (int) block_sum<THREADS>((double) ncontact, red);
-  const int nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;   // from k_self_detect
+  const int nself = (S.contact_enabled && S.self_enabled) ? srec.meta[(size_t) b * kMetaStride] : 0;   // from the detection pass
   bool improved = false, converged = false, stalled = false, best_is_current = false;
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     }
     if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
       __syncthreads();
-      self_friction_layers<THREADS>(S, A.self, b, rec_f, rec_r);
+      self_friction_layers<THREADS>(S, srec, b, rec_f, rec_r);
       part = 0.f;
       for (int i = tid; i < N; i += THREADS) {
         f3 rhs = (ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i]) * S.sq_dinv[i];
@@ -391,6 +399,7 @@ template <int THREADS, int VPT, int XL>
 static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
   if (S.win_ok) lds = std::max(lds, (size_t) S.win_lds_bytes);
+  if (A.inline_detect) lds = std::max(lds, sizeof(int) * (size_t) kSelfDetectLdsInts);
   static size_t configured = 0;
   if (lds > configured) {
     (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);

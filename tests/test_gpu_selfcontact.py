@@ -107,3 +107,26 @@ def test_no_self_contacts_is_a_noop():
     assert ref["nself"] == 0 and st["self_contacts"][0] == 0 and e.get_self_contacts(1)["count"] == 0
     x1, _ = e.get_state(1)
     assert np.abs(x1[0] - ref["x"]).max() <= 4.5e-5
+
+
+def test_fused_rollout_with_self_contacts_equals_stepwise_calls():
+    """dc_rollout_forward runs all steps of a rollout (detection + layering + step) in one launch; per-step calls launch
+    the detection kernel and the step kernel separately. Same code, same inputs: bitwise identical states and contacts."""
+    V, F, o, e, x0, v0 = folded_pair(chain=True, seed=7)
+    S = 4
+    e.alloc_batch(2, S)
+    X = np.stack([x0, f32(x0 + 0.001)]); Vv = np.stack([v0, v0])
+    e.set_state(0, X, Vv)
+    e.rollout_forward(0, S)
+    xa, va = e.get_state(S)
+    ca = [e.get_self_contacts(s + 1) for s in range(S)]
+    for s in range(S):
+        st = e.step_forward(s)
+    xb, vb = e.get_state(S)
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(va, vb)
+    for s in range(S):
+        cb = e.get_self_contacts(s + 1)
+        assert ca[s]["count"] == cb["count"] and ca[s]["layers"] == cb["layers"]
+        np.testing.assert_array_equal(ca[s]["pairs"], cb["pairs"])
+    assert ca[0]["count"] > 20
