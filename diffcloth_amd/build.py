@@ -61,9 +61,9 @@ def build_pymodule(force=False, verbose=False):
     import sysconfig
     import pybind11
     host = os.path.join(CSRC, "host")
-    srcs = [os.path.join(host, s) for s in ("simulation.cpp", "scene_tables.cpp", "pymodule.cpp")]
+    srcs = [os.path.join(host, s) for s in ("simulation.cpp", "scene_tables.cpp", "optimize.cpp", "pymodule.cpp")]
     out = os.path.join(LIBDIR, "diffcloth_py" + sysconfig.get_config_var("EXT_SUFFIX"))
-    deps = srcs + [os.path.join(host, "simulation.h"), os.path.join(ROOT, "include", "diffcloth_hip.h"), LIB]
+    deps = srcs + [os.path.join(host, "simulation.h"), os.path.join(host, "optimize.h"), os.path.join(ROOT, "include", "diffcloth_hip.h"), LIB]
     if not force and not _stale(out, deps):
         return out
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",

@@ -9,6 +9,7 @@
 #include <fstream>
 #include <memory>
 #include "simulation.h"
+#include "optimize.h"
 
 namespace py = pybind11;
 using namespace dchost;
@@ -27,16 +28,6 @@ static py::array_t<double> toNp(const VecXd &v) { return py::array_t<double>((py
 template <size_t K>
 static py::array_t<double> toNp(const std::array<double, K> &v) { return py::array_t<double>((py::ssize_t) K, v.data()); }
 
-// OptimizeHelper: only the attributes the Python drivers read (python_interface.cpp:336-362); the L-BFGS machinery
-// of src/code/optimization stays with the reference (out of scope).
-struct OptimizeHelper {
-  Simulation *sim = nullptr;
-  BackwardTaskInformation taskInfo;
-  LossInfo lossInfo;
-  int forward_steps = 0;
-  std::string lossType = "MATCHSHAPE";
-};
-
 static Simulation *makeSim(const std::string &exampleName, bool runBackward) {
   Simulation::forwardConvergenceThreshold = 1e-5;      // python_interface.cpp:13
   SceneConfiguration cfg = sceneByName(exampleName);   // throws "Undefined example name (...)" like throwError
@@ -51,19 +42,9 @@ static Simulation *makeSim(const std::string &exampleName, bool runBackward) {
 
 static OptimizeHelper *makeOptimizeHelperWithSim(const std::string &exampleName, Simulation *sim) {
   Simulation::forwardConvergenceThreshold = 1e-5;      // python_interface.cpp:99
-  OptimizeHelper *h = new OptimizeHelper();
-  h->sim = sim;
   sim->setPrintVerbose(false);
-  h->forward_steps = sim->sceneConfig.stepNum;
-  // per-demo gradient switches (optimization/OptimizationTaskSetup.cpp:154-225)
-  if (exampleName == "wear_hat" || exampleName == "wear_sock") h->taskInfo.dL_dcontrolPoints = true;
-  else if (exampleName == "wind_tshirt") { h->taskInfo.dL_dk_pertype[2] = true; h->taskInfo.dL_dfwind = true; }
-  else if (exampleName == "sphere") { h->taskInfo.dL_dmu = true; h->taskInfo.mu_primitives = {0}; }
-  else if (exampleName == "inverse_design" || exampleName == "wind_sim2real") { h->taskInfo.dL_dx0 = true; }
-  else throw std::runtime_error("Undefined example name (" + exampleName + ").");
-  h->taskInfo.forwardAccuracyLevel = sim->sceneConfig.forwardConvergenceThresh;
-  h->taskInfo.backwardAccuracyLevel = sim->sceneConfig.backwardConvergenceThresh;
-  if (exampleName == "wear_hat") {                     // target shape of the hat demo (assets: remeshed/Hat/hat_target.txt)
+  OptimizeHelper *h = makeOptimizeHelperForDemo(exampleName, sim);      // BackwardTaskSolver::getOptimizeHelperPointer
+  if (exampleName == "wear_hat") {                     // debug target shape of the hat demo (assets: remeshed/Hat/hat_target.txt)
     std::string root = Simulation::assetRoot.empty() ? (std::getenv("DIFFCLOTH_ASSETS") ? std::getenv("DIFFCLOTH_ASSETS") : "/root/reference/src/assets/meshes") : Simulation::assetRoot;
     std::ifstream in(root + "/remeshed/Hat/hat_target.txt");
     VecXd shape;
@@ -256,12 +237,46 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def("getTriangles", [](const Simulation &s) { return s.triangles(); })
       .def("getAttachmentVertices", [](const Simulation &s) { return s.attachments(); });
 
-  py::class_<OptimizeHelper>(m, "OptimizeHelper")
-      .def_readonly("forward_steps", &OptimizeHelper::forward_steps)
-      .def_readonly("sim", &OptimizeHelper::sim, py::return_value_policy::reference)
+  py::enum_<LossType>(m, "LossType")
+      .value("MATCHSHAPE_WITH_TRANSLATION", MATCHSHAPE_WITH_TRANSLATION).value("MULTISTEP_MATCHSHAPE", MULTISTEP_MATCHSHAPE)
+      .value("MATCHSHAPE_TRANSLATION_INVARINT", MATCHSHAPE_TRANSLATION_INVARINT).value("ASSISTED_DRESSING_KEYPOINTS", ASSISTED_DRESSING_KEYPOINTS)
+      .value("MATCH_TRAJECTORY", MATCH_TRAJECTORY).value("MATCH_TRAJECTORY_MAX", MATCH_TRAJECTORY_MAX).value("MATCH_VELOCITY", MATCH_VELOCITY)
+      .value("DRESS_ANGLE", DRESS_ANGLE);
+
+  py::class_<ParamInfo>(m, "ParamInfo")                 // python_interface.cpp:260-266
+      .def(py::init<>())
+      .def_property("x0", [](const ParamInfo &p) { return toNp(p.x0); }, [](ParamInfo &p, const NpArr &a) { p.x0 = toVec(a); })
+      .def_property("v0", [](const ParamInfo &p) { return toNp(p.v0); }, [](ParamInfo &p, const NpArr &a) { p.v0 = toVec(a); })
+      .def_property("f_ext", [](const ParamInfo &p) { return toNp(p.f_ext); }, [](ParamInfo &p, const NpArr &a) { p.f_ext = toVec(a); })
+      .def_property("f_extwind", [](const ParamInfo &p) { return toNp(p.f_extwind); },
+                    [](ParamInfo &p, const NpArr &a) { VecXd v = toVec(a); for (int i = 0; i < 5; i++) p.f_extwind[i] = v.at(i); })
+      .def_readwrite("density", &ParamInfo::density)
+      .def_readonly("k_pertype", &ParamInfo::k_pertype)
+      .def_readonly("controlPointSplines", &ParamInfo::controlPointSplines)
+      .def_readonly("mu", &ParamInfo::mu);
+
+  py::class_<OptimizeHelper>(m, "OptimizeHelper")      // python_interface.cpp:337-365
+      .def_property_readonly("paramLowerBound", [](const OptimizeHelper &h) { return toNp(h.paramLowerBound); })
+      .def_property_readonly("paramUpperBound", [](const OptimizeHelper &h) { return toNp(h.paramUpperBound); })
+      .def_readonly("forward_steps", &OptimizeHelper::FORWARD_STEPS)
+      .def_readonly("sim", &OptimizeHelper::system, py::return_value_policy::reference)
+      .def_readonly("paramLogScaleTransformOn", &OptimizeHelper::paramLogScaleTransformOn)
+      .def_readonly("paramName", &OptimizeHelper::paramName)
       .def_readonly("taskInfo", &OptimizeHelper::taskInfo)
       .def_readonly("lossType", &OptimizeHelper::lossType)
-      .def_readonly("lossInfo", &OptimizeHelper::lossInfo);
+      .def_readonly("lossInfo", &OptimizeHelper::lossInfo)
+      .def_readonly("paramActual", &OptimizeHelper::param_actual)
+      .def("getActualParam", [](const OptimizeHelper &h) { return toNp(h.getActualParam()); }, "getactualparam")
+      .def("getRandomParam", [](OptimizeHelper &h, int seed) { return toNp(h.getRandomParam(seed)); }, "generate random initial parameters",
+           py::arg("randSeed") = 0)
+      .def("runSimulationAndGetLoss", [](OptimizeHelper &h, const NpArr &x) { return h.runSimulationAndGetLoss(toVec(x)); },
+           "compute loss from parameter vector", py::arg("x"))
+      .def("vecXdToParamInfo", [](const OptimizeHelper &h, const NpArr &x) { return h.vecXdToParamInfo(toVec(x)); }, py::arg("x"))
+      .def("paramInfoToVecXd", [](const OptimizeHelper &h, const ParamInfo &p) { return toNp(h.paramInfoToVecXd(p)); }, py::arg("param"))
+      .def("gradientInfoToVecXd", [](const OptimizeHelper &h, const BackwardInformation &g) { return toNp(h.gradientInfoToVecXd(g)); },
+           "convert grad struct to grad vector", py::arg("grad"))
+      .def("runSimulationAndGetLossGradient", [](OptimizeHelper &h, const NpArr &x) { return h.runSimulationAndGetLossAndGradients(toVec(x)); },
+           "compute loss and grads from parameter vector", py::arg("x"));
 
   m.def("makeSim", &makeSim, "initialize a simulation instance", py::arg("exampleName"), py::arg("runBackward") = true);
   m.def("makeSimFromMesh",

@@ -334,6 +334,27 @@ void Simulation::configureDevice() {
   paramsClipThr = gradientClippingThreshold; paramsDirect = false;
 }
 
+// New fabric parameters (stiffness per constraint type, density): constraint weights, lumped masses and the system matrix
+// are rebuilt on the device (setConstraintWeight / updateMassMatrix / initializePrefactoredMatrices, Simulation.cpp:3500-3556).
+void Simulation::rebuildSystem() {
+  dc_params prm;
+  dc_default_params(&prm);
+  prm.time_step = sceneConfig.timeStep;
+  prm.density = sceneConfig.fabric.density;
+  prm.k_stretch = sceneConfig.fabric.k_stiff_stretching;
+  prm.k_bend = sceneConfig.fabric.k_stiff_bending;
+  prm.k_att = k_stiff_attachment;
+  for (int d = 0; d < 3; d++) prm.gravity[d] = gravity[d];
+  prm.gravity_enabled = gravityEnabled; prm.contact_enabled = contactEnabled; prm.selfcollision_enabled = selfcollisionEnabled;
+  prm.forward_tol = forwardConvergenceThreshold; prm.backward_tol = backwardConvergenceThreshold;
+  prm.gradient_clipping = gradientClipping; prm.gradient_clipping_threshold = gradientClippingThreshold;
+  prm.adjoint_mode = backwardGradientForceDirectSolver ? 1 : 0;
+  check(ctx, dc_set_params(ctx, &prm), "dc_set_params");
+  check(ctx, dc_build(ctx), "dc_build");
+  paramsFwdTol = prm.forward_tol; paramsBwdTol = prm.backward_tol; paramsClip = gradientClipping;
+  paramsClipThr = gradientClippingThreshold; paramsDirect = backwardGradientForceDirectSolver;
+}
+
 // The reference reads its mutable statics at every step; mirror that by refreshing the solver knobs when they changed.
 void Simulation::pushParams() {
   if (paramsFwdTol == forwardConvergenceThreshold && paramsBwdTol == backwardConvergenceThreshold &&

@@ -137,10 +137,38 @@ struct BackwardTaskInformation {  // Simulation.h:188-209
   int randSeed = 0, srandSeed = 0;
 };
 
-struct LossInfo {                 // Simulation.h:252-261 (fields bound in python_interface.cpp:262-266)
+enum LossType {                   // engine/Constants.h:12-22 (same order)
+  MATCHSHAPE_WITH_TRANSLATION, MULTISTEP_MATCHSHAPE, MATCHSHAPE_TRANSLATION_INVARINT, ASSISTED_DRESSING_KEYPOINTS,
+  MATCH_TRAJECTORY, MATCH_TRAJECTORY_MAX, MATCH_VELOCITY, DRESS_ANGLE
+};
+
+struct CorresPondenceTargetInfo {  // (sic) Simulation.h:211-219: the farthest of `particleIndices` is pulled to targetPos at frameIdx
+  int frameIdx = 0;
+  Vec3d targetPos = {0, 0, 0};
+  std::vector<int> particleIndices;
+};
+
+struct ForwardInformation;
+struct LossInfo {                 // Simulation.h:252-261
   Vec3d targetLoc = {0, 0, 0}, targetTranslation = {0, 0, 0};
   std::vector<std::pair<int, VecXd>> targetFrameShape;
+  std::vector<std::pair<VecXd, VecXd>> targetSimulation;   // (x, v) per frame of the ground-truth run
+  VecXd targetShape;
+  std::vector<int> loopPoints;     // sorted particle ids (std::set in the reference)
+  double targetTwirlHeight = 0;
+  std::vector<CorresPondenceTargetInfo> targetPosPairs;
 };
+
+struct ParamInfo {                // Simulation.h:120-133
+  VecXd x0, v0, f_ext, f_ext_timestep, f_constantForceField;
+  std::array<double, 5> f_extwind = {0, 0, 0, 0, 0};
+  double density = 0;
+  std::array<double, 4> k_pertype = {0, 0, 0, 0};
+  std::vector<std::vector<Spline>> controlPointSplines;
+  std::vector<std::pair<int, double>> mu;
+};
+
+struct TaskSolveStatistics { int totalForwardSim = 0, totalBackprop = 0; };   // Simulation.h:221-250 (counters only)
 
 class Simulation {
  public:
@@ -162,6 +190,7 @@ class Simulation {
   Vec3d gravity = {0, -9.8, 0};              // :356
   Vec3d wind = {0.01, 0, 1};                 // :357
   double windNorm = 0.15, windFrequency = 14, windPhase = 0;
+  double k_stiff_attachment = 10000;           // AttachmentSpring::k_stiff (AttachmentSpring.cpp:10)
   Vec3d restShapeMinDim = {0, 0, 0}, restShapeMaxDim = {0, 0, 0}, restShapeMidPoint = {0, 0, 0};
   VecXd rlFixedPointPos;
   std::vector<Spline> controlPointSplines;   // sysMat[0].controlPointSplines
@@ -175,6 +204,14 @@ class Simulation {
 
   void resetSystem();
   void resetSystem(const std::vector<Spline> &controlPoints);   // Simulation.cpp:2858-2862
+  // rollout-level driver of the optimisation demos (csrc/host/optimize.cpp)
+  double calculateLossAndGradient(LossType lossType, LossInfo &lossInfo, VecXd &dL_dx, VecXd &dL_dv, int idx, bool calculateLoss);   // Simulation.cpp:3237-3488
+  void resetSystemWithParams(BackwardTaskInformation &taskConfiguration, ParamInfo &param);                                          // :3490-3584
+  std::vector<BackwardInformation> runBackwardTask(BackwardTaskInformation taskConfiguration, LossType lossType, LossInfo &lossInfo,
+                                                   TaskSolveStatistics &taskStatistics, int FORWARD_STEPS, ParamInfo guess, bool lossOnly,
+                                                   bool skipForward = false);                                                       // :3853-3961
+  void rebuildSystem();          // stiffness / density changed: new constraint weights, masses and system matrix on the device
+  std::vector<std::pair<VecXd, VecXd>> groundTruthForwardRecords;
   void step();
   void stepNN(int idx, const VecXd &x, const VecXd &v, const VecXd &fixedPointPos);
   BackwardInformation stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,

@@ -117,7 +117,8 @@ def test_spline_driven_step_and_spline_gradients(hat):
     gx = f32(rng.standard_normal(3 * 579) * 1e-2); gv = np.zeros_like(gx)
     z = np.zeros_like(gx)
     back = None
-    expect = [np.zeros(3), np.zeros(3)]
+    expect = [np.zeros(s.getParameterNumber()) for s in splines]     # 9 each: the control tasks switch to ENDPOINT_AND_TANGENTS
+    assert all(s.getParameterNumber() == 9 for s in splines)
     for step in reversed(range(1, S + 1)):
         rec = sim.getPastStateInfo(step)
         if back is None:
@@ -131,3 +132,30 @@ def test_spline_driven_step_and_spline_gradients(hat):
     for k in range(2):
         assert np.linalg.norm(expect[k]) > 0
         np.testing.assert_allclose(got[0][k], expect[k], rtol=1e-12, atol=1e-18)
+
+
+def test_optimize_helper_rollout_loss_and_gradient_sphere_demo():
+    """OptimizeHelper.runSimulationAndGetLossGradient on the sphere demo (friction coefficient of the rotating sphere's
+    contact, MATCH_TRAJECTORY against a ground-truth rollout at mu = 0.3; optimization/OptimizationTaskSetup.cpp:176-182):
+    zero loss and gradient at the ground truth, and the gradient at another mu against central finite differences of the
+    loss (whole rollout: reset -> K steps -> loss -> backward sweep, Simulation.cpp:3853-3961)."""
+    d = pytest.importorskip("diffcloth_py")
+    sim = d.makeSim("sphere")
+    helper = d.makeOptimizeHelperWithSim("sphere", sim)
+    assert helper.lossType == d.LossType.MATCH_TRAJECTORY and helper.taskInfo.dL_dmu
+    assert list(helper.paramName) == ["mu"] and helper.paramLowerBound[0] == 0.01 and helper.paramUpperBound[0] == 0.95
+    x_true = helper.getActualParam()
+    np.testing.assert_allclose(x_true, [0.3])
+    recs = helper.runSimulationAndGetLossGradient(x_true)
+    assert len(recs) == helper.forward_steps + 1
+    assert recs[0].loss < 1e-10                                   # the ground-truth rollout reproduces itself (deterministic kernels)
+    x = np.array([0.55])
+    recs = helper.runSimulationAndGetLossGradient(x)
+    g = helper.gradientInfoToVecXd(recs[0])
+    L0 = recs[0].loss
+    assert L0 > 0 and np.isfinite(g).all()
+    eps = 0.02
+    Lp = helper.runSimulationAndGetLoss(x + eps); Lm = helper.runSimulationAndGetLoss(x - eps)
+    fd = (Lp - Lm) / (2 * eps)
+    print(f"\n[optimize helper] loss {L0:.4e} dL/dmu adjoint {g[0]:.4e} finite difference {fd:.4e}")
+    assert abs(g[0] - fd) <= 0.2 * abs(fd) + 1e-9                 # stick/slide switching makes the loss only piecewise smooth in mu
