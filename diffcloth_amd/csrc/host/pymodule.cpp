@@ -258,7 +258,7 @@ PYBIND11_MODULE(diffcloth_py, m) {
   py::class_<OptimizeHelper>(m, "OptimizeHelper")      // python_interface.cpp:337-365
       .def_property_readonly("paramLowerBound", [](const OptimizeHelper &h) { return toNp(h.paramLowerBound); })
       .def_property_readonly("paramUpperBound", [](const OptimizeHelper &h) { return toNp(h.paramUpperBound); })
-      .def_readonly("forward_steps", &OptimizeHelper::FORWARD_STEPS)
+      .def_readwrite("forward_steps", &OptimizeHelper::FORWARD_STEPS)    // writable here (read-only in the reference): shorter rollouts for checks
       .def_readonly("sim", &OptimizeHelper::system, py::return_value_policy::reference)
       .def_readonly("paramLogScaleTransformOn", &OptimizeHelper::paramLogScaleTransformOn)
       .def_readonly("paramName", &OptimizeHelper::paramName)
