@@ -13,7 +13,10 @@
 //   * the search direction p lives in LDS as a float2 (x, y) plane + a float z plane (a neighbour costs one
 //     ds_read_b64 + one ds_read_b32), the residual r and A p in registers, the iterate x in registers for the
 //     first VPT - XL rows of a thread and in the LDS left over by p for the rest: nothing of a CG iteration
-//     touches global memory except the (L2-resident, batch-shared) packet stream.
+//     touches global memory except the (L2-resident, batch-shared) packet stream;
+//   * the per-constraint work of a PD iteration (local projections, friction, right-hand side) runs through the LDS
+//     element windows of dc_winlib.h, and a launch can carry all time steps of a rollout (FwdArgs::nsteps) with the
+//     self-collision detection of each step inlined (dc_selflib.h).
 // Reference: Simulation::step (Simulation.cpp:1043-1428), global solve :1267 (SimplicialLLT::solve) replaced by
 // this PCG on the correction system (see dc_forward.hip header).
 #define DC_KERNEL_TU

@@ -1,7 +1,8 @@
 // pybind11 module `diffcloth_py`: same module name, functions, classes and attribute names as the reference's
 // src/code/python_interface.cpp:164-378, backed by the MI355X stepper. Vectors cross the boundary as numpy float64
-// arrays (the reference uses pybind11/eigen.h, which gives Python exactly that). Additive, batched entry points
-// live on `SimulationBatch` and do not change the reference surface.
+// arrays (the reference uses pybind11/eigen.h, which gives Python exactly that). Additions (makeSimFromMesh, Spline,
+// writable OptimizeHelper.forward_steps, ...) do not change the reference surface; batched rollouts are driven through
+// the C-ABI (diffcloth_amd/capi.py).
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
