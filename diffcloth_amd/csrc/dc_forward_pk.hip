@@ -85,7 +85,10 @@ __device__ __forceinline__ void consume(const int4 (&e)[PB], const float *lp, in
 
 }  // namespace
 
-template <int THREADS, int VPT, int XL>
+// DETECT: the self-collision detection + layering of every step is inlined (fused sweeps with self-collision). It is a
+// template parameter, not a run-time branch: the mere presence of that code in the kernel changes the register allocation
+// of the PCG loop (SpMV 21 k -> 29 k cycles), which runs without it must not pay for.
+template <int THREADS, int VPT, int XL, bool DETECT>
 __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
   const DevSystem &S = *Sp;
   constexpr int NP = THREADS * VPT;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   SelfRec srec = A.self;                      // self contacts of this step's record
   srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
   srec.meta += (size_t) step * A.slot_meta;
-  if (A.inline_detect) {                      // fused sweeps: detection + layering of this step run here (dc_selflib.h)
+  if constexpr (DETECT) {                     // fused sweeps: detection + layering of this step run here (dc_selflib.h)
     self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, (int *) lp);
     __syncthreads();
   }
@@ -398,17 +401,23 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   }   // step
 }
 
-template <int THREADS, int VPT, int XL>
-static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+template <int THREADS, int VPT, int XL, bool DETECT>
+static void launch_pk_inst(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
   if (S.win_ok) lds = std::max(lds, (size_t) S.win_lds_bytes);
   if (A.inline_detect) lds = std::max(lds, sizeof(int) * (size_t) kSelfDetectLdsInts);
   static size_t configured = 0;
   if (lds > configured) {
-    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL, DETECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     configured = lds;
   }
-  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL, DETECT>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+}
+
+template <int THREADS, int VPT, int XL>
+static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+  if (A.inline_detect) launch_pk_inst<THREADS, VPT, XL, true>(S, W, A, B, st);
+  else launch_pk_inst<THREADS, VPT, XL, false>(S, W, A, B, st);
 }
 
 // 512 threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).
