@@ -171,13 +171,17 @@ int dc_step_backward(dc_ctx *ctx, int slot, const double *dL_dxnew, const double
 int dc_get_param_gradients(dc_ctx *ctx, int slot, double *out /*B*8*/);
 
 /* ---- device-resident rollouts (no host copies inside; used by bench.py and batched callers) --------- */
-/* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Asynchronous.   */
+/* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Asynchronous. When the packet
+ * kernel is in use all steps of a rollout run inside ONE launch (each rollout advances on its own, self-collision
+ * detection inlined per step); results are bitwise those of nsteps dc_step_forward calls.                          */
 int dc_rollout_forward(dc_ctx *ctx, int slot, int nsteps);
 /* Seed the carried gradient (dL_dx, dL_dv) on the device: g_x = scale_x * (x[slot] - target), g_v = 0
  * (the MATCH-shape loss gradient of Simulation.cpp:3237-3488); target NULL means the rest shape.        */
 int dc_seed_gradient(dc_ctx *ctx, int slot, const double *target /*3N or NULL*/, double scale_x);
 /* nsteps backward steps from record `slot` down to slot-nsteps+1, carrying (dL_dx, dL_dv) on the device
- * exactly as Simulation::runBackwardTask does (Simulation.cpp:3938-3952). Asynchronous.                 */
+ * exactly as Simulation::runBackwardTask does (Simulation.cpp:3938-3952), all steps in one launch. dL_dmu accumulates
+ * over the steps, the per-step parameter gradients stay readable per slot (dc_get_param_gradients); dL_dx_fixed of the
+ * individual steps is only available through dc_step_backward. Asynchronous.                                        */
 int dc_rollout_backward(dc_ctx *ctx, int slot, int nsteps);
 int dc_get_gradient(dc_ctx *ctx, double *dL_dx, double *dL_dv, double *dL_dmu /*B*num_groups or NULL*/);
 int dc_get_stats(dc_ctx *ctx, int slot, dc_step_stats *fwd /*B or NULL*/, dc_bwd_stats *bwd /*B or NULL*/);
