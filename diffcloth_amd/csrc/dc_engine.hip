@@ -9,6 +9,7 @@
 #include "dc_device.h"
 #include "dc_system.h"
 #include "dc_windows.h"
+#include "dc_packets.h"
 
 using namespace dc;
 
@@ -410,58 +411,17 @@ int dc_build(dc_ctx *c) {
       S.win_ok = 1;
     }
   }
-  {  // packet-ELL copy of the scaled matrix for dc_forward_pk.hip
-    static const int allowed[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20};
-    const int need = (N + 511) / 512;
-    int vpt = 0;
-    for (int a : allowed) if (a >= need) { vpt = a; break; }
-    int bw = 0;
-    for (int r = 0; r < N; r++)
-      for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++) bw = std::max(bw, std::abs(H.P_col[k] - r));
-    S.pk_ok = (vpt > 0 && bw <= 511) ? 1 : 0;
-    S.pk_vpt = vpt; S.pk = nullptr; S.pk_ptr = nullptr; S.pk_n = nullptr; S.sq_dinv = nullptr;
-    if (S.pk_ok) {
-      const int NPk = 512 * vpt, nch = NPk / 64, PBk = 4;
-      std::vector<double> sq(N);
-      for (int i = 0; i < N; i++) sq[i] = std::sqrt((double) dinv[i]);
-      std::vector<float> sqf(NPk, 0.f);
-      for (int i = 0; i < N; i++) sqf[i] = (float) sq[i];
-      std::vector<int> pptr(nch), pn(nch), flat;
-      for (int ch = 0; ch < nch; ch++) {
-        int w = 0;
-        for (int r = 64 * ch; r < std::min(N, 64 * ch + 64); r++) w = std::max(w, H.P_ptr[r + 1] - H.P_ptr[r] - 1);
-        const int np = std::max(PBk, ((w + 2) / 3 + PBk - 1) / PBk * PBk);
-        pptr[ch] = (int) (flat.size() / 4); pn[ch] = np;
-        flat.resize(flat.size() + (size_t) 4 * 64 * np, 0);
-        for (int l = 0; l < 64; l++) {
-          const int r = 64 * ch + l;
-          int kk = r < N ? H.P_ptr[r] : 0;
-          const int kend = r < N ? H.P_ptr[r + 1] : 0;
-          for (int s = 0; s < np; s++) {
-            int bits[3] = {0, 0, 0}, wd = 0;
-            for (int q = 0; q < 3; q++) {
-              int d = 512;
-              while (kk < kend && H.P_col[kk] == r) kk++;          // the diagonal is implicit (= 1 after scaling)
-              if (kk < kend) {
-                const int col = H.P_col[kk];
-                const float v = (float) (H.P_val[kk] * sq[r] * sq[col]);
-                std::memcpy(&bits[q], &v, sizeof(int));
-                d = col - r + 512;
-                kk++;
-              }
-              wd |= d << (10 * q);
-            }
-            const size_t o = 4 * ((size_t) pptr[ch] + (size_t) s * 64 + l);
-            flat[o] = bits[0]; flat[o + 1] = bits[1]; flat[o + 2] = bits[2]; flat[o + 3] = wd;
-          }
-        }
-      }
+  {  // packet-ELL copy of the scaled matrix for dc_forward_pk.hip (dc_packets.h)
+    HostPackets HP;
+    S.pk_ok = 0; S.pk_vpt = 0; S.pk = nullptr; S.pk_ptr = nullptr; S.pk_n = nullptr; S.sq_dinv = nullptr;
+    if (HP.build(H)) {
       const int *pkp;
-      if ((rc = upload<int>(c, &pkp, flat))) return rc;
+      if ((rc = upload<int>(c, &pkp, HP.pk))) return rc;
       S.pk = (const int4 *) pkp;
-      if ((rc = upload<int>(c, &S.pk_ptr, pptr))) return rc;
-      if ((rc = upload<int>(c, &S.pk_n, pn))) return rc;
-      if ((rc = upload<float>(c, &S.sq_dinv, sqf))) return rc;
+      if ((rc = upload<int>(c, &S.pk_ptr, HP.pk_ptr))) return rc;
+      if ((rc = upload<int>(c, &S.pk_n, HP.pk_n))) return rc;
+      if ((rc = upload<float>(c, &S.sq_dinv, HP.sq_dinv))) return rc;
+      S.pk_vpt = HP.vpt; S.pk_ok = 1;
     }
   }
   S.h = (float) p.time_step; S.k_att = (float) p.k_att;

@@ -1,0 +1,24 @@
+// Host-side builder of the packet-ELL copy of the system matrix used by the resident PCG (dc_forward_pk.hip):
+// P symmetrically scaled to unit diagonal (D^-1/2 P D^-1/2, so that plain CG on it is Jacobi-preconditioned CG on P),
+// off-diagonals packed three to a 16-byte packet {v0, v1, v2, d0 | d1 << 10 | d2 << 20} with d = column - row + 512,
+// wave-sliced: chunk c = rows 64c .. 64c+63, packet (s, lane) at pk[4 * (pk_ptr[c] + 64 s + lane)], pk_n[c] packets per
+// row (a multiple of 4). Padding packets are {0, 0, 0, 512 | 512 << 10 | 512 << 20} (value 0 on the row itself).
+#pragma once
+#include <vector>
+#include "dc_system.h"
+
+namespace dc {
+
+struct HostPackets {
+  bool ok = false;
+  int vpt = 0;                    // rows per thread of the 512-thread kernel the tables are padded for (512 * vpt rows)
+  int bandwidth = 0;              // max |column - row| of P
+  std::vector<int> pk;            // 4 ints per packet
+  std::vector<int> pk_ptr, pk_n;  // per 64-row chunk
+  std::vector<float> sq_dinv;     // [512 * vpt] sqrt(1 / P_ii), 0 for padding rows
+
+  // false when the tables cannot be used: N > 10 240 rows or bandwidth > 511
+  bool build(const HostSystem &H);
+};
+
+}  // namespace dc

@@ -91,7 +91,7 @@ bool HostWindows::build(const HostSystem &H, size_t lds_budget) {
   if (best_own == 0) return false;
   // the per-vertex phase runs one owned vertex per thread and round: a window of a whole number of 1024-vertex rounds
   // leaves no mostly-idle last round (1152 owned vertices = 2 rounds for 1024 threads, 3 for 512)
-  if (best_own > 1024 && best_own % 1024 != 0) {
+  if (best.nwin > 1 && best_own > 1024 && best_own % 1024 != 0) {
     const int rounded = best_own / 1024 * 1024;
     Plan p = plan_for(H, rounded, emin, emax);
     best = p; best_own = rounded;
