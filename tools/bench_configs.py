@@ -1,0 +1,52 @@
+"""Developer script: fwd+bwd throughput of the other BASELINE.json configs (C2 T-shirt, C3 hat, C5 sock, dress mesh) with
+device-resident fused rollouts. Not the headline metric (bench.py is); numbers go into DESIGN.md §6."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes, meshes
+from diffcloth_amd import capi
+
+def f32(a): return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+def run(name, B, K, cfg, prims_fn, att, selfc, fwd_tol, orient="FRONT", dim=6.0):
+    V, F = scenes.load_mesh(cfg["mesh"])
+    P, rmin, rmax = scenes.normalise_model(V, orient, dim)
+    P = f32(P)
+    e = capi.Engine(0)
+    e.set_mesh(P, F); e.set_attachments(att)
+    e.set_params(time_step=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], forward_tol=fwd_tol,
+                 backward_tol=5e-4, cg_rel_tol=1e-4, cg_max_iter=2000, gradient_clipping=1, selfcollision_enabled=int(selfc),
+                 adjoint_mode=1, adjoint_rel_tol=1e-6)
+    e.set_primitives(prims_fn(rmin, rmax))
+    e.build()
+    e.alloc_batch(B, K + 2)
+    rng = np.random.default_rng(0)
+    X = np.stack([f32(P.reshape(-1) + 0.001 * rng.standard_normal(P.size)) for _ in range(B)])
+    e.set_state(0, X, np.zeros_like(X))
+    e.rollout_forward(0, 2)
+    e.seed_gradient(2, None, 1e-4); e.rollout_backward(2, 1); e.sync(); e.kernel_times(reset=True)
+    t0 = time.perf_counter()
+    e.rollout_forward(2, K); e.seed_gradient(2 + K, None, 2.0 / ((K + 1) * e.N)); e.rollout_backward(2 + K, K); e.sync()
+    dt = time.perf_counter() - t0
+    kt = e.kernel_times()
+    pd = np.mean([e.get_stats(s)[0]["pd_iters"].mean() for s in range(3, 3 + K)])
+    sc = np.mean([e.get_stats(s)[0]["self_contacts"].mean() for s in range(3, 3 + K)])
+    adj = np.mean([e.get_stats(s)[1]["adjoint_iters"].mean() for s in range(3, 3 + K)])
+    cg = np.mean([e.get_stats(s)[0]["cg_iters"].mean() for s in range(3, 3 + K)])
+    print(f"{name}: N={e.N} B={B} K={K}: {B * K / dt:.0f} rollout-steps/s, {dt / K * 1e3:.2f} ms per batch step "
+          f"(fwd {kt['fwd_ms'] / K:.2f} ms, bwd {kt['bwd_ms'] / K:.2f} ms), mean PD iters {pd:.0f} (PCG {cg / max(pd, 1):.0f} each), BiCGSTAB iters {adj:.0f}, self contacts {sc:.0f}")
+
+hat = lambda rmin, rmax: [dict(kind=capi.DC_PRIM_SPHERE, group=0, center=f32(scenes.hat_head_center(rmin, rmax, 2.1)), radius=2.1, mu=0.1)]
+none = lambda rmin, rmax: []
+def leg(rmin, rmax):
+    c, ch = scenes.sock_leg(rmin, rmax)
+    return [dict(kind=capi.DC_PRIM_SPHERE if k == 0 else capi.DC_PRIM_CAPSULE, group=0, center=f32(c + c0), radius=float(r), mu=0.4, top_offset=f32(t), length=float(l))
+            for k, c0, t, r, l in ch]
+T = scenes.TSHIRT
+run("C2 tshirt (wind off, free fall, self-collision on)", 1, 10, T, none, [], True, 1e-8, "BACK")
+run("C2 tshirt x256", 256, 10, T, none, [], True, 1e-8, "BACK")
+run("C3 hat", 64, 10, scenes.HAT, hat, scenes.HAT["attachments"], False, 1e-8)
+run("C5 sock", 512, 10, scenes.SOCK, leg, scenes.SOCK["attachments"], False, 1e-9, "CUSTOM", 5.0)
+D = dict(mesh="dress", h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
+run("dress (3634 vertices, self-collision on)", 256, 5, D, none, [0, 1, 2, 3, 4, 5], True, 1e-8, "FRONT", 8.0)
