@@ -220,10 +220,16 @@ def test_rollout_on_device_equals_stepwise_calls():
     assert kt["fwd_launches"] == 1 and kt["bwd_launches"] == 1 and kt["fwd_ms"] > 0      # fused sweeps: one launch each
     # the fused backward sweep (all steps of a rollout in one launch) against step-by-step calls through the host boundary
     xS, _ = e.get_state(S)
+    fused_params = [e.get_param_gradients(s) for s in range(1, S + 1)]       # per-slot parameter gradients of the fused sweep
+    fused_stats = [e.get_stats(s)[1]["adjoint_iters"].copy() for s in range(1, S + 1)]
     gx = f32(xS - f32(V.reshape(-1))[None, :]); gv = np.zeros_like(gx)       # dc_seed_gradient(S, rest, 1.0) on the host
     for s in range(S, 0, -1):
         out = e.step_backward(s, gx, gv, is_start=(s == 1))
         gx, gv = out["dL_dx"], out["dL_dv"]
+        pg = e.get_param_gradients(s)
+        for key in ("dL_dk", "dL_ddensity", "sum_dfext"):
+            np.testing.assert_allclose(pg[key], fused_params[s - 1][key], rtol=1e-5, atol=1e-12)
+        np.testing.assert_array_equal(out["adjoint_iters"], fused_stats[s - 1])
     np.testing.assert_allclose(dx, gx, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(dv, gv, rtol=1e-6, atol=1e-9)
 
