@@ -335,3 +335,25 @@ def test_parameter_gradients_match_oracle(mu):
     # sums of signed per-element terms: fp32 rounding of the residual A^T(p - A x) (a small difference of O(1)
     # quantities near equilibrium) bounds these at ~1e-3 relative
     assert np.all(ek <= 5e-3) and ed <= 1e-3 and ew <= 1e-4
+
+
+def test_capped_runs_return_the_best_iterate_like_the_reference():
+    """Simulation.cpp:1357-1367: when the PD iteration cap is hit the step returns the iterate with the smallest update norm.
+    The device tracks it lazily (the best iterate is copied only at the first non-improving iteration after a minimum, from
+    v - delta); every cap from 2 to 16 on a step with contact switching must reproduce the oracle's returned state, and caps beyond the fp32
+    floor (non-monotone update norms: the copy path) must still return a state within tolerance of it."""
+    worst = 0.0
+    for K in list(range(2, 17)) + [24, 32, 40]:      # the last three run past the fp32 floor: the update norm stops decreasing
+        V, F, o, e = build_pair(9, mu=0.05, fwd_tol=1e-30, cap=K, cg_tol=1e-7)
+        x0, v0 = settle(o, V, 38)
+        v0 = f32(v0 + 0.3 * np.sin(np.arange(v0.size)))        # a kick: contacts open and close during the iteration
+        ref = o.step(x0, v0)
+        assert ref["iters"] == K and not ref["converged"]
+        e.alloc_batch(1, 1)
+        e.set_state(0, x0, v0)
+        st = e.step_forward(0)
+        assert st["pd_iters"][0] == K and st["converged"][0] == 0
+        x1, v1 = e.get_state(1)
+        worst = max(worst, np.abs(x1[0] - ref["x"]).max())
+    print(f"\n[best iterate] caps 2..16, 24, 32, 40: worst max|dx| {worst:.3e}")
+    assert worst <= POS_TOL
