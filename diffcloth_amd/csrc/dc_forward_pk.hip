@@ -41,10 +41,20 @@ namespace {
 
 constexpr int PB = 4;   // packets per batch; rows are stored padded to a multiple of PB packets
 
+// Wave-wide sum through DPP row operations (VALU only) instead of six ds_bpermute round trips: quad swaps, row mirrors,
+// then the row_bcast:15 / row_bcast:31 steps that carry the row totals across the wave; the total lands in lane 63.
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xF, true));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>(), integral_constant<int, 0xF>());    // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>(), integral_constant<int, 0xF>());    // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x141>(), integral_constant<int, 0xF>());   // row_half_mirror
+  v += dpp(v, integral_constant<int, 0x140>(), integral_constant<int, 0xF>());   // row_mirror: every lane holds its row's sum
+  v += dpp(v, integral_constant<int, 0x142>(), integral_constant<int, 0xA>());   // row_bcast:15 -> rows 1 and 3 add rows 0 and 2
+  v += dpp(v, integral_constant<int, 0x143>(), integral_constant<int, 0xC>());   // row_bcast:31 -> rows 2, 3 add the lower half
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // fp32 inside a wave, fp64 across the waves (the CG scalars only steer the iteration; the fixed point of the PD
