@@ -51,6 +51,7 @@ struct AdjCtx {
   const float *xnew, *rec_f, *rec_n, *mu;
   const int *rec_prim;
   float *y, *corner, *lds;
+  int lds_floats;               // size of the dynamic LDS region (0 without element windows)
   SelfRec self;
   int nself, b;
 };
@@ -77,7 +78,7 @@ __device__ __forceinline__ void contact_transpose(const DevSystem &S, const AdjC
       st3(y, i, N, z);
     }
     __syncthreads();
-    self_JT_layers<THREADS>(S, C.self, C.b, y);
+    if (!self_JT_layers_lds<THREADS>(S, C.self, C.b, y, C.lds, C.lds_floats)) self_JT_layers<THREADS>(S, C.self, C.b, y);
     for (int i = tid; i < N; i += THREADS) {
       f3 z = ld3(y, i, N);
       st3(y, i, N, z + contact_JT(S, C, i, z));
@@ -234,13 +235,13 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     __syncthreads();
     A.x_new -= A.slot_state; A.rec_f -= A.slot_state; A.rec_n -= A.slot_state; A.rec_prim -= A.slot_prim;
     A.x_prev -= A.slot_state; A.v_prev -= A.slot_state;
-    A.self.pair -= A.slot_self; A.self.nrm -= A.slot_self; A.self.dvec -= A.slot_self; A.self.meta -= A.slot_meta;
+    A.self.pair -= A.slot_self; A.self.nrm -= A.slot_self; A.self.dvec -= A.slot_self; A.self.meta -= A.slot_meta; A.self.verts -= 2 * A.slot_self;
     if (A.d_param) A.d_param -= A.slot_param;
     A.x_fixed -= A.slot_xf; A.stats -= A.slot_stats;
     A.is_start = (A.slot - step == 1) ? 1 : 0;            // isStart: Simulation.cpp:3947
   }
   AdjCtx C;
-  C.lds = dyn_lds;
+  C.lds = dyn_lds; C.lds_floats = WIN ? S.win_lds_bytes / 4 : 0;
   C.xnew = A.x_new + off; C.rec_f = A.rec_f + off; C.rec_n = A.rec_n + off;
   C.rec_prim = A.rec_prim + (size_t) b * N;
   C.mu = A.mu + (size_t) b * S.ngroups;

@@ -112,9 +112,10 @@ struct DevWork {
 // layer_offset[0..nlayers]} with the contacts stored layer by layer.
 struct SelfRec {
   int2 *pair;
-  float4 *nrm;
+  float4 *nrm;        // .w carries the two working-set slots of the contact: slotA | slotB << 16 (as int bits)
   float4 *dvec;
-  int *meta;
+  int *meta;          // [kMetaStride - 1] = number of distinct vertices in the contacts (working-set size)
+  int *verts;         // [2 * cap] vertex of every working-set slot
 };
 
 struct FwdArgs {

@@ -271,4 +271,107 @@ __device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec
   }
 }
 
+// ---- the same two passes inside LDS ----------------------------------------------------------------------------
+// A chain of L contacts takes L layers (contactSorting), each with a handful of contacts: the versions above pay one
+// workgroup barrier and one global-memory round trip per layer. Here the working set (the values of the M distinct
+// vertices of the contacts, the contact records, the layer offsets) is staged into LDS once, ONE wave walks the layers in
+// order (LDS operations of a wave execute in program order, so a layer sees the previous layer's writes without any
+// workgroup barrier), and the results are scattered back. `lds` offers `lds_floats` floats; returns false (nothing done)
+// when the working set does not fit, and the caller takes the global-memory version.
+__device__ __forceinline__ int self_lds_need(int M, int C, int nl) { return 7 * M + 8 * C + nl + 2; }
+
+template <int THREADS>
+__device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, const SelfRec &R, int b, const float *f, float *r,
+                                                         float *lds, int lds_floats) {
+  const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
+  const int *meta = R.meta + (size_t) b * kMetaStride;
+  const int C = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
+  if (self_lds_need(M, C, nl) > lds_floats) return false;
+  const int2 *pair = R.pair + (size_t) b * cap;
+  const float4 *nrm = R.nrm + (size_t) b * cap;
+  float4 *dvec = R.dvec + (size_t) b * cap;
+  const int *verts = R.verts + (size_t) b * 2 * cap;
+  float *lf = lds, *lr = lds + 3 * M, *lim = lds + 6 * M;
+  float4 *ln = (float4 *) (lds + 7 * M + ((4 - (7 * M) % 4) % 4));       // 16-byte aligned
+  float4 *ld = ln + C;
+  int *loff = (int *) (ld + C);
+  (void) pair;
+  for (int s = tid; s < M; s += THREADS) {
+    const int v = verts[s];
+    lf[s] = f[v]; lf[M + s] = f[N + v]; lf[2 * M + s] = f[2 * N + v];
+    lr[s] = r[v]; lr[M + s] = r[N + v]; lr[2 * M + s] = r[2 * N + v];
+    lim[s] = 1.0f / S.mass[v];
+  }
+  for (int k = tid; k < C; k += THREADS) ln[k] = nrm[k];
+  for (int l = tid; l <= nl; l += THREADS) loff[l] = meta[2 + l];
+  __syncthreads();
+  if (tid < 64) {
+    for (int l = 0; l < nl; l++) {
+      const int k1 = loff[l + 1];
+      for (int k = loff[l] + tid; k < k1; k += 64) {
+        const float4 n4 = ln[k];
+        const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
+        const f3 n = mk(n4.x, n4.y, n4.z);
+        const float iA = lim[sa], iB = lim[sb];
+        f3 rA = mk(lr[sa], lr[M + sa], lr[2 * M + sa]), rB = mk(lr[sb], lr[M + sb], lr[2 * M + sb]);
+        f3 d = (mk(lf[sa], lf[M + sa], lf[2 * M + sa]) + rA) * iA - (mk(lf[sb], lf[M + sb], lf[2 * M + sb]) + rB) * iB;
+        ld[k] = make_float4(d.x, d.y, d.z, 0.f);
+        f3 ri = dry_friction(n, d, kClothMu) * (1.0f / (iA + iB));           // k = mA mB / (mA + mB)
+        rA = rA + ri; rB = rB - ri;
+        lr[sa] = rA.x; lr[M + sa] = rA.y; lr[2 * M + sa] = rA.z;
+        lr[sb] = rB.x; lr[M + sb] = rB.y; lr[2 * M + sb] = rB.z;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");             // compiler: keep the layers' LDS accesses in order
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; r[v] = lr[s]; r[N + v] = lr[M + s]; r[2 * N + v] = lr[2 * M + s]; }
+  for (int k = tid; k < C; k += THREADS) dvec[k] = ld[k];
+  __syncthreads();
+  return true;
+}
+
+template <int THREADS>
+__device__ __forceinline__ bool self_JT_layers_lds(const DevSystem &S, const SelfRec &R, int b, float *z, float *lds, int lds_floats) {
+  const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
+  const int *meta = R.meta + (size_t) b * kMetaStride;
+  const int C = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
+  if (self_lds_need(M, C, nl) > lds_floats) return false;
+  const float4 *nrm = R.nrm + (size_t) b * cap;
+  const float4 *dvec = R.dvec + (size_t) b * cap;
+  const int *verts = R.verts + (size_t) b * 2 * cap;
+  float *lz = lds, *lim = lds + 3 * M;
+  float4 *ln = (float4 *) (lds + 7 * M + ((4 - (7 * M) % 4) % 4));
+  float4 *ld = ln + C;
+  int *loff = (int *) (ld + C);
+  for (int s = tid; s < M; s += THREADS) {
+    const int v = verts[s];
+    lz[s] = z[v]; lz[M + s] = z[N + v]; lz[2 * M + s] = z[2 * N + v];
+    lim[s] = 1.0f / S.mass[v];
+  }
+  for (int k = tid; k < C; k += THREADS) { ln[k] = nrm[k]; ld[k] = dvec[k]; }
+  for (int l = tid; l <= nl; l += THREADS) loff[l] = meta[2 + l];
+  __syncthreads();
+  if (tid < 64) {
+    for (int l = nl - 1; l >= 0; l--) {
+      const int k1 = loff[l + 1];
+      for (int k = loff[l] + tid; k < k1; k += 64) {
+        const float4 n4 = ln[k], d4 = ld[k];
+        const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
+        const float iA = lim[sa], iB = lim[sb];
+        f3 zA = mk(lz[sa], lz[M + sa], lz[2 * M + sa]), zB = mk(lz[sb], lz[M + sb], lz[2 * M + sb]);
+        f3 g = dri_dfi_T(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * (1.0f / (iA + iB));
+        zA = zA + g * iA; zB = zB - g * iB;
+        lz[sa] = zA.x; lz[M + sa] = zA.y; lz[2 * M + sa] = zA.z;
+        lz[sb] = zB.x; lz[M + sb] = zB.y; lz[2 * M + sb] = zB.z;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+  }
+  __syncthreads();
+  for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; z[v] = lz[s]; z[N + v] = lz[M + s]; z[2 * N + v] = lz[2 * M + s]; }
+  __syncthreads();
+  return true;
+}
+
 }  // namespace dc

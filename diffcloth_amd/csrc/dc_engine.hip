@@ -40,6 +40,7 @@ struct dc_ctx {
   int2 *SC_pair = nullptr;          // [(tape+1)][B][cap] self contacts per record
   float4 *SC_nrm = nullptr, *SC_d = nullptr;
   int *SC_meta = nullptr;           // [(tape+1)][B][kMetaStride]
+  int *SC_verts = nullptr;          // [(tape+1)][B][2 * cap] working-set vertex lists of the self contacts
   int self_cap = 0;
   float *xf_cur = nullptr;          // [B][3][Af]
   float *XF = nullptr;              // [(tape+1)][B][3][Af] fixed-point targets per record
@@ -132,6 +133,7 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   {
     const size_t sc = (size_t) c->B * c->self_cap * (slot + 1), sm = (size_t) c->B * kMetaStride * (slot + 1);
     A.self.pair = c->SC_pair + sc; A.self.nrm = c->SC_nrm + sc; A.self.dvec = c->SC_d + sc; A.self.meta = c->SC_meta + sm;
+    A.self.verts = c->SC_verts + 2 * sc;
   }
   A.fwd_tol = (float) c->params.forward_tol;
   A.cg_tol = (float) (c->params.cg_rel_tol > 0 ? c->params.cg_rel_tol : 1e-4);
@@ -150,6 +152,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   {
     const size_t sc = (size_t) c->B * c->self_cap * slot, sm = (size_t) c->B * kMetaStride * slot;
     A.self.pair = c->SC_pair + sc; A.self.nrm = c->SC_nrm + sc; A.self.dvec = c->SC_d + sc; A.self.meta = c->SC_meta + sm;
+    A.self.verts = c->SC_verts + 2 * sc;
   }
   A.gx = c->GX; A.gv = c->GV;
   A.ix = with_init ? c->IX : nullptr; A.iv = with_init ? c->IV : nullptr;
@@ -552,6 +555,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
     if ((rc = dev_alloc(c, pool, &c->SC_nrm, (size_t) B * cap * slots))) return rc;
     if ((rc = dev_alloc(c, pool, &c->SC_d, (size_t) B * cap * slots))) return rc;
     if ((rc = dev_alloc(c, pool, &c->SC_meta, (size_t) B * kMetaStride * slots))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->SC_verts, (size_t) B * 2 * cap * slots))) return rc;
     if ((rc = dev_alloc(c, pool, &c->W.sd_cell, (size_t) B * N))) return rc;
     if ((rc = dev_alloc(c, pool, &c->W.sd_order, (size_t) B * N))) return rc;
     if ((rc = dev_alloc(c, pool, &c->W.sd_sx, se))) return rc;

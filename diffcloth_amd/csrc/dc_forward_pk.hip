@@ -125,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
   SelfRec srec = A.self;                      // self contacts of this step's record
   srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
-  srec.meta += (size_t) step * A.slot_meta;
+  srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // fused sweeps: detection + layering of this step run here (dc_selflib.h)
     self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, (int *) lp);
     __syncthreads();
@@ -251,10 +251,12 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     }
     if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
       __syncthreads();
-      self_friction_layers<THREADS>(S, srec, b, rec_f, rec_r);
+      // (the LDS version uses the search-direction planes as scratch: they are rebuilt, padding rows included, below)
+      if (!self_friction_layers_lds<THREADS>(S, srec, b, rec_f, rec_r, lp, 3 * NP)) self_friction_layers<THREADS>(S, srec, b, rec_f, rec_r);
       part = 0.f;
-      for (int i = tid; i < N; i += THREADS) {
-        f3 rhs = (ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i]) * S.sq_dinv[i];
+      for (int i = tid; i < NP; i += THREADS) {
+        f3 rhs = mk(0, 0, 0);
+        if (i < N) rhs = (ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i]) * S.sq_dinv[i];
         ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
         part += dot(rhs, rhs);
       }

@@ -166,7 +166,7 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
   auto v_guess = [&](int i) { const float m = S.mass[i]; return ld3(vn, i, N) + (grav * m + fu) * (h / m); };   // (s_n - x_n) / h
 
   if (!S.contact_enabled || !S.self_enabled) {
-    if (tid == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; }
+    if (tid == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; meta[kMetaStride - 1] = 0; }
     return;
   }
   // ---- 1. bounding box / longest axis / cells (Simulation.cpp:283-300) ----
@@ -311,6 +311,22 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
   }
   __syncthreads();
   for (int k = tid; k < C; k += THREADS) onrm[k] = rawn[k];
+  __syncthreads();
+  // ---- 6. working set of the layered friction passes: the distinct vertices of the contacts get slots 0..M-1 (in order
+  // of first appearance) so that those passes can run inside LDS; slots ride in nrm.w, the vertex list in selfrec.verts
+  if (tid == 0) {
+    int *slot_of = cell;                       // [N] scratch of the detection, free again
+    int *verts = selfrec.verts + (size_t) b * 2 * cap;
+    for (int k = 0; k < C; k++) { slot_of[opair[k].x] = -1; slot_of[opair[k].y] = -1; }
+    int M = 0;
+    for (int k = 0; k < C; k++) {
+      const int2 ab = opair[k];
+      if (slot_of[ab.x] < 0) { slot_of[ab.x] = M; verts[M++] = ab.x; }
+      if (slot_of[ab.y] < 0) { slot_of[ab.y] = M; verts[M++] = ab.y; }
+      onrm[k].w = __int_as_float(slot_of[ab.x] | (slot_of[ab.y] << 16));
+    }
+    meta[kMetaStride - 1] = M;
+  }
 }
 
 
