@@ -1,0 +1,135 @@
+"""GPU parity at BASELINE.json's full size (config C4: 100 x 100 grid cloth, N = 10 000, 256 rollouts on one GPU — the
+bench.py workload) and beyond the packet kernels' size limit (N = 16 384 > 10 240: the global-memory kernels).
+
+At these sizes the fp64 oracle checks two sampled rollouts; the whole batch is covered by size-independent properties:
+  * rollouts are independent and the kernels deterministic: two batch slots fed the same input give bit-identical
+    states and gradients, whatever their neighbours do;
+  * the backward step is linear in the incoming gradient (adjoint of the linearised step, Simulation.cpp:1455-1780);
+  * every rollout converges and reports finite results.
+"""
+import numpy as np
+import pytest
+
+import meshes
+import orc
+from diffcloth_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+H = 1.0 / 180
+FABRIC = dict(density=0.3, k_stretch=150.0, k_bend=1e-5)      # sphereFabric, OptimizationTaskConfigurations.cpp:81-96
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def scene(nx, selfcollision, fwd_tol):
+    V, F = meshes.grid_cloth(nx, nx, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    c = f32(meshes.sphere_scene_center(V, 2.0))
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_params(time_step=H, forward_tol=fwd_tol, backward_tol=1e-9, cg_rel_tol=1e-6, cg_max_iter=3000, gradient_clipping=0,
+                 selfcollision_enabled=int(selfcollision), adjoint_mode=1, adjoint_rel_tol=1e-8, **FABRIC)
+    e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=c, radius=2.0, mu=0.9)])
+    e.build()
+    o = orc.Oracle(V, F, h=H, fwd_tol=fwd_tol, bwd_tol=1e-9, selfcollision=bool(selfcollision), gradient_clipping=False, **FABRIC)
+    o.add_sphere(c, 2.0, 0.9)
+    o.build()
+    return V, F, e, o
+
+
+def start_states(V, B, twins):
+    """bench.py's per-rollout start: the cloth shifted over the sphere, own friction coefficient; `twins` = pairs of
+    batch slots that get the same input."""
+    X = np.empty((B, V.size)); MU = np.empty((B, 1))
+    for b in range(B):
+        rng = np.random.default_rng(1000 + b)
+        shift = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.09, -0.02), rng.uniform(-0.5, 0.5)])
+        X[b] = f32((V + shift).reshape(-1)); MU[b, 0] = rng.uniform(0.1, 0.9)
+    for a, b in twins:
+        X[b] = X[a]; MU[b] = MU[a]
+    return X, f32(MU)
+
+
+def check_against_oracle(o, e, step, sample, MU, gx, gv, st, gb, pos_tol, grad_tol):
+    xs, vs = e.get_state(step)
+    x1, v1 = e.get_state(step + 1)
+    for b in sample:
+        o.set_mu(0, float(MU[b, 0]))
+        ref = o.step(xs[b], vs[b])
+        assert ref["converged"] and st["prim_contacts"][b] == ref["nprim"] and st["self_contacts"][b] == ref["nself"]
+        rb = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
+        dx = np.abs(x1[b] - ref["x"]).max()
+        ex, ev = rel(gb["dL_dx"][b], rb["dL_dx"]), rel(gb["dL_dv"][b], rb["dL_dv"])
+        print(f"\n[full size] rollout {b}: contacts {ref['nprim']}, PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}, "
+              f"max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
+        assert dx <= pos_tol
+        assert ex <= grad_tol and ev <= grad_tol
+
+
+def test_c4_10k_vertices_batch_256():
+    B, W = 256, 5
+    V, F, e, o = scene(100, selfcollision=True, fwd_tol=1e-8)
+    assert e.N == 10000
+    twins = [(3, 200), (0, 255)]
+    X0, MU = start_states(V, B, twins)
+    e.alloc_batch(B, W + 1)
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    e.rollout_forward(0, W)                                   # contact onset, all steps of a rollout in one launch
+    st = e.step_forward(W)
+    rng = np.random.default_rng(11)
+    g1x = f32(rng.standard_normal(X0.shape)); g1v = f32(0.01 * rng.standard_normal(X0.shape))
+    g2x = f32(rng.standard_normal(X0.shape)); g2v = f32(0.01 * rng.standard_normal(X0.shape))
+    for a, b in twins:
+        for g in (g1x, g1v, g2x, g2v):
+            g[b] = g[a]
+    gb1 = e.step_backward(W + 1, g1x, g1v, is_start=False)
+    gb2 = e.step_backward(W + 1, g2x, g2v, is_start=False)
+    gb3 = e.step_backward(W + 1, f32(g1x + 2 * g2x), f32(g1v + 2 * g2v), is_start=False)
+    assert np.all(np.isin(st["converged"], (1, 2))) and np.all(np.isin(gb1["converged"], (1, 2)))
+    assert st["prim_contacts"].min() > 0, "every rollout touches the sphere after the warm-up steps"
+    x1, v1 = e.get_state(W + 1)
+    assert np.isfinite(x1).all() and np.isfinite(v1).all() and np.isfinite(gb1["dL_dx"]).all()
+    # batch slots are independent and deterministic
+    for a, b in twins:
+        assert np.array_equal(x1[a], x1[b]) and np.array_equal(v1[a], v1[b])
+        assert np.array_equal(gb1["dL_dx"][a], gb1["dL_dx"][b]) and np.array_equal(gb1["dL_dv"][a], gb1["dL_dv"][b])
+        assert st["pd_iters"][a] == st["pd_iters"][b] and st["cg_iters"][a] == st["cg_iters"][b]
+    # linearity of the adjoint step over the whole batch (seed g1 + 2 g2 is rounded to fp32: 1e-7 relative)
+    worst = 0.0
+    for key in ("dL_dx", "dL_dv"):
+        lin = gb1[key] + 2 * gb2[key]
+        err = np.linalg.norm(gb3[key] - lin, axis=1) / np.linalg.norm(lin, axis=1)
+        worst = max(worst, err.max())
+    print(f"\n[full size] B={B} N={e.N}: PD iterations {st['pd_iters'].min()}..{st['pd_iters'].max()}, contacts "
+          f"{st['prim_contacts'].min()}..{st['prim_contacts'].max()}, adjoint linearity worst rel err {worst:.2e}")
+    assert worst <= 2e-5
+    check_against_oracle(o, e, W, (0, 137), MU, g1x, g1v, st, gb1, pos_tol=5e-5, grad_tol=1e-4)
+
+
+def test_mesh_beyond_the_packet_kernel_limit():
+    """128 x 128 grid: N = 16 384 vertices do not fit the LDS-resident kernels (N <= 10 240); the engine must take its
+    global-memory kernels by itself and stay within the same tolerances."""
+    B, W = 3, 4
+    V, F, e, o = scene(128, selfcollision=False, fwd_tol=1e-8)
+    assert e.N == 16384
+    X0, MU = start_states(V, B, [])
+    e.alloc_batch(B, W + 1)
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    for s in range(W):
+        e.step_forward(s)
+    st = e.step_forward(W)
+    rng = np.random.default_rng(12)
+    gx = f32(rng.standard_normal(X0.shape)); gv = f32(0.01 * rng.standard_normal(X0.shape))
+    gb = e.step_backward(W + 1, gx, gv, is_start=False)
+    assert np.all(np.isin(st["converged"], (1, 2))) and np.all(np.isin(gb["converged"], (1, 2)))
+    assert st["prim_contacts"].min() > 0
+    check_against_oracle(o, e, W, (1,), MU, gx, gv, st, gb, pos_tol=5e-5, grad_tol=1e-4)
