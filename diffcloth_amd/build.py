@@ -61,7 +61,7 @@ def build_pymodule(force=False, verbose=False):
     import sysconfig
     import pybind11
     host = os.path.join(CSRC, "host")
-    srcs = [os.path.join(host, s) for s in ("simulation.cpp", "scene_tables.cpp", "optimize.cpp", "pymodule.cpp")]
+    srcs = [os.path.join(host, s) for s in ("simulation.cpp", "scene_tables.cpp", "optimize.cpp", "export.cpp", "pymodule.cpp")]
     out = os.path.join(LIBDIR, "diffcloth_py" + sysconfig.get_config_var("EXT_SUFFIX"))
     deps = srcs + [os.path.join(host, "simulation.h"), os.path.join(host, "optimize.h"), os.path.join(ROOT, "include", "diffcloth_hip.h"), LIB]
     if not force and not _stale(out, deps):

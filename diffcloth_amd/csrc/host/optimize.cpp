@@ -171,6 +171,7 @@ std::vector<BackwardInformation> Simulation::runBackwardTask(BackwardTaskInforma
   const double L = calculateLossAndGradient(lossType, lossInfo, dL_dlastx, dL_dlastv, frames - 1, true);
   forwardRecords.back().loss = L;
   stats.totalForwardSim++;
+  stats.completeForwardLog.emplace_back(guess, forwardRecords.back());
   if (lossOnly) { first.loss = L; return {first}; }
   BackwardInformation derivative;
   derivative.dL_dx = dL_dlastx; derivative.dL_dv = dL_dlastv; derivative.loss = L;
@@ -184,7 +185,9 @@ std::vector<BackwardInformation> Simulation::runBackwardTask(BackwardTaskInforma
     all.push_back(derivative);
   }
   std::reverse(all.begin(), all.end());
+  all[0].correspondingForwardIdxInStats = stats.totalForwardSim - 1;
   stats.totalBackprop++;
+  stats.completeBackwardLog.emplace_back(guess, all[0]);
   return all;
 }
 
@@ -347,6 +350,23 @@ double OptimizeHelper::runSimulationAndGetLoss(const VecXd &x) {
 std::vector<BackwardInformation> OptimizeHelper::runSimulationAndGetLossAndGradients(const VecXd &x) {
   ParamInfo param = vecXdToParamInfo(x);
   return system->runBackwardTask(taskInfo, lossType, lossInfo, statistics, FORWARD_STEPS, param, false);
+}
+
+void OptimizeHelper::saveLastIter() {
+  system->backwardOptimizationRecords.emplace_back(lastBackwardOptRecord);
+  system->backwardOptimizationGuesses.push_back(lastGuess);
+  system->exportStatistics(demoNum, statistics, taskInfo);
+}
+
+double OptimizeHelper::operator()(const VecXd &x, VecXd &grad) {
+  iter++;
+  ParamInfo param = vecXdToParamInfo(x);
+  std::vector<BackwardInformation> records = system->runBackwardTask(taskInfo, lossType, lossInfo, statistics, FORWARD_STEPS, param, false);
+  lastBackwardOptRecord = {system->forwardRecords, records};
+  lastGuess = {param, records[0].loss};
+  if (exportEveryEvaluation) saveLastIter();
+  grad = gradientInfoToVecXd(records[0]);
+  return records[0].loss;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -38,6 +38,14 @@ class OptimizeHelper {
   VecXd getRandomParam(int randSeed = 0);
   double runSimulationAndGetLoss(const VecXd &x);
   std::vector<BackwardInformation> runSimulationAndGetLossAndGradients(const VecXd &x);
+  // The L-BFGS callback of the reference (OptimizeHelper::operator(), OptimizeHelper.cpp:533-575) without its render
+  // window: one rollout + backward sweep, the iteration is recorded and written to disk (saveLastIter), returns the loss.
+  double operator()(const VecXd &x, VecXd &grad);
+  void saveLastIter();            // OptimizeHelper.cpp:528-532
+  int demoNum = 0, iter = 0;
+  bool exportEveryEvaluation = true;
+  std::pair<std::vector<ForwardInformation>, std::vector<BackwardInformation>> lastBackwardOptRecord;
+  std::pair<ParamInfo, double> lastGuess;
 
  private:
   void setParameterBounds();

@@ -222,6 +222,12 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def("setPrintVerbose", &Simulation::setPrintVerbose, "set whether to print verbose info", py::arg("flag"))
       .def("getPastStateInfo", &Simulation::getPastStateInfo, "get the forward info of a past time step", py::arg("stepIdx"))
       .def("exportCurrentSimulation", &Simulation::exportCurrentSimulation, "export the simulation to files", py::arg("fileName"))
+      // on-disk formats beyond the reference's Python surface (its C++ side: Simulation.cpp:4003-4238, Simulation.h:574-620)
+      .def_readwrite_static("outputRoot", &Simulation::outputRoot)
+      .def("exportSimulation", [](Simulation &s, const std::string &name) { s.exportSimulation(name, s.forwardRecords); },
+           "write <name>/<i>.obj + info.txt, the layout the reference's viewer replays", py::arg("fileName"))
+      .def("resetForwardRecordsFromFolder", &Simulation::resetForwardRecordsFromFolder, "append one record per <i>.obj of the folder", py::arg("subFolder"))
+      .def_static("parameterToString", &Simulation::parameterToString, py::arg("taskInfo"), py::arg("param"))
       .def("stepBackward",
            [](Simulation &s, BackwardTaskInformation &ti, BackwardInformation &g, const ForwardInformation &f, bool isStart, const NpArr &ix, const NpArr &iv) {
              return s.stepBackward(ti, g, f, isStart, toVec(ix), toVec(iv));
@@ -277,8 +283,17 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def("gradientInfoToVecXd", [](const OptimizeHelper &h, const BackwardInformation &g) { return toNp(h.gradientInfoToVecXd(g)); },
            "convert grad struct to grad vector", py::arg("grad"))
       .def("runSimulationAndGetLossGradient", [](OptimizeHelper &h, const NpArr &x) { return h.runSimulationAndGetLossAndGradients(toVec(x)); },
-           "compute loss and grads from parameter vector", py::arg("x"));
+           "compute loss and grads from parameter vector", py::arg("x"))
+      .def_readwrite("exportEveryEvaluation", &OptimizeHelper::exportEveryEvaluation)
+      .def_property_readonly("experimentName", [](OptimizeHelper &h) { return h.statistics.experimentName; })
+      .def("evaluate", [](OptimizeHelper &h, const NpArr &x) { VecXd g; const double L = h(toVec(x), g); return py::make_tuple(L, toNp(g)); },
+           "the reference's L-BFGS callback (OptimizeHelper::operator()), headless: loss, flat gradient; logs the iteration to disk", py::arg("x"));
 
+  m.def("loadObjFile", [](const std::string &file) {
+    VecXd pts; std::vector<int> tris;
+    if (!Simulation::loadObjFile(file, pts, tris)) throw std::runtime_error("cannot read " + file);
+    return py::make_tuple(toNp(pts), py::array_t<int>((py::ssize_t) tris.size(), tris.data()));
+  }, "read the v / f records of an OBJ file (flat xyz array, flat 0-based triangle array)", py::arg("file"));
   m.def("makeSim", &makeSim, "initialize a simulation instance", py::arg("exampleName"), py::arg("runBackward") = true);
   m.def("makeSimFromMesh",
         [](const std::string &sceneName, const NpArr &verts, const std::vector<int> &tris, bool runBackward) {

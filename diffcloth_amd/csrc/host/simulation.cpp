@@ -3,6 +3,7 @@
 // (reference Simulation.cpp:1804-2067, 2170-2405, 2611-2757); the per-step work is delegated to the dc_* C-ABI.
 #include "simulation.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -517,6 +518,7 @@ VecXd Simulation::fixedPointTargets(double t) {
 
 void Simulation::step() {
   if ((int) forwardRecords.size() >= tapeSlots) throw std::runtime_error("Simulation::step: tape exhausted (stepNum + 8 records)");
+  const auto tStart = std::chrono::steady_clock::now();
   pushParams();
   const ForwardInformation &prev = forwardRecords.back();
   ForwardInformation rec;
@@ -558,6 +560,7 @@ void Simulation::step() {
   rec.totalConverged = prev.totalConverged + (rec.converged ? 1 : 0);
   rec.cumulateIter = prev.cumulateIter + st.pd_iters;
   rec.s_n.assign(3 * (size_t) N, 0.0);
+  rec.totalRuntime = prev.totalRuntime + std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tStart).count();
   forwardRecords.push_back(std::move(rec));
 }
 
@@ -590,6 +593,7 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
   if (gradient_new.dL_dx.size() != n3 || gradient_new.dL_dv.size() != n3) throw std::runtime_error("stepBackward: gradient size mismatch");
   if (fwd.deviceSlot < 1 || fwd.deviceSlot >= (int) forwardRecords.size() + 1) throw std::runtime_error("stepBackward: record has no device slot");
+  const auto tStart = std::chrono::steady_clock::now();
   pushParams();
   BackwardInformation ret;
   ret.dL_dx.resize(n3); ret.dL_dv.resize(n3);
@@ -656,17 +660,8 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
       double prev = k < gradient_new.dL_dmu.size() ? gradient_new.dL_dmu[k].second : 0.0;
       ret.dL_dmu.push_back({prim, prev + (prim >= 0 && prim < (int) dmu.size() ? dmu[prim] : 0.0)});
     }
+  ret.totalRuntime = gradient_new.totalRuntime + std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tStart).count();
   return ret;
-}
-
-void Simulation::exportCurrentMeshPos(int step, const std::string &fileName) const {   // OBJ frame dump (Simulation.cpp:4131-4238)
-  const ForwardInformation &r = forwardRecords.at(step);
-  std::ofstream out(fileName + ".obj");
-  for (int i = 0; i < N; i++) out << "v " << r.x[3 * i] << " " << r.x[3 * i + 1] << " " << r.x[3 * i + 2] << "\n";
-  for (size_t t = 0; t < tris.size() / 3; t++) out << "f " << tris[3 * t] + 1 << " " << tris[3 * t + 1] + 1 << " " << tris[3 * t + 2] + 1 << "\n";
-}
-void Simulation::exportCurrentSimulation(const std::string &fileName) const {
-  for (size_t s = 0; s < forwardRecords.size(); s++) exportCurrentMeshPos((int) s, fileName + "_" + std::to_string(s));
 }
 
 }  // namespace dchost

@@ -109,6 +109,7 @@ struct ForwardInformation {       // Simulation.h:68-100 (hot-path fields)
   bool converged = false;
   int convergeIter = 0, totalConverged = 0, cumulateIter = 0, stepIdx = 0;
   double loss = 0;
+  long long totalRuntime = 0;     // microseconds spent in step() up to and including this record (Simulation.cpp:1396-1397)
   double simDurartionFraction = 0;   // (sic) t / (timeStep * stepNum), the spline parameter of this step
   std::vector<Spline> splines;
   int deviceSlot = 0;             // tape slot of libdiffcloth_hip holding this record
@@ -126,6 +127,7 @@ struct BackwardInformation {      // Simulation.h:136-162 (hot-path fields)
   long long totalRuntime = 0;
   bool converged = false;
   int convergedAccum = 0, backwardIters = 0, backwardTotalIters = 0;
+  int correspondingForwardIdxInStats = 0;
 };
 
 struct BackwardTaskInformation {  // Simulation.h:188-209
@@ -168,7 +170,14 @@ struct ParamInfo {                // Simulation.h:120-133
   std::vector<std::pair<int, double>> mu;
 };
 
-struct TaskSolveStatistics { int totalForwardSim = 0, totalBackprop = 0; };   // Simulation.h:221-250 (counters only)
+struct TaskSolveStatistics {      // Simulation.h:221-250
+  int totalForwardSim = 0, totalBackprop = 0;
+  int optimizationRecordsSaved = 0, forwardWritten = 0, backwardWritten = 0;
+  bool configWritten = false;
+  std::string experimentName;
+  std::vector<std::pair<ParamInfo, ForwardInformation>> completeForwardLog;     // last frame of every forward run
+  std::vector<std::pair<ParamInfo, BackwardInformation>> completeBackwardLog;   // first frame of every backward sweep
+};
 
 class Simulation {
  public:
@@ -229,8 +238,24 @@ class Simulation {
   void setPrintVerbose(bool v) { printVerbose = v; }
   void setWindAncCollision(bool wind_, bool collision, bool selfCollision, bool constantForceField);
   void appendPerStepGradient(const VecXd &x) { perStepGradient.push_back(x); }
+  // ---- on-disk formats (export.cpp); every path is relative to outputFolder() ----
+  static std::string outputRoot;   // "" -> $DIFFCLOTH_OUTPUT, else "output" (the reference writes to SOURCE_PATH/output/)
+  static std::string outputFolder();
+  static bool loadObjFile(const std::string &file, VecXd &points, std::vector<int> &triangles);
   void exportCurrentMeshPos(int step, const std::string &fileName) const;
   void exportCurrentSimulation(const std::string &fileName) const;
+  void exportSimulation(const std::string &fileName, const std::vector<ForwardInformation> &records) const;
+  void exportFrameInfo(const ForwardInformation &record, const std::string &file) const;
+  int resetForwardRecordsFromFolder(const std::string &subFolder);    // appends one record per "<i>.obj"; returns the frame count
+  void exportStatistics(int demoIdx, TaskSolveStatistics &statistics, const BackwardTaskInformation &taskInfo, bool writePerf = true);
+  static std::string taskInfoToString(const BackwardTaskInformation &taskInfo);
+  static std::string parameterToString(const BackwardTaskInformation &taskInfo, const ParamInfo &param);
+  static std::string forwardInfoToString(const BackwardTaskInformation &taskInfo, const ForwardInformation &record);
+  static std::string backwrdInfoAndGradToString(const BackwardTaskInformation &taskInfo, const BackwardInformation &grad);   // (sic)
+  double meshArea(const VecXd &x) const;
+  // records of the optimisation iterations kept for exportStatistics (Simulation.h:441-443)
+  std::vector<std::pair<std::vector<ForwardInformation>, std::vector<BackwardInformation>>> backwardOptimizationRecords;
+  std::vector<std::pair<ParamInfo, double>> backwardOptimizationGuesses;
   const VecXd &restPositions() const { return rest; }
   const std::vector<int> &triangles() const { return tris; }
   const std::vector<int> &attachments() const { return attachmentVertices; }
