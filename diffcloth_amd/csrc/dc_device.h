@@ -62,6 +62,9 @@ struct DevSystem {
   const int DC_C *pk_n;
   const float DC_G *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
+  // explicit inverse of the scaled matrix for small meshes (dc_dense.h): [N + pad][dense_ld] fp32, null = not built
+  const float DC_G *dense_inv;
+  int dense_ld;
   // vertex renumbering (bandwidth reduction, dc_engine.hip): device index <-> caller's index; null = identity
   const int DC_G *user_of;           // [N] device -> caller
   const int DC_G *dev_of;            // [N] caller -> device

@@ -10,6 +10,7 @@
 #include "dc_system.h"
 #include "dc_windows.h"
 #include "dc_packets.h"
+#include "dc_dense.h"
 
 using namespace dc;
 
@@ -425,6 +426,16 @@ int dc_build(dc_ctx *c) {
       if ((rc = upload<int>(c, &S.pk_n, HP.pk_n))) return rc;
       if ((rc = upload<float>(c, &S.sq_dinv, HP.sq_dinv))) return rc;
       S.pk_vpt = HP.vpt; S.pk_ok = 1;
+    }
+  }
+  {  // small meshes: explicit inverse of the scaled matrix (dc_dense.h) for the forward global step
+    HostDense HD;
+    const char *envd = getenv("DC_DENSE_MAX_N");   // development switch: 0 disables, other values move the size limit
+    const int max_n = envd ? atoi(envd) : 768;          // 2.4 MB: the matrix must stay in every XCD's 4 MB L2 next to the other tables
+    S.dense_inv = nullptr; S.dense_ld = 0;
+    if (S.pk_ok && S.win_ok && HD.build(H, max_n)) {
+      if ((rc = upload<float>(c, &S.dense_inv, HD.inv))) return rc;
+      S.dense_ld = HD.ld;
     }
   }
   S.h = (float) p.time_step; S.k_att = (float) p.k_att;

@@ -22,6 +22,7 @@
 #define DC_KERNEL_TU
 #include "dc_devlib.h"
 #include "dc_winlib.h"
+#include "dc_denselib.h"
 #include "dc_selflib.h"
 #include <algorithm>
 
@@ -98,7 +99,7 @@ __device__ __forceinline__ void consume(const int4 (&e)[PB], const float *lp, in
 // DETECT: the self-collision detection + layering of every step is inlined (fused sweeps with self-collision). It is a
 // template parameter, not a run-time branch: the mere presence of that code in the kernel changes the register allocation
 // of the PCG loop (SpMV 21 k -> 29 k cycles), which runs without it must not pay for.
-template <int THREADS, int VPT, int XL, bool DETECT>
+template <int THREADS, int VPT, int XL, bool DETECT, bool DENSE>
 __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
   const DevSystem &S = *Sp;
   constexpr int NP = THREADS * VPT;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   constexpr int XR = VPT - XL;
   extern __shared__ float lp[];          // search direction: float2 (x, y) [NP] then float z [NP]; then x rows [XL][3][THREADS]
   float *lx = lp + 3 * NP;
+  float *ldense = lp + 3 * THREADS * (VPT + XL);      // DENSE: partial sums of the product with the explicit inverse
   __shared__ double red[THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,7 +278,73 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       }
     }
     PH(1)
+    // ap = Ahat * (the vector in lp), part2 += <lp, ap>; rows of a thread tid + k * THREADS
+    auto spmv = [&](int wz, float &part2) {
+      int4 nxt[PB];
+      load_batch(nxt, S.pk + S.pk_ptr[wz] + lane, 0);
+#pragma unroll
+      for (int k = 0; k < VPT; k++) {
+        const int chunk = wz + k * WAVES;   // wave-uniform: pk_ptr / pk_n are scalar loads
+        const int i = chunk * 64 + lane;
+        const int np = S.pk_n[chunk];
+        const int4 *row = S.pk + S.pk_ptr[chunk] + lane;
+        int4 cur[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) cur[j] = nxt[j];
+        if (k + 1 < VPT) load_batch(nxt, S.pk + S.pk_ptr[chunk + WAVES] + lane, 0);
+        const float2 pxy = ((const float2 *) lp)[i];
+        const float pz = lp[2 * NP + i];
+        float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
+        const int base = i - 512;
+        consume<NP>(cur, lp, base, ax, ay, az);
+        for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
+          load_batch(cur, row, s0);
+          consume<NP>(cur, lp, base, ax, ay, az);
+        }
+        ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
+        part2 += pxy.x * ax + pxy.y * ay + pz * az;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     // ---- global step: Jacobi PCG on P dv = rhs as plain CG on the scaled system, resident in LDS + registers ----
+    if constexpr (DENSE) {
+      // ---- small meshes: dv = Ahat^-1 rhs by the explicit fp32 inverse (dc_denselib.h) + iterative refinement with the
+      // packet SpMV until the same stopping rule holds (relative residual <= cg_tol); lp holds the current residual ----
+      if (rz > 1e-300) {
+        const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+        for (int it = 0; it < A.cg_max;) {
+          __syncthreads();
+          int zs;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+          const int wz = wv + zs, tz = tid + zs;
+          const int C = dense_partials<THREADS>(S, (const float2 *) lp, lp + 2 * NP, ldense);
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < VPT; k++) {            // z = Ahat^-1 r : accumulate into the iterate, hand to the SpMV
+            const int i = tz + k * THREADS;
+            const f3 z = dense_row_sum(ldense, S.dense_ld, C, i);
+            xx[k][0] += z.x; xx[k][1] += z.y; xx[k][2] += z.z;
+            ((float2 *) lp)[i] = make_float2(z.x, z.y); lp[2 * NP + i] = z.z;
+          }
+          __syncthreads();
+          float part2 = 0.f;
+          spmv(wz, part2);
+          part2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < VPT; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { rr[k][c] -= ap[k][c]; part2 = fmaf(rr[k][c], rr[k][c], part2); }
+          const double rz_new = block_sum_f<THREADS>(part2, red);      // (its barriers order the lp reads above and the writes below)
+          it++; cg_total++;
+          if (!(rz_new > stop)) break;
+#pragma unroll
+          for (int k = 0; k < VPT; k++) {
+            const int i = tz + k * THREADS;
+            ((float2 *) lp)[i] = make_float2(rr[k][0], rr[k][1]); lp[2 * NP + i] = rr[k][2];
+          }
+        }
+      }
+    } else
     if (rz > 1e-300) {
       const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
       for (int it = 0; it < A.cg_max;) {
@@ -285,31 +353,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         int zs;                               // opaque zero: keeps the per-row addresses out of LICM's reach (they
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));   // would be hoisted into ~60 live registers otherwise)
         const int wz = wv + zs, tz = tid + zs;
-        int4 nxt[PB];
-        load_batch(nxt, S.pk + S.pk_ptr[wz] + lane, 0);
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int chunk = wz + k * WAVES;   // wave-uniform: pk_ptr / pk_n are scalar loads
-          const int i = chunk * 64 + lane;
-          const int np = S.pk_n[chunk];
-          const int4 *row = S.pk + S.pk_ptr[chunk] + lane;
-          int4 cur[PB];
-#pragma unroll
-          for (int j = 0; j < PB; j++) cur[j] = nxt[j];
-          if (k + 1 < VPT) load_batch(nxt, S.pk + S.pk_ptr[chunk + WAVES] + lane, 0);
-          const float2 pxy = ((const float2 *) lp)[i];
-          const float pz = lp[2 * NP + i];
-          float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
-          const int base = i - 512;
-          consume<NP>(cur, lp, base, ax, ay, az);
-          for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
-            load_batch(cur, row, s0);
-            consume<NP>(cur, lp, base, ax, ay, az);
-          }
-          ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
-          part2 += pxy.x * ax + pxy.y * ay + pz * az;
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        spmv(wz, part2);
         PH(2)
         const double pAp = block_sum_f<THREADS>(part2, red);
         PH(3)
@@ -413,23 +457,31 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   }   // step
 }
 
-template <int THREADS, int VPT, int XL, bool DETECT>
+template <int THREADS, int VPT, int XL, bool DETECT, bool DENSE>
 static void launch_pk_inst(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
+  if (DENSE) lds += sizeof(float) * (size_t) dense_lds_floats(S.dense_ld, THREADS / 64);
   if (S.win_ok) lds = std::max(lds, (size_t) S.win_lds_bytes);
   if (A.inline_detect) lds = std::max(lds, sizeof(int) * (size_t) kSelfDetectLdsInts);
   static size_t configured = 0;
   if (lds > configured) {
-    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL, DETECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     configured = lds;
   }
-  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL, DETECT>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
 
 template <int THREADS, int VPT, int XL>
 static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
-  if (A.inline_detect) launch_pk_inst<THREADS, VPT, XL, true>(S, W, A, B, st);
-  else launch_pk_inst<THREADS, VPT, XL, false>(S, W, A, B, st);
+  if constexpr (VPT <= 3) {     // small meshes: the explicit-inverse solve when the engine built it (dc_dense.h)
+    if (S.dense_inv) {
+      if (A.inline_detect) launch_pk_inst<THREADS, VPT, XL, true, true>(S, W, A, B, st);
+      else launch_pk_inst<THREADS, VPT, XL, false, true>(S, W, A, B, st);
+      return;
+    }
+  }
+  if (A.inline_detect) launch_pk_inst<THREADS, VPT, XL, true, false>(S, W, A, B, st);
+  else launch_pk_inst<THREADS, VPT, XL, false, false>(S, W, A, B, st);
 }
 
 // 512 threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).

@@ -26,7 +26,6 @@ std::string Simulation::outputRoot = "";
 
 namespace {
 const char *kConstraintNames[4] = {"CONSTRAINT_SPRING_STRETCH", "CONSTRAINT_ATTACHMENT", "CONSTRAINT_TRIANGLE", "CONSTRAINT_TRIANGLE_BENDING"};
-const char *kSplineNames[3] = {"ENDPOINT", "ENDPOINT_AND_UP", "ENDPOINT_AND_TANGENTS"};
 const char *kWindNames[5] = {"NO_WIND", "WIND_CONSTANT", "WIND_SIN", "WIND_SIN_AND_FALLOFF", "WIND_FACTOR_PER_STEP"};
 
 std::string fixedStr(double v, int precision = 2) {

@@ -11,6 +11,7 @@
 #include <random>
 #include <vector>
 #include "dc_packets.h"
+#include "dc_dense.h"
 #include "dc_system.h"
 #include "dc_windows.h"
 
@@ -191,6 +192,38 @@ int main() {
   HostPackets P3;
   if (P3.build(H3)) fail("packets: a bandwidth > 511 must be refused");
   std::printf("ok refusal bandwidth=%d\n", P3.bandwidth);
+  // 4. explicit inverse of the scaled matrix of a small mesh (dc_dense.h): symmetric, zero padded, Ahat * inv = I to fp32
+  {
+    grid(24, 20, false, pos, tri);
+    HostSystem H4;
+    if (!H4.set_mesh(24 * 20, pos.data(), (int) tri.size() / 3, tri.data()) || !H4.build_numerics(1.0 / 100, 0.224, 1200.0, 120.0, 1e4)) fail("small system");
+    HostDense D;
+    if (!D.build(H4, 768)) fail("dense: build refused");
+    const int n = H4.N;
+    if (D.n != n || D.ld != 512 || D.rows != n + kDensePadRows || D.inv.size() != (size_t) D.rows * D.ld) fail("dense: layout");
+    for (int i = 0; i < D.rows; i++)
+      for (int j = 0; j < D.ld; j++) {
+        const float v = D.inv[(size_t) i * D.ld + j];
+        if ((i >= n || j >= n) && v != 0.f) fail("dense: padding must be zero");
+        if (i < n && j < n && v != D.inv[(size_t) j * D.ld + i]) fail("dense: not symmetric");
+      }
+    std::vector<double> s(n);
+    for (int i = 0; i < n; i++)
+      for (int k = H4.P_ptr[i]; k < H4.P_ptr[i + 1]; k++) if (H4.P_col[k] == i) s[i] = std::sqrt(1.0 / H4.P_val[k]);
+    double worst = 0;
+    for (int c = 0; c < n; c += 37) {           // columns of Ahat * inv against the identity
+      for (int i = 0; i < n; i++) {
+        double acc = 0;
+        for (int k = H4.P_ptr[i]; k < H4.P_ptr[i + 1]; k++) acc += H4.P_val[k] * s[i] * s[H4.P_col[k]] * (double) D.inv[(size_t) H4.P_col[k] * D.ld + c];
+        worst = std::max(worst, std::fabs(acc - (i == c ? 1.0 : 0.0)));
+      }
+    }
+    std::printf("dense defect=%.2e worst=%.2e\n", D.defect, worst);
+    if (!(worst < 2e-3) || !(D.defect < 2e-3)) fail("dense: not an inverse");
+    HostDense D2;
+    if (D2.build(H4, 100) || D2.ok) fail("dense: size limit ignored");
+    std::printf("ok dense n=%d ld=%d defect=%.2e max|Ahat inv - I|=%.2e\n", n, D.ld, D.defect, worst);
+  }
   std::printf("ALL OK\n");
   return 0;
 }

@@ -19,6 +19,7 @@ CORE = "test_forward_step_matches_oracle_with_contact or test_backward_step_matc
     {"DC_FWD_VARIANT": "0", "DC_WINDOWS": "0"},           # ELL resident PCG, global-memory element passes
     {"DC_FWD_VARIANT": "1"},                              # ELL resident PCG (second thread shape), windowed adjoint
     {"DC_RENUMBER": "1"},                                 # default kernels on renumbered grids
+    {"DC_DENSE_MAX_N": "0"},                              # resident PCG instead of the explicit inverse small meshes get by default
 ])
 def test_core_parity_on_fallback_kernels(env):
     e = dict(os.environ)

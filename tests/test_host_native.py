@@ -1,4 +1,4 @@
-"""Host-side table builders of the HIP kernels (packet-ELL matrix, element windows, RCM renumbering), checked on the
+"""Host-side table builders of the HIP kernels (packet-ELL matrix, element windows, RCM renumbering, explicit inverse of small systems), checked on the
 CPU by a small C++ harness (tests/native/host_tables_check.cpp) against the plain constraint system."""
 import os
 import subprocess
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_packet_window_and_rcm_tables(tmp_path):
     csrc = os.path.join(ROOT, "diffcloth_amd", "csrc")
     exe = str(tmp_path / "host_tables_check")
-    srcs = [os.path.join(ROOT, "tests", "native", "host_tables_check.cpp")] + [os.path.join(csrc, f) for f in ("dc_system.cpp", "dc_windows.cpp", "dc_packets.cpp")]
+    srcs = [os.path.join(ROOT, "tests", "native", "host_tables_check.cpp")] + [os.path.join(csrc, f) for f in ("dc_system.cpp", "dc_windows.cpp", "dc_packets.cpp", "dc_dense.cpp")]
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", csrc, "-o", exe] + srcs)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
