@@ -84,6 +84,19 @@ def cpu_baseline(args, V, F, center, x0, v0, mu, steps, gscale):
                        f"reference adjoint iteration")
 
 
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01f_traffic.json")
+
+
+def measured_traffic(args, K, W, B):
+    """{kernel: HBM-side bytes per launch} measured by rocprofv3 --pmc for the default workload (profiles/), {} otherwise."""
+    default = (K == 10 and W == 5 and B == 256 and args.grid == 100 and args.selfcollision == 1 and args.fwd_tol == 1e-8
+               and args.cg_tol == 1e-4 and args.adjoint_mode == 1 and args.adjoint_rel_tol == 1e-6)
+    if not default or not os.path.exists(TRAFFIC_FILE):
+        return {}
+    with open(TRAFFIC_FILE) as f:
+        return {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +201,11 @@ def main():
                 "steps_per_launch": K / max(launches, 1), "ms_per_step": ms / K}
     k_fwd = kernel_entry("k_pd_step_pk", bytes_fwd, kt["fwd_ms"], kt["fwd_launches"])
     k_bwd = kernel_entry("k_adjoint_step", bytes_bwd, kt["bwd_ms"], kt["bwd_launches"])
+    # HBM-side bytes per launch from the PMC passes of the round profile (tools/profile_round.sh -> profiles/*_traffic.json:
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, FETCH_SIZE doubled as the
+    # calibration kernels show for this part) — only quoted when this run is the profiled workload, else null
+    traffic = measured_traffic(args, K, W, B) if world == 1 else {}
+    k_fwd["traffic"] = traffic.get("k_pd_step_pk"); k_bwd["traffic"] = traffic.get("k_adjoint_step")
     dom = k_fwd if kt["fwd_ms"] >= kt["bwd_ms"] else k_bwd
     dx, dv, dmu = e.get_gradient()
     finite = bool(np.isfinite(dx).all() and np.isfinite(dv).all())
@@ -210,9 +228,9 @@ def main():
                        "batch_steps_per_s": world * K / dt, "gradients_finite": finite,
                        "parallelism": f"rollout-sharded x{world}"},
             # dominant kernel first (contract fields), then both kernels. `achieved` prices the ALGORITHMIC bytes; the
-            # forward kernel keeps the PCG vectors in LDS/registers, so its figure can exceed the HBM peak — the HBM
-            # bytes it really moves are in profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), `traffic` stays null here.
-            "roofline": {"bound": "hbm", **dom, "traffic": None, "kernels": [k_fwd, k_bwd]},
+            # forward kernel keeps the PCG vectors in LDS/registers, so its figure can exceed the HBM peak — `traffic` is
+            # what it really moves through the fabric (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/).
+            "roofline": {"bound": "hbm", **dom, "kernels": [k_fwd, k_bwd]},
         }
         if world == 1 and args.cpu_steps > 0:
             xw, vw = e.get_state(W)
