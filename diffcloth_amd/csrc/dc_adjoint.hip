@@ -15,6 +15,7 @@
 //   mode 1  direct solve (semantics of backwardGradientForceDirectSolver / solveDirect, Simulation.cpp:1431-1440):
 //           block-Jacobi preconditioned BiCGSTAB on K itself, relative residual <= adjoint_rel_tol.
 #define DC_KERNEL_TU
+#include <cstdlib>
 #include "dc_devlib.h"
 #include "dc_winlib.h"
 
@@ -510,7 +511,15 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   }   // step
 }
 
-static int pick_threads_bwd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }
+static int pick_threads_bwd(int N) {
+  static const int forced = getenv("DC_BWD_THREADS") ? atoi(getenv("DC_BWD_THREADS")) : 0;     // development switch
+  if (forced == 256 || forced == 512 || forced == 1024) return forced;
+  // 16 waves per rollout at every mesh size: the Krylov iteration is a chain of barrier-separated phases with global-memory
+  // round trips, and with one workgroup per CU (256 rollouts) only the waves of that workgroup can hide them — measured
+  // 1.3 - 1.7 x over 256 / 512 threads from N = 579 to N = 3634 (tools/bench_configs.py), even with idle lanes at N < 1024
+  (void) N;
+  return 1024;
+}
 
 template <int THREADS>
 static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
