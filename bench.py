@@ -11,7 +11,8 @@ rollouts of the job; `value` = rollout-steps per second over the whole job = B_t
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 One process per GPU; rollouts are independent, so ranks share nothing on the data path ("weak" scaling: 256
-rollouts per GPU). The only collective is the barrier / MAX-reduce of the timing.
+rollouts per GPU). The only collectives are the optimiser-level all-reduce of the summed parameter gradient at the end of
+the backward sweep (diffcloth_amd/distributed.py) and the barrier / MAX-reduce of the timing.
 """
 import argparse
 import json
@@ -131,6 +132,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the stepper has no CPU path")
 
+    from diffcloth_amd.distributed import allreduce_loss_and_grads
     V, F = grid_cloth(args.grid, 4.5)
     V = V.astype(np.float32).astype(np.float64)
     import meshes
@@ -164,6 +166,10 @@ def main():
     e.rollout_forward(W, K)                 # K forward steps, tape on the device
     e.seed_gradient(W + K, None, gscale)    # dL/dx_K of the match-trajectory loss, on the device
     e.rollout_backward(W + K, K)            # K backward steps
+    # optimiser-level reduction: the friction-coefficient gradient summed over all rollouts of the job — one
+    # fused all-reduce (RCCL over xGMI at N > 1, nothing at N = 1), the only exchange between ranks
+    dmu_local = e.get_mu_gradient().sum(axis=0)      # also waits for the sweep
+    _, (dmu_total,) = allreduce_loss_and_grads(0.0, [dmu_local])
     e.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -226,6 +232,7 @@ def main():
                        "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
                        "mean_adjoint_iters_per_step": adj / (B * K), "converged_fraction": conv / (B * K),
                        "batch_steps_per_s": world * K / dt, "gradients_finite": finite,
+                       "dL_dmu_sum_over_job": float(np.asarray(dmu_total).sum()),
                        "parallelism": f"rollout-sharded x{world}"},
             # dominant kernel first (contract fields), then both kernels. `achieved` prices the ALGORITHMIC bytes; the
             # forward kernel keeps the PCG vectors in LDS/registers, so its figure can exceed the HBM peak — `traffic` is

@@ -265,6 +265,12 @@ class Engine:
         self._chk(self.lib.dc_get_gradient(self.h, _d(dx), _d(dv), _d(dmu)))
         return dx, dv, dmu
 
+    def get_mu_gradient(self):
+        """dL/dmu accumulated by the backward sweep, per rollout and friction group (small copy; waits for the stream)."""
+        dmu = np.zeros((self.B, self.ngroups))
+        self._chk(self.lib.dc_get_gradient(self.h, None, None, _d(dmu)))
+        return dmu
+
     def get_param_gradients(self, slot):
         out = np.zeros((self.B, 8))
         self._chk(self.lib.dc_get_param_gradients(self.h, C.c_int(slot), _d(out)))
