@@ -85,6 +85,7 @@ struct DevSystem {
   const int DC_G *conn_idx;          // sorted neighbours incl. self
   float max_radii;
   int self_cap;                 // capacity of the per-rollout self-contact list
+  int self_lds;                 // 1: the layered self-contact passes run in LDS when their working set fits (dc_devlib.h)
   float h, k_att, gx, gy, gz;
   float k_stretch, k_bend, density;
   int contact_enabled, self_enabled, pad1;

@@ -286,7 +286,7 @@ __device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, con
   const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
   const int *meta = R.meta + (size_t) b * kMetaStride;
   const int C = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
-  if (self_lds_need(M, C, nl) > lds_floats) return false;
+  if (!S.self_lds || self_lds_need(M, C, nl) > lds_floats) return false;
   const int2 *pair = R.pair + (size_t) b * cap;
   const float4 *nrm = R.nrm + (size_t) b * cap;
   float4 *dvec = R.dvec + (size_t) b * cap;
@@ -336,7 +336,7 @@ __device__ __forceinline__ bool self_JT_layers_lds(const DevSystem &S, const Sel
   const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
   const int *meta = R.meta + (size_t) b * kMetaStride;
   const int C = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
-  if (self_lds_need(M, C, nl) > lds_floats) return false;
+  if (!S.self_lds || self_lds_need(M, C, nl) > lds_floats) return false;
   const float4 *nrm = R.nrm + (size_t) b * cap;
   const float4 *dvec = R.dvec + (size_t) b * cap;
   const int *verts = R.verts + (size_t) b * 2 * cap;

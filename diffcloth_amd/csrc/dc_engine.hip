@@ -363,6 +363,7 @@ int dc_build(dc_ctx *c) {
     for (double r : H.radii) mr = std::max(mr, r);
     S.max_radii = (float) mr;
     S.self_cap = p.max_self_contacts > 0 ? p.max_self_contacts : 2048;
+    { const char *envs = getenv("DC_SELF_LDS"); S.self_lds = !(envs && envs[0] == '0'); }   // development switch: 0 = global-memory layer passes
   }
   {  // wave-sliced ELL copy of P for the LDS-resident PCG
     const int nchunks = (N + 63) / 64;

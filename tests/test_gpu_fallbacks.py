@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CORE = "test_forward_step_matches_oracle_with_contact or test_backward_step_matches_oracle or test_forward_and_backward_with_self_contacts " \
-       "or test_parameter_gradients_match_oracle or test_free_running_tshirt"
+       "or test_parameter_gradients_match_oracle or test_free_running_tshirt or test_fused_rollout_with_self_contacts"
 
 
 @pytest.mark.parametrize("env", [
@@ -19,6 +19,7 @@ CORE = "test_forward_step_matches_oracle_with_contact or test_backward_step_matc
     {"DC_FWD_VARIANT": "0", "DC_WINDOWS": "0"},           # ELL resident PCG, global-memory element passes
     {"DC_FWD_VARIANT": "1"},                              # ELL resident PCG (second thread shape), windowed adjoint
     {"DC_RENUMBER": "1"},                                 # default kernels on renumbered grids
+    {"DC_SELF_LDS": "0"},                                 # layered self-contact passes through global memory (working sets beyond LDS)
     {"DC_DENSE_MAX_N": "0"},                              # resident PCG instead of the explicit inverse small meshes get by default
 ])
 def test_core_parity_on_fallback_kernels(env):
