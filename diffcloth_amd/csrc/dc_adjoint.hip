@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include "dc_devlib.h"
 #include "dc_winlib.h"
+#include "dc_denselib.h"
 
 namespace dc {
 
@@ -220,7 +221,7 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
 
 }  // namespace
 
-template <int THREADS, bool WIN>
+template <int THREADS, bool WIN, bool DENSE>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
   const DevSystem &S = *Sp;
   extern __shared__ float dyn_lds[];      // element windows (S.win_lds_bytes)
@@ -289,7 +290,27 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
         part += dot(r, r) * di;
       }
       const double rz = block_sum<THREADS>((double) part, red);
-      cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red);
+      if constexpr (DENSE) {
+        // small meshes: P^-1 r = D^-1/2 Ahat^-1 D^-1/2 r with the explicit fp32 inverse (dc_denselib.h) — its ~1e-5 relative
+        // error is at the level of the inner PCG tolerance, and the outer iteration works on the true residual g - K u
+        const int ld = S.dense_ld;
+        float2 *dxy = (float2 *) dyn_lds;
+        float *dz = dyn_lds + 2 * ld, *dpart = dyn_lds + 3 * ld;
+        __syncthreads();                                   // cg_r complete, LDS free
+        for (int i = tid; i < ld; i += THREADS) {
+          f3 q = mk(0, 0, 0);
+          if (i < N) q = ld3(cg_r, i, N) * S.sq_dinv[i];
+          dxy[i] = make_float2(q.x, q.y); dz[i] = q.z;
+        }
+        __syncthreads();
+        const int Cn = dense_partials<THREADS>(S, dxy, dz, dpart);
+        __syncthreads();
+        for (int i = tid; i < N; i += THREADS) st3(cg_x, i, N, dense_row_sum(dpart, ld, Cn, i) * S.sq_dinv[i]);
+        cg_total += 1;
+        (void) rz;
+      } else {
+        cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red);
+      }
       part = 0.f;
       for (int i = tid; i < N; i += THREADS) {
         f3 d = ld3(cg_x, i, N);
@@ -521,23 +542,26 @@ static int pick_threads_bwd(int N) {
   return 1024;
 }
 
-template <int THREADS>
+template <int THREADS, bool DENSE>
 static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
-  if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
-  const size_t lds = (size_t) S.win_lds_bytes;
+  if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
+  size_t lds = (size_t) S.win_lds_bytes;
+  if (DENSE) lds = std::max(lds, sizeof(float) * (size_t) (3 * S.dense_ld + dense_lds_floats(S.dense_ld, THREADS / 64)));
   static size_t configured = 0;
   if (lds > configured) {
-    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     configured = lds;
   }
-  hipLaunchKernelGGL((k_adjoint_step<THREADS, true>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+  // small meshes, reference iteration (mode 0): the inner solve with P is one product with the explicit inverse (dc_dense.h)
+  if (S.dense_inv && S.win_ok && A.mode == 0 && pick_threads_bwd(S.N) == 1024) { launch_adj<1024, true>(S, W, A, B, st); return; }
   switch (pick_threads_bwd(S.N)) {
-    case 256: launch_adj<256>(S, W, A, B, st); break;
-    case 512: launch_adj<512>(S, W, A, B, st); break;
-    default: launch_adj<1024>(S, W, A, B, st); break;
+    case 256: launch_adj<256, false>(S, W, A, B, st); break;
+    case 512: launch_adj<512, false>(S, W, A, B, st); break;
+    default: launch_adj<1024, false>(S, W, A, B, st); break;
   }
 }
 
