@@ -280,6 +280,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     for (int it = 0; it < A.it_cap; it++) {
       float d1, d2;
       adjoint_operator<THREADS, WIN>(S, C, u, false, cg_ap, nullptr, d1, d2);
+      __syncthreads();          // the windows hand out vertices in their own order: K u is complete only after a barrier
       part = 0.f;
       for (int i = tid; i < N; i += THREADS) {
         f3 r = ld3(gin, i, N) - ld3(cg_ap, i, N);
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = gin;
     float d1, d2;
     adjoint_operator<THREADS, WIN>(S, C, u, false, v, nullptr, d1, d2);
+    __syncthreads();            // (as above; inside the loop the block reductions that follow every application do this)
     part = 0.f;
     for (int i = tid; i < N; i += THREADS) {
       f3 q = ld3(gin, i, N) - ld3(v, i, N);
