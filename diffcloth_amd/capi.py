@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffcloth_hip.so")
 
-DC_PRIM_SPHERE, DC_PRIM_CAPSULE = 0, 1
+DC_PRIM_SPHERE, DC_PRIM_CAPSULE, DC_PRIM_PLANE, DC_PRIM_BOWL = 0, 1, 2, 3
 
 
 class DcError(RuntimeError):
@@ -21,7 +21,7 @@ class DcError(RuntimeError):
 
 class dc_primitive(C.Structure):
     _fields_ = [("kind", C.c_int), ("group", C.c_int), ("center", C.c_double * 3), ("top_offset", C.c_double * 3),
-                ("radius", C.c_double), ("length", C.c_double), ("mu", C.c_double), ("rotates", C.c_int)]
+                ("corner2", C.c_double * 3), ("radius", C.c_double), ("length", C.c_double), ("mu", C.c_double), ("rotates", C.c_int)]
 
 
 class dc_params(C.Structure):
@@ -153,6 +153,7 @@ class Engine:
             for d in range(3):
                 arr[k].center[d] = float(p["center"][d])
                 arr[k].top_offset[d] = float(p.get("top_offset", (0, 0, 0))[d])
+                arr[k].corner2[d] = float(p.get("corner2", (0, 0, 0))[d])
             arr[k].radius = float(p["radius"])
             arr[k].length = float(p.get("length", 0.0))
             arr[k].mu = float(p.get("mu", 0.0))

@@ -27,7 +27,8 @@ constexpr int kMetaStride = 1024;  // ints per (slot, rollout): count, nlayers, 
 struct DevPrim {
   int kind, group, rotates, pad;
   float cx, cy, cz, radius;
-  float tx, ty, tz, length;
+  float tx, ty, tz, length;     // capsule: top offset; plane: corner upperLeft relative to the centre
+  float ux, uy, uz, pad2;       // plane: corner upperRight relative to the centre
 };
 
 // Shared (per-context) tables: topology + matrices, identical for every rollout of the batch.

@@ -106,7 +106,8 @@ __device__ __forceinline__ f3 dri_dmu(f3 n, f3 d, float mu) {
   return mk(0, 0, 0);
 }
 
-// Primitive::isInContact family (Sphere Primitive.cpp:221-261, Capsule :570-604) for one flattened primitive.
+// Primitive::isInContact family (Sphere Primitive.cpp:221-261, Capsule :570-604, Plane :66-130, Bowl :362-381) for one
+// flattened primitive.
 __device__ __forceinline__ bool prim_in_contact(const DevPrim &p, f3 pos, f3 &normal) {
   f3 c = mk(p.cx, p.cy, p.cz);
   f3 q = pos - c;
@@ -114,6 +115,45 @@ __device__ __forceinline__ bool prim_in_contact(const DevPrim &p, f3 pos, f3 &no
     float dist = sqrtf(dot(q, q)) - p.radius;
     normal = normalized(q);
     return dist < 0.1f;
+  }
+  if (p.kind == DC_PRIM_BOWL) {     // Bowl::isInContact (Primitive.cpp:362-381): inside of the lower half of a shell, eps 0.005
+    const float len = sqrtf(dot(q, q));
+    normal = q * (-1.0f / len);
+    return (len - p.radius <= 0.005f) && !(pos.y > p.cy) && (len > p.radius - 0.005f);
+  }
+  if (p.kind == DC_PRIM_PLANE) {    // Plane::isInContact (Primitive.cpp:66-130): finite rectangle, eps 0.4, thickness 5, edge tol 5e-4
+    const f3 ul = mk(p.tx, p.ty, p.tz), ur = mk(p.ux, p.uy, p.uz), lr = ul * -1.0f, ll = ur * -1.0f;
+    const float eps = 0.4f, edge_tol = 0.0005f;
+    const float br = sqrtf(fmaxf(dot(ul, ul), dot(ur, ur)));
+    if (sqrtf(dot(q, q)) > br + eps) return false;
+    const f3 n = normalized(cross(ur, ul));
+    const float dp = dot(n, q);
+    if (fabsf(dp) > eps) return false;         // (with it the thickness test of :84-85 can never trigger)
+    const f3 pp = q - n * dp;
+    auto inside = [&](f3 a, f3 b, f3 c) {      // Primitive.h:176-190
+      const f3 AB = b - a, AC = c - a, nn = cross(AB, AC), AP = pp - a;
+      const float n2 = dot(nn, nn);
+      const float alpha = dot(cross(AB, AP), nn) / n2, beta = dot(cross(AP, AC), nn) / n2, gamma = 1.f - alpha - beta;
+      return alpha >= 0.f && beta >= 0.f && gamma >= 0.f && gamma <= 1.f && alpha <= 1.f && beta <= 1.f;
+    };
+    if (inside(ul, ur, ll) || inside(ll, ur, lr)) { normal = n; return true; }   // dp >= -eps here: the sign factor of :93 is +1
+    const f3 ea[4] = {ul, ur, ll, ul}, eb[4] = {ur, lr, lr, ll};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const f3 AB = eb[k] - ea[k], AP = q - ea[k];
+      const f3 pr = AB * (dot(AP, AB) / dot(AB, AB));
+      const f3 Pp = ea[k] + pr;
+      const float ABl = sqrtf(dot(AB, AB)), APl = sqrtf(dot(pr, pr));
+      const f3 pb = Pp - eb[k];
+      float t = APl / ABl;
+      if (sqrtf(dot(pb, pb)) > ABl) t = -t;
+      const f3 off = q - Pp;
+      if (sqrtf(dot(off, off)) < edge_tol && t > -edge_tol && t < 1.f + edge_tol) {
+        normal = normalized(t < 0.f ? q - ea[k] : (t > 1.f ? q - eb[k] : off));
+        return true;
+      }
+    }
+    return false;
   }
   // capsule: Primitive.h:198-211 projectionOnLine + Primitive.cpp:583-603
   f3 top = mk(p.tx, p.ty, p.tz);

@@ -452,6 +452,7 @@ int dc_build(dc_ctx *c) {
     d.kind = q.kind; d.group = c->group_of_prim[k]; d.rotates = q.rotates; d.pad = 0;
     d.cx = (float) q.center[0]; d.cy = (float) q.center[1]; d.cz = (float) q.center[2]; d.radius = (float) q.radius;
     d.tx = (float) q.top_offset[0]; d.ty = (float) q.top_offset[1]; d.tz = (float) q.top_offset[2]; d.length = (float) q.length;
+    d.ux = (float) q.corner2[0]; d.uy = (float) q.corner2[1]; d.uz = (float) q.corner2[2]; d.pad2 = 0.f;
   }
   {  // device-resident copy of the descriptor itself (kernels take a pointer to it)
     DevSystem *dS = nullptr;

@@ -216,6 +216,22 @@ void Simulation::initScene() {
       primitives.push_back(s);
       break;
     }
+    case Y0PLANE: {                 // :1811-1819, :1887-1892: the bowl of Simulation.h:458 (the reference also gives every
+      Primitive b; b.type = BOWL; b.radius = 0.5; b.mu = 0; b.center = b.centerInit = {0, 0.5, 0};   // particle v = (0, -10, 0))
+      primitives.push_back(b);
+      break;
+    }
+    case SLOPE: {                   // :1946-1962 with the slope plane of Simulation.h:474
+      Primitive pl; pl.type = PLANE; pl.mu = 0.2;
+      const Vec3d c0 = {0, -11, 10}, ul = {-8 - c0[0], -1 - c0[1], -1 - c0[2]}, ur = {8 - c0[0], -1 - c0[1], -1 - c0[2]};
+      pl.upperLeft = ul; pl.upperRight = ur;
+      const Vec3d lowerRight = {-ul[0], -ul[1], -ul[2]};
+      const Vec3d shift = {(lowerRight[0] - ur[0]) * 0.5, (lowerRight[1] - ur[1]) * 0.5, (lowerRight[2] - ur[2]) * 0.5};
+      const Vec3d ref = {(restShapeMaxDim[0] + restShapeMinDim[0]) * 0.5, restShapeMinDim[1], restShapeMinDim[2] - 1.0};
+      pl.center = pl.centerInit = {ref[0] + shift[0], ref[1] + shift[1] - 2, ref[2] + shift[2]};
+      primitives.push_back(pl);
+      break;
+    }
     case FOOT: {                    // :1916-1925 + LowerLeg::createNewMesh (Primitive.h:350-374)
       Primitive leg; leg.type = LOWER_LEG; leg.isPrimitiveCollection = true; leg.mu = 0;
       Vec3d high = {restShapeMidPoint[0], restShapeMaxDim[1], restShapeMidPoint[2]};
@@ -306,9 +322,9 @@ void Simulation::configureDevice() {
     const Primitive &p = primitives[g];
     auto add = [&](const Primitive &q, const Vec3d &c) {
       dc_primitive d{};
-      d.kind = q.type == CAPSULE ? DC_PRIM_CAPSULE : DC_PRIM_SPHERE;
+      d.kind = q.type == CAPSULE ? DC_PRIM_CAPSULE : (q.type == PLANE ? DC_PRIM_PLANE : (q.type == BOWL ? DC_PRIM_BOWL : DC_PRIM_SPHERE));
       d.group = (int) g;
-      for (int k = 0; k < 3; k++) { d.center[k] = c[k]; d.top_offset[k] = q.topOffset[k]; }
+      for (int k = 0; k < 3; k++) { d.center[k] = c[k]; d.top_offset[k] = q.type == PLANE ? q.upperLeft[k] : q.topOffset[k]; d.corner2[k] = q.upperRight[k]; }
       d.radius = q.radius; d.length = q.length; d.mu = p.mu; d.rotates = q.rotates;
       flat.push_back(d);
     };

@@ -28,7 +28,7 @@ enum Orientation { FRONT, DOWN, BACK, CUSTOM_ORIENTATION };                     
 enum AttachmentConfigs { NO_ATTACHMENTS, LEFT_RIGHT_CORNERS_2, CUSTOM_ARRAY };    // :38-42
 enum TrajectoryConfigs { NO_TRAJECTORY, CORNERS_2_UP, CORNERS_2_WEARHAT, CORNERS_1_WEARHAT, CORNERS_2_WEARSOCK,
                          TRAJECTORY_DRESS_TWIRL, FIXED_POINT_TRAJECTORY, PER_STEP_TRAJECTORY };
-enum PrimitiveConfiguration { PRIM_NONE, PLANE_AND_SPHERE, PLANE_BUST_WEARHAT, FOOT, BIG_SPHERE };
+enum PrimitiveConfiguration { PRIM_NONE, PLANE_AND_SPHERE, PLANE_BUST_WEARHAT, FOOT, BIG_SPHERE, Y0PLANE, SLOPE };
 enum WindConfig { NO_WIND, WIND_CONSTANT, WIND_SIN, WIND_SIN_AND_FALLOFF, WIND_FACTOR_PER_STEP };   // :55-61
 enum PrimitiveType { PLANE, CUBE, SPHERE, CAPSULE, FOOT_PRIM, LOWER_LEG, BOWL };
 
@@ -63,6 +63,7 @@ struct Primitive {                // the fields of Primitive.h the Python side r
   double radius = 1, length = 0, mu = 0;
   bool rotates = false, isPrimitiveCollection = false;
   Vec3d topOffset = {0, 0, 0};
+  Vec3d upperLeft = {0, 0, 0}, upperRight = {0, 0, 0};   // PLANE: two corners relative to the centre (Primitive.cpp:13-21)
   std::vector<Primitive> primitives;            // children of a LowerLeg
   VecXd getPointVec() const { return VecXd(center.begin(), center.end()); }
 };

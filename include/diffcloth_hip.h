@@ -27,7 +27,7 @@ typedef struct dc_ctx dc_ctx;
 enum { DC_OK = 0, DC_ERR_INVALID = 1, DC_ERR_HIP = 2, DC_ERR_STATE = 3, DC_ERR_TOPOLOGY = 4 };
 
 /* Primitive kinds (Primitive.h PrimitiveType; only the analytic isInContact family is on the hot path). */
-enum { DC_PRIM_SPHERE = 0, DC_PRIM_CAPSULE = 1 };
+enum { DC_PRIM_SPHERE = 0, DC_PRIM_CAPSULE = 1, DC_PRIM_PLANE = 2, DC_PRIM_BOWL = 3 };
 
 /* One analytic obstacle. A LowerLeg (Primitive.cpp:383-418) is passed as its three children
  * (joint sphere, foot capsule, leg capsule) sharing one `group`; friction uses the group's mu and the
@@ -36,8 +36,11 @@ typedef struct dc_primitive {
   int kind;            /* DC_PRIM_*                                                              */
   int group;           /* primitive id seen by the caller (index into Simulation::primitives)    */
   double center[3];    /* world position tested against: center_prim (+ child centerInit)        */
-  double top_offset[3];/* capsule: globalRotation * (0,length,0)  (Primitive.cpp:582)            */
-  double radius;
+  double top_offset[3];/* capsule: globalRotation * (0,length,0)  (Primitive.cpp:582);
+                          plane: corner upperLeft relative to the centre (Plane ctor, Primitive.cpp:13-21) */
+  double corner2[3];   /* plane: corner upperRight relative to the centre (the rectangle's other two corners are
+                          the negatives; Plane::isInContact Primitive.cpp:66-130). Unused otherwise           */
+  double radius;       /* sphere, capsule; bowl: the hemisphere shell Bowl::isInContact tests (Primitive.cpp:362-381) */
   double length;       /* capsule length                                                         */
   double mu;           /* Primitive::mu (default for rollouts without a per-rollout override)     */
   int rotates;         /* Sphere::rotates (Primitive.cpp:255-257)                                 */

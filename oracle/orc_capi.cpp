@@ -40,6 +40,16 @@ void orc_add_capsule(void *s, const double *center, const double *topOffset, dou
   p.topOffset = V3(topOffset[0], topOffset[1], topOffset[2]); p.radius = radius; p.length = length; p.mu = mu;
   ((Sim *) s)->prims.push_back(p);
 }
+// Plane (Primitive.cpp:13-47): centre + the corners upperLeft, upperRight given relative to the centre
+void orc_add_plane(void *s, const double *center, const double *upperLeft, const double *upperRight, double mu) {
+  Primitive p; p.kind = PRIM_PLANE; p.center = V3(center[0], center[1], center[2]); p.mu = mu;
+  p.upperLeft = V3(upperLeft[0], upperLeft[1], upperLeft[2]); p.upperRight = V3(upperRight[0], upperRight[1], upperRight[2]);
+  ((Sim *) s)->prims.push_back(p);
+}
+void orc_add_bowl(void *s, const double *center, double radius, double mu) {
+  Primitive p; p.kind = PRIM_BOWL; p.center = V3(center[0], center[1], center[2]); p.radius = radius; p.mu = mu;
+  ((Sim *) s)->prims.push_back(p);
+}
 // LowerLeg = joint sphere + foot capsule + leg capsule (Primitive.cpp:383-418); children given by their
 // centerInit offsets: child k: kind, centerInit[3], topOffset[3], radius, length  (9 doubles each)
 void orc_add_lower_leg(void *s, const double *center, double mu, int nchild, const double *child) {

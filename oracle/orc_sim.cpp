@@ -373,7 +373,7 @@ static std::pair<V3, double> projectionOnLine(const V3 &a, const V3 &b, const V3
 }
 
 // Sphere::isInContact Primitive.cpp:221-261 (eps 0.1; discretized branch not used by shipped demos' hot path),
-// Capsule::isInContact Primitive.cpp:570-604, LowerLeg::isInContact Primitive.cpp:410-418.
+// Capsule::isInContact Primitive.cpp:570-604, LowerLeg::isInContact Primitive.cpp:410-418, Plane :66-130, Bowl :362-381.
 bool Sim::primInContact(const Primitive &p, const V3 &center_prim, const V3 &pos, const V3 &vel, V3 &normal,
                         double &dist, V3 &v_out) const {
   switch (p.kind) {
@@ -398,6 +398,52 @@ bool Sim::primInContact(const Primitive &p, const V3 &center_prim, const V3 &pos
       else if (t > 1) { dist = (posLocal - top).norm() - (p.radius + 0.1); normal = (posLocal - top).normalized(); }
       else { dist = (posLocal - pr.first).norm() - (p.radius + 0.1); normal = (posLocal - pr.first).normalized(); }
       return dist < delta;
+    }
+    case PRIM_PLANE: {     // Plane::isInContact Primitive.cpp:66-130: a finite rectangle (two triangles), eps 0.4, thickness 5
+      const double eps = 0.4, thickness = 5, edgeTol = 0.0005;
+      const V3 posShifted = pos - center_prim;
+      const V3 ul = p.upperLeft, ur = p.upperRight, lr = ul * -1.0, ll = ur * -1.0;
+      const double boundaryRadius = std::max(ul.norm(), ur.norm());
+      if (posShifted.norm() > boundaryRadius + eps) return false;
+      const V3 n = ur.cross(ul).normalized();                // planeNormal, d = 0 (Primitive.cpp:38-41)
+      const double distToPlane = n.dot(posShifted);
+      dist = distToPlane;
+      if (std::fabs(distToPlane) > eps) return false;
+      if (distToPlane < 0 && -distToPlane > eps + thickness) return false;
+      const V3 pp = posShifted - n * n.dot(posShifted);     // projectionOnPlane
+      auto inside = [&](const V3 &a, const V3 &b, const V3 &c) {   // Primitive.h:176-190
+        const V3 AB = b - a, AC = c - a, nn = AB.cross(AC), AP = pp - a;
+        const double n2 = nn.dot(nn);
+        const double alpha = AB.cross(AP).dot(nn) / n2, beta = AP.cross(AC).dot(nn) / n2, gamma = 1 - alpha - beta;
+        return alpha >= 0 && beta >= 0 && gamma >= 0 && gamma <= 1 && alpha <= 1 && beta <= 1;
+      };
+      if (inside(ul, ur, ll) || inside(ll, ur, lr)) {        // mesh (0,1,2) and (2,1,3) of points {ul, ur, ll, lr}
+        normal = n * (distToPlane < -eps ? -1.0 : 1.0);
+        v_out = p.velocity;
+        return true;
+      }
+      const V3 ea[4] = {ul, ur, ll, ul}, eb[4] = {ur, lr, lr, ll};
+      for (int k = 0; k < 4; k++) {
+        std::pair<V3, double> pr = projectionOnLine(ea[k], eb[k], posShifted);
+        const double t = pr.second;
+        if ((posShifted - pr.first).norm() < edgeTol && t > -edgeTol && t < 1 + edgeTol) {
+          if (t < 0) normal = (posShifted - ea[k]).normalized();
+          else if (t > 1) normal = (posShifted - eb[k]).normalized();
+          else normal = (posShifted - pr.first).normalized();
+          v_out = p.velocity;
+          return true;
+        }
+      }
+      return false;
+    }
+    case PRIM_BOWL: {      // Bowl::isInContact Primitive.cpp:362-381: inside of the lower half of a sphere shell, eps 0.005
+      const double eps = 0.005;
+      dist = (pos - center_prim).norm() - p.radius;
+      normal = (center_prim - pos).normalized();
+      v_out = p.velocity;
+      if (dist > eps) return false;
+      if (pos[1] > center_prim[1]) return false;
+      return (pos - center_prim).norm() > p.radius - eps;
     }
     case PRIM_LOWER_LEG: {
       for (const Primitive &c : p.children)

@@ -19,7 +19,7 @@ namespace orc {
 typedef std::array<double, 9> M3;  // row-major 3x3
 
 enum CollisionType { TAKE_OFF = 0, STICK = 1, SLIDE = 2 };
-enum PrimKind { PRIM_SPHERE = 0, PRIM_CAPSULE = 1, PRIM_LOWER_LEG = 2 };
+enum PrimKind { PRIM_SPHERE = 0, PRIM_CAPSULE = 1, PRIM_LOWER_LEG = 2, PRIM_PLANE = 3, PRIM_BOWL = 4 };
 
 struct TriRest {          // Triangle.cpp:587-645 (ctor), Triangle.h:173-175 (weight)
   int v[3];
@@ -40,6 +40,7 @@ struct Primitive {        // Primitive.cpp (isInContact family)
   double radius = 1, mu = 0, length = 0;
   bool rotates = false;   // Sphere::rotates (Primitive.cpp:255-257)
   V3 topOffset;           // capsule: globalRotation * (0, length, 0)   (Primitive.cpp:582)
+  V3 upperLeft, upperRight;   // plane: two corners relative to the centre; the others are their negatives (Primitive.cpp:13-21)
   V3 velocity;
   std::vector<Primitive> children;  // LowerLeg: joint sphere, foot capsule, leg capsule
 };

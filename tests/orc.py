@@ -101,6 +101,15 @@ class Oracle:
         self.L.orc_add_capsule(self.h, _d(f64(center)), _d(f64(top_offset)), C.c_double(radius), C.c_double(length), C.c_double(mu))
         self.nprim += 1
 
+    def add_plane(self, center, upper_left, upper_right, mu):
+        """corners relative to the centre (Plane ctor, Primitive.cpp:13-21)"""
+        self.L.orc_add_plane(self.h, _d(f64(center)), _d(f64(upper_left)), _d(f64(upper_right)), C.c_double(mu))
+        self.nprim += 1
+
+    def add_bowl(self, center, radius, mu):
+        self.L.orc_add_bowl(self.h, _d(f64(center)), C.c_double(radius), C.c_double(mu))
+        self.nprim += 1
+
     def add_lower_leg(self, center, mu, children):
         ch = f64(children).reshape(-1)
         self.L.orc_add_lower_leg(self.h, _d(f64(center)), C.c_double(mu), C.c_int(ch.size // 9), _d(ch))
