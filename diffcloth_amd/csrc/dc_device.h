@@ -131,6 +131,7 @@ struct FwdArgs {
   const float *x_fixed;         // [B][3][Af] fixed-point targets for this step
   const float *mu;              // [B][ngroups]
   const float *fu;              // [B][3] uniform extra force or nullptr
+  const float *fv;              // [B][3][N] per-vertex extra force (wind with fall-off, constant force field) or nullptr
   dc_step_stats *stats;         // [B]
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;

@@ -48,6 +48,8 @@ struct dc_ctx {
   float *DPAR = nullptr;            // [(tape+1)][B][8] per-step parameter gradients
   float *mu = nullptr, *fu = nullptr;
   bool fu_set = false;
+  float *fv = nullptr;              // [B][3][N] per-vertex extra force
+  bool fv_set = false;
   float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DXF = nullptr, *DMU = nullptr, *target = nullptr;
   dc_step_stats *fstats = nullptr;  // [(tape+1)][B]
   dc_bwd_stats *bstats = nullptr;   // [(tape+1)][B], indexed by the slot whose record was differentiated
@@ -129,7 +131,7 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.x_out = c->X + se * (slot + 1); A.v_out = c->V + se * (slot + 1);
   A.rec_f = c->F + se * (slot + 1); A.rec_r = c->R + se * (slot + 1); A.rec_n = c->NRM + se * (slot + 1);
   A.rec_prim = c->PRIM + sp * (slot + 1);
-  A.x_fixed = c->xf_cur; A.mu = c->mu; A.fu = c->fu_set ? c->fu : nullptr;
+  A.x_fixed = c->xf_cur; A.mu = c->mu; A.fu = c->fu_set ? c->fu : nullptr; A.fv = c->fv_set ? c->fv : nullptr;
   A.stats = c->fstats + (size_t) c->B * (slot + 1);
   {
     const size_t sc = (size_t) c->B * c->self_cap * (slot + 1), sm = (size_t) c->B * kMetaStride * (slot + 1);
@@ -581,6 +583,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->DPAR, (size_t) B * 8 * slots))) return rc;
   if ((rc = dev_alloc(c, pool, &c->mu, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fu, (size_t) B * 3))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->fv, (size_t) B * 3 * N))) return rc;
   if ((rc = dev_alloc(c, pool, &c->GX, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->GV, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->IX, se))) return rc;
@@ -592,7 +595,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->bstats, (size_t) B * slots))) return rc;
   c->stage_elems = se;
   for (int k = 0; k < 4; k++) if ((rc = dev_alloc(c, pool, &c->stage[k], se))) return rc;
-  c->fu_set = false;
+  c->fu_set = false; c->fv_set = false;
   // default fixed-point targets = rest positions of the attached vertices (FixedPoint::pos = pos_rest)
   if (Af > 0) {
     std::vector<float> xf((size_t) B * 3 * Af);
@@ -628,6 +631,30 @@ int dc_set_uniform_force(dc_ctx *c, const double *f) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->fu, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
   c->fu_set = true;
+  return DC_OK;
+}
+
+int dc_set_vertex_forces(dc_ctx *c, const double *f) {
+  if (!c || c->B <= 0) return fail(c, DC_ERR_STATE, "dc_set_vertex_forces: no batch");
+  if (!f) { c->fv_set = false; return DC_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = h2d_planar(c, f, c->fv, c->host.N, 0);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->fv_set = true;
+  return DC_OK;
+}
+
+int dc_get_force_gradient(dc_ctx *c, double *dL_df) {
+  int rc = check_batch(c, 0, 0);
+  if (rc) return rc;
+  if (!dL_df) return fail(c, DC_ERR_INVALID, "dc_get_force_gradient: null output");
+  // the adjoint kernel leaves y = (I + dr_df)^T u* of its last step in the work vector it shares with the forward kernel
+  if ((rc = d2h_planar(c, c->W.vbest, dL_df, c->host.N, 0))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const double h2 = c->params.time_step * c->params.time_step;
+  const size_t n = (size_t) c->B * 3 * c->host.N;
+  for (size_t k = 0; k < n; k++) dL_df[k] *= h2;
   return DC_OK;
 }
 

@@ -142,7 +142,7 @@ constexpr int kSelfCells = 4096;               // bins of the 2-D broad-phase gr
 constexpr int kSelfDetectLdsInts = 16 + (kSelfCells + 1) + kSelfCells + 1 + 2048;
 template <int THREADS>
 __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const DevWork &W, int b, const float *x_in, const float *v_in,
-                                                    int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, int *lds) {
+                                                    int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, const float *fv_all, int *lds) {
   float *redf = (float *) lds;              // [16]
   int *hist = lds + 16;                     // [kSelfCells + 1]
   int *cursor = hist + kSelfCells + 1;      // [kSelfCells]
@@ -163,7 +163,13 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
   const float h = S.h;
   const f3 grav = mk(S.gx, S.gy, S.gz);
   const f3 fu = fu_all ? mk(fu_all[3 * b], fu_all[3 * b + 1], fu_all[3 * b + 2]) : mk(0, 0, 0);
-  auto v_guess = [&](int i) { const float m = S.mass[i]; return ld3(vn, i, N) + (grav * m + fu) * (h / m); };   // (s_n - x_n) / h
+  const float *fv = fv_all ? fv_all + (size_t) b * 3 * N : nullptr;
+  auto v_guess = [&](int i) {                                        // (s_n - x_n) / h
+    const float m = S.mass[i];
+    f3 fext = grav * m + fu;
+    if (fv) fext = fext + ld3(fv, i, N);
+    return ld3(vn, i, N) + fext * (h / m);
+  };
 
   if (!S.contact_enabled || !S.self_enabled) {
     if (tid == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; meta[kMetaStride - 1] = 0; }

@@ -137,6 +137,8 @@ void Simulation::resetSystemWithParams(BackwardTaskInformation &task, ParamInfo 
     for (int d = 0; d < 3; d++) wind[d] = n > 0 ? param.f_extwind[d] / n : 0.0;
     windFrequency = param.f_extwind[3]; windPhase = param.f_extwind[4];
   }
+  if (task.dL_dconstantForceField) external_force_field = param.f_constantForceField;   // Simulation.cpp:3524-3526
+  if (task.dL_dwindFactor) perstepWindFactor = param.f_ext_timestep;                    // :3528-3530
   if (task.dL_dcontrolPoints && !param.controlPointSplines.empty()) controlPointSplines = param.controlPointSplines[0];
   if (task.dL_dmu)
     for (const auto &pm : param.mu) primitives.at(pm.first).mu = pm.second;

@@ -144,6 +144,8 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readonly("dL_dmu", &BackwardInformation::dL_dmu)
       .def_readonly("loss", &BackwardInformation::loss)
       .def_readonly("totalRuntime", &BackwardInformation::totalRuntime)
+      .def_property_readonly("dL_dconstantForceField", [](const BackwardInformation &b) { return toNp(b.dL_dconstantForceField); })
+      .def_property_readonly("dL_dwindtimestep", [](const BackwardInformation &b) { return toNp(b.dL_dwindtimestep); })
       .def_readonly("converged", &BackwardInformation::converged)
       .def_readonly("convergedAccum", &BackwardInformation::convergedAccum)
       .def_readonly("backwardIters", &BackwardInformation::backwardIters)
@@ -161,6 +163,7 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readwrite("mu_primitives", &BackwardTaskInformation::mu_primitives)
       .def_readwrite("dL_dx0", &BackwardTaskInformation::dL_dx0)
       .def_readwrite("dL_dwindFactor", &BackwardTaskInformation::dL_dwindFactor)
+      .def_readwrite("dL_dconstantForceField", &BackwardTaskInformation::dL_dconstantForceField)
       .def_readonly("forwardAccuracyLevel", &BackwardTaskInformation::forwardAccuracyLevel)
       .def_readonly("backwardAccuracyLevel", &BackwardTaskInformation::backwardAccuracyLevel)
       .def_readonly("randSeed", &BackwardTaskInformation::randSeed)
@@ -224,6 +227,15 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def("exportCurrentSimulation", &Simulation::exportCurrentSimulation, "export the simulation to files", py::arg("fileName"))
       // on-disk formats beyond the reference's Python surface (its C++ side: Simulation.cpp:4003-4238, Simulation.h:574-620)
       .def_readwrite_static("outputRoot", &Simulation::outputRoot)
+      // wind fall-off / per-step wind factors / constant force field of fillForces (Simulation.cpp:55-116; C++-only members of the reference)
+      .def_property("windFallOff", [](Simulation &s) { return toNp(s.windFallOff); }, [](Simulation &s, const NpArr &a) { s.windFallOff = toVec(a); })
+      .def_property("perstepWindFactor", [](Simulation &s) { return toNp(s.perstepWindFactor); }, [](Simulation &s, const NpArr &a) { s.perstepWindFactor = toVec(a); })
+      .def_property("external_force_field", [](Simulation &s) { return toNp(s.external_force_field); }, [](Simulation &s, const NpArr &a) { s.external_force_field = toVec(a); })
+      .def_readwrite("enableConstantForcefield", &Simulation::enableConstantForcefield)
+      .def_readwrite("windEnabled", &Simulation::windEnabled)
+      .def("setWind", [](Simulation &s, const NpArr &dir, double norm, double freq, double phase) { VecXd d = toVec(dir); for (int k = 0; k < 3; k++) s.wind[k] = d.at(k); s.windNorm = norm; s.windFrequency = freq; s.windPhase = phase; },
+           "wind direction (unit vector), norm, sin frequency and phase (Simulation.h:357-360)", py::arg("direction"), py::arg("norm"), py::arg("frequency") = 14.0, py::arg("phase") = 0.0)
+      .def("setWindFallOffFromFocusPoint", [](Simulation &s, const NpArr &p) { VecXd v = toVec(p); s.setWindFallOffFromFocusPoint({v.at(0), v.at(1), v.at(2)}); }, py::arg("focus"))
       .def("exportSimulation", [](Simulation &s, const std::string &name) { s.exportSimulation(name, s.forwardRecords); },
            "write <name>/<i>.obj + info.txt, the layout the reference's viewer replays", py::arg("fileName"))
       .def("resetForwardRecordsFromFolder", &Simulation::resetForwardRecordsFromFolder, "append one record per <i>.obj of the folder", py::arg("subFolder"))

@@ -488,11 +488,22 @@ void Spline::updateControlPoints(const VecXd &step) {
   }
 }
 
-double Simulation::windFactorAt(double t) const {   // fillForces (Simulation.cpp:64-87)
+double Simulation::windFactorAt(double t, int stepIdx) const {   // fillForces (Simulation.cpp:64-87)
   switch (sceneConfig.windConfig) {
     case WIND_SIN: case WIND_SIN_AND_FALLOFF: return (std::sin(windFrequency * t + windPhase) + 1.0) / 2.0;
     case NO_WIND: return 0.0;
+    case WIND_FACTOR_PER_STEP: return stepIdx >= 0 && (size_t) stepIdx < perstepWindFactor.size() ? perstepWindFactor[stepIdx] : 1.0;
     default: return 1.0;
+  }
+}
+
+void Simulation::setWindFallOffFromFocusPoint(const Vec3d &focus) {
+  windFallOff.assign(3 * (size_t) N, 1.0);
+  const VecXd &x = forwardRecords.empty() ? rest : forwardRecords.back().x;
+  for (int i = 0; i < N; i++) {
+    const double dx = focus[0] - x[3 * i], dy = focus[1] - x[3 * i + 1], dz = focus[2] - x[3 * i + 2];
+    const double f = std::min(1.0 / std::sqrt(dx * dx + dy * dy + dz * dz), 1.0);     // (the reference's "distSquared" is the norm)
+    for (int d = 0; d < 3; d++) windFallOff[3 * (size_t) i + d] = f;
   }
 }
 
@@ -542,12 +553,24 @@ void Simulation::step() {
   rec.stepIdx = (int) forwardRecords.size();
   rec.deviceSlot = prev.deviceSlot + 1;
   rec.x_prev = prev.x; rec.v_prev = prev.v;
-  rec.windFactor = windFactorAt(rec.t);
-  if (windEnabled) {
+  rec.windFactor = windFactorAt(rec.t, rec.stepIdx);       // (the reference indexes perstepWindFactor by forwardRecords.size())
+  // fillForces (Simulation.cpp:55-116): uniform wind through dc_set_uniform_force; wind with per-vertex fall-off and the
+  // constant force field through dc_set_vertex_forces
+  const bool fallOff = windEnabled && windHasFallOff() && windFallOff.size() == 3 * (size_t) N;
+  const bool field = enableConstantForcefield && external_force_field.size() == 3 * (size_t) N;
+  if (windEnabled && !fallOff) {
     double f[3];
     for (int d = 0; d < 3; d++) f[d] = wind[d] * windNorm * rec.windFactor;
     check(ctx, dc_set_uniform_force(ctx, f), "dc_set_uniform_force");
   } else check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
+  if (fallOff || field) {
+    VecXd fv(3 * (size_t) N, 0.0);
+    for (size_t k = 0; k < fv.size(); k++) {
+      if (fallOff) fv[k] += wind[k % 3] * windNorm * rec.windFactor * windFallOff[k];
+      if (field) fv[k] += external_force_field[k];
+    }
+    check(ctx, dc_set_vertex_forces(ctx, fv.data()), "dc_set_vertex_forces");
+  } else check(ctx, dc_set_vertex_forces(ctx, nullptr), "dc_set_vertex_forces");
   rec.x_fixedpoints = fixedPointTargets(rec.t);
   rec.simDurartionFraction = rec.t / (sceneConfig.timeStep * sceneConfig.stepNum);
   rec.splines = controlPointSplines;
@@ -658,15 +681,42 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
   const double perType[4] = {0.0, par[2], par[0], par[1]};
   for (int k = 0; k < 4; k++)
     if (taskInfo.dL_dk_pertype[k]) ret.dL_dk_pertype[k] = gradient_new.dL_dk_pertype[k] + perType[k];
+  // dL_dfext_vec = h^2 (I + dr_df)^T u* per vertex (:1700-1760): its plain sum comes with the parameter gradients; the
+  // per-vertex vector is fetched only when a fall-off weighting, the force field or the per-step factors need it
+  const bool needVec = taskInfo.dL_dconstantForceField || taskInfo.dL_dwindFactor ||
+                       ((taskInfo.dL_dfext || taskInfo.dL_dfwind) && sceneConfig.windConfig == WIND_SIN_AND_FALLOFF);
+  VecXd fvec;
+  if (needVec) {
+    fvec.resize(n3);
+    check(ctx, dc_get_force_gradient(ctx, fvec.data()), "dc_get_force_gradient");
+  }
+  const bool haveFall = windFallOff.size() == n3;
+  double total[3] = {par[4], par[5], par[6]};       // sum_i dL_dfext_vec_i, fall-off weighted for WIND_SIN_AND_FALLOFF
+  if (needVec && sceneConfig.windConfig == WIND_SIN_AND_FALLOFF && haveFall) {
+    total[0] = total[1] = total[2] = 0;
+    for (size_t k = 0; k < n3; k++) total[k % 3] += fvec[k] * windFallOff[k];
+  }
   ret.dL_dfext = gradient_new.dL_dfext;
-  if (taskInfo.dL_dfext)                        // :1702-1712
-    for (int d = 0; d < 3; d++) ret.dL_dfext[d] += par[4 + d] * fwd.windFactor;
+  if (taskInfo.dL_dfext)                        // :1700-1712
+    for (int d = 0; d < 3; d++) ret.dL_dfext[d] += total[d] * fwd.windFactor;
+  ret.dL_dconstantForceField = gradient_new.dL_dconstantForceField;
+  if (taskInfo.dL_dconstantForceField) {        // :1714-1718
+    if (ret.dL_dconstantForceField.size() != n3) ret.dL_dconstantForceField.assign(n3, 0.0);
+    for (size_t k = 0; k < n3; k++) ret.dL_dconstantForceField[k] += fvec[k];
+  }
+  ret.dL_dwindtimestep = gradient_new.dL_dwindtimestep;
+  if (taskInfo.dL_dwindFactor) {                // :1720-1729
+    if (ret.dL_dwindtimestep.size() <= (size_t) fwd.stepIdx) ret.dL_dwindtimestep.resize((size_t) fwd.stepIdx + 1, 0.0);
+    double acc = 0;
+    for (size_t k = 0; k < n3; k++) acc += fvec[k] * wind[k % 3] * windNorm * (haveFall ? windFallOff[k] : 1.0);
+    ret.dL_dwindtimestep[fwd.stepIdx] = acc;
+  }
   ret.dL_dwind = gradient_new.dL_dwind;
-  if (taskInfo.dL_dfwind) {                     // :1730-1764 (sin wind model without fall-off)
+  if (taskInfo.dL_dfwind) {                     // :1731-1760 (sin wind model, with or without fall-off)
     const double c = std::cos(windFrequency * fwd.t + windPhase);
     double tf = 0;
-    for (int d = 0; d < 3; d++) tf += par[4 + d] * wind[d] * windNorm;
-    for (int d = 0; d < 3; d++) ret.dL_dwind[d] += par[4 + d] * fwd.windFactor;
+    for (int d = 0; d < 3; d++) tf += total[d] * wind[d] * windNorm;
+    for (int d = 0; d < 3; d++) ret.dL_dwind[d] += total[d] * fwd.windFactor;
     ret.dL_dwind[3] += tf * c * 0.5 * fwd.t;
     ret.dL_dwind[4] += tf * c * 0.5;
   }

@@ -129,6 +129,8 @@ struct BackwardInformation {      // Simulation.h:136-162 (hot-path fields)
   bool converged = false;
   int convergedAccum = 0, backwardIters = 0, backwardTotalIters = 0;
   int correspondingForwardIdxInStats = 0;
+  VecXd dL_dconstantForceField;   // 3N, accumulated over the steps (Simulation.cpp:1714-1718)
+  VecXd dL_dwindtimestep;         // one entry per step (Simulation.cpp:1720-1729)
 };
 
 struct BackwardTaskInformation {  // Simulation.h:188-209
@@ -200,6 +202,11 @@ class Simulation {
   Vec3d gravity = {0, -9.8, 0};              // :356
   Vec3d wind = {0.01, 0, 1};                 // :357
   double windNorm = 0.15, windFrequency = 14, windPhase = 0;
+  VecXd windFallOff;                          // 3N per-vertex factors of the wind (Simulation.h:349; ones unless set, :2592-2593)
+  VecXd perstepWindFactor;                    // WIND_FACTOR_PER_STEP: factor of step k (Simulation.h:350, :3213-3214)
+  VecXd external_force_field;                 // 3N constant force field, added when enableConstantForcefield (Simulation.cpp:87-89)
+  bool enableConstantForcefield = false;
+  void setWindFallOffFromFocusPoint(const Vec3d &focus);   // min(1 / |focus - x_i|, 1) per vertex (Simulation.cpp:3125-3130)
   double k_stiff_attachment = 10000;           // AttachmentSpring::k_stiff (AttachmentSpring.cpp:10)
   Vec3d restShapeMinDim = {0, 0, 0}, restShapeMaxDim = {0, 0, 0}, restShapeMidPoint = {0, 0, 0};
   VecXd rlFixedPointPos;
@@ -269,7 +276,8 @@ class Simulation {
   void configureDevice();
   void pushParams();
   VecXd fixedPointTargets(double t);
-  double windFactorAt(double t) const;
+  double windFactorAt(double t, int stepIdx) const;
+  bool windHasFallOff() const { return sceneConfig.windConfig == WIND_SIN_AND_FALLOFF || sceneConfig.windConfig == WIND_FACTOR_PER_STEP; }
 
   dc_ctx *ctx = nullptr;
   int N = 0, tapeSlots = 0;

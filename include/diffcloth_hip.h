@@ -143,6 +143,10 @@ int dc_set_mu(dc_ctx *ctx, const double *mu);
 /* uniform external force added to every vertex of rollout b during the NEXT forward steps (wind*windNorm*
  * windFactor of fillForces, Simulation.cpp:96-105): f[b*3+d]; NULL = none                              */
 int dc_set_uniform_force(dc_ctx *ctx, const double *f);
+/* per-vertex external force added during the NEXT forward steps: f[b*3N + 3i + d] (xyz interleaved like the states). Carries
+ * what fillForces adds per vertex beyond gravity and the uniform wind: wind * windNorm * windFactor (.) windFallOff for
+ * WIND_SIN_AND_FALLOFF / WIND_FACTOR_PER_STEP and the constant force field (Simulation.cpp:87-105); NULL = none       */
+int dc_set_vertex_forces(dc_ctx *ctx, const double *f /*B*3N or NULL*/);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* Simulation::step()/stepNN() (Simulation.cpp:1020-1428): advance slot -> slot+1 for all rollouts.
@@ -172,6 +176,10 @@ int dc_step_backward(dc_ctx *ctx, int slot, const double *dL_dxnew, const double
  * dL/ddensity (adddr_dd = false), [4..6] h^2 * sum_i ((I + dr_df)^T u*)_i = the summed dL_dfext_vec from which the
  * caller forms dL_dfext / dL_dwind (multiply by windFactor, cos(...) etc. as :1730-1760), [7] unused.            */
 int dc_get_param_gradients(dc_ctx *ctx, int slot, double *out /*B*8*/);
+/* dL/df per vertex of the LAST backward step: h^2 ((I + dr_df)^T u*)_i, B*3N xyz interleaved — the vector the reference
+ * calls dL_dfext_vec (Simulation.cpp:1700-1760), from which dL_dconstantForceField (sum over the steps), dL_dwindtimestep
+ * (dot with (wind * windNorm) (.) windFallOff) and the fall-off variants of dL_dfext / dL_dwind are formed.            */
+int dc_get_force_gradient(dc_ctx *ctx, double *dL_df /*B*3N*/);
 
 /* ---- device-resident rollouts (no host copies inside; used by bench.py and batched callers) --------- */
 /* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Asynchronous. When the packet

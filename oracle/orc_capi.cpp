@@ -30,6 +30,16 @@ void orc_set_wind(void *s, int enabled, int config, const double *w) {
   S->P.windEnabled = enabled; S->P.windConfig = config;
   S->P.wind = V3(w[0], w[1], w[2]); S->P.windNorm = w[3]; S->P.windFrequency = w[4]; S->P.windPhase = w[5];
 }
+// per-vertex wind fall-off (3N or NULL = ones), constant force field (3N or NULL = off), per-step wind factor of the next step
+void orc_set_force_extras(void *s, const double *falloff, const double *field, double perStepFactor) {
+  Sim *S = (Sim *) s;
+  const size_t n3 = 3 * (size_t) S->N;
+  S->windFallOff.clear(); S->external_force_field.clear();
+  if (falloff) S->windFallOff.assign(falloff, falloff + n3);
+  if (field) S->external_force_field.assign(field, field + n3);
+  S->P.enableConstantForcefield = field != nullptr;
+  S->P.perStepWindFactor = perStepFactor;
+}
 void orc_clear_primitives(void *s) { ((Sim *) s)->prims.clear(); }
 void orc_add_sphere(void *s, const double *center, double radius, double mu, int rotates) {
   Primitive p; p.kind = PRIM_SPHERE; p.center = V3(center[0], center[1], center[2]); p.radius = radius; p.mu = mu; p.rotates = rotates;
@@ -160,11 +170,11 @@ int orc_get_self_contacts(void *s, int id, int *ints, double *dbls, int cap) {
     }
   return total;
 }
-// Backward through record `id`. scal: [dL_dk_stretch, dL_dk_bend, dL_dk_att, dL_ddensity, dL_dwind(5)] (9 doubles)
+// Backward through record `id`. scal: [dL_dk_stretch, dL_dk_bend, dL_dk_att, dL_ddensity, dL_dwind(5), dL_dwindtimestep] (10 doubles)
 // info: [converged, backwardIters, usedDirect]
 void orc_step_backward(void *s, int id, const double *dL_dxnew, const double *dL_dvnew, const double *dL_dxinit,
                        const double *dL_dvinit, int isStart, int forceDirect, double *dL_dx, double *dL_dv,
-                       double *dL_dxfixed, int numMu, double *dL_dmu, double *scal, int *info) {
+                       double *dL_dxfixed, int numMu, double *dL_dmu, double *scal, int *info, double *dfext_vec /*3N or NULL*/) {
   Sim *S = (Sim *) s;
   BackwardOut o = S->stepBackward(S->records[id], dL_dxnew, dL_dvnew, dL_dxinit, dL_dvinit, isStart, forceDirect, numMu);
   std::memcpy(dL_dx, o.dL_dx.data(), sizeof(double) * o.dL_dx.size());
@@ -173,6 +183,8 @@ void orc_step_backward(void *s, int id, const double *dL_dxnew, const double *dL
   if (dL_dmu) std::memcpy(dL_dmu, o.dL_dmu.data(), sizeof(double) * o.dL_dmu.size());
   if (scal) { for (int k = 0; k < 3; k++) scal[k] = o.dL_dk[k]; scal[3] = o.dL_ddensity; for (int k = 0; k < 5; k++) scal[4 + k] = o.dL_dwind[k]; }
   if (info) { info[0] = o.converged; info[1] = o.backwardIters; info[2] = o.usedDirect; }
+  if (scal) scal[9] = o.dL_dwindtimestep;
+  if (dfext_vec) std::memcpy(dfext_vec, o.dL_dfext_vec.data(), sizeof(double) * o.dL_dfext_vec.size());
 }
 // Collision detection + layering only (for tests of Sim.cpp:225-624).
 int orc_detect(void *s, const double *x_n, const double *v, int *nprim, int *nself, int *nlayers) {

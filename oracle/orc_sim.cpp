@@ -697,19 +697,28 @@ void Sim::dryFrictionVector(const std::vector<double> &f, std::vector<PrimContac
 // Forward step
 // ------------------------------------------------------------------------------------------------
 
-// Simulation::fillForces Sim.cpp:55-116 (gravity + uniform wind; fall-off / per-step / force-field variants omitted).
+// Simulation::fillForces Sim.cpp:55-116: gravity, wind (constant / sin / per-step factor, with the per-vertex fall-off for
+// WIND_SIN_AND_FALLOFF and WIND_FACTOR_PER_STEP), constant force field.
 double Sim::fillForces(std::vector<double> &f_ext, double t_now) const {
   f_ext.assign(3 * (size_t) N, 0.0);
   double windFactor = 1.0;
   switch (P.windConfig) {
+    case 3:
     case 2: windFactor = (std::sin(P.windFrequency * t_now + P.windPhase) + 1.0) / 2.0; break;
     case 0: windFactor = 0.0; break;
+    case 4: windFactor = P.perStepWindFactor; break;
     default: windFactor = 1.0; break;
   }
+  if (P.enableConstantForcefield && external_force_field.size() == f_ext.size()) f_ext = external_force_field;
+  const bool fall = (P.windConfig == 3 || P.windConfig == 4) && windFallOff.size() == f_ext.size();
   for (int i = 0; i < N; i++) {
     V3 f_i;
     if (P.gravityEnabled) f_i += P.gravity * mass[i];
-    if (P.windEnabled) f_i += P.wind * (P.windNorm * windFactor);
+    if (P.windEnabled) {
+      V3 wf = P.wind * (P.windNorm * windFactor);
+      if (fall) wf = V3(wf.x * windFallOff[3 * i], wf.y * windFallOff[3 * i + 1], wf.z * windFallOff[3 * i + 2]);
+      f_i += wf;
+    }
     addseg3(f_ext, i, f_i);
   }
   return windFactor;
@@ -1059,10 +1068,29 @@ BackwardOut Sim::stepBackward(const Record &rec, const double *dL_dxnew_in, cons
       }
     out.dL_ddensity = s;
   }
-  // --- dL/dwind (Sim.cpp:1730-1764), WIND_SIN without fall-off ---
+  // --- dL_dfext_vec, dL/dconstantForceField (= this vector, summed over the steps by the caller), dL/dwindtimestep
+  //     (Sim.cpp:1714-1729) ---
+  out.dL_dfext_vec.resize(n3);
+  for (int i = 0; i < N; i++) {
+    const V3 q = (seg3(u, i) + seg3(w, i)) * t2;
+    out.dL_dfext_vec[3 * i] = q.x; out.dL_dfext_vec[3 * i + 1] = q.y; out.dL_dfext_vec[3 * i + 2] = q.z;
+  }
+  const bool fallAny = windFallOff.size() == n3;
+  {
+    const V3 wf = P.wind * P.windNorm;
+    double acc = 0;
+    for (int i = 0; i < N; i++)
+      for (int d = 0; d < 3; d++) acc += out.dL_dfext_vec[3 * i + d] * wf[d] * (fallAny ? windFallOff[3 * i + d] : 1.0);
+    out.dL_dwindtimestep = acc;
+  }
+  // --- dL/dwind (Sim.cpp:1730-1764), sin wind model with or without fall-off ---
   if (P.windEnabled) {
     V3 tot;
-    for (int i = 0; i < N; i++) tot += (seg3(u, i) + seg3(w, i)) * t2;
+    for (int i = 0; i < N; i++) {
+      V3 q = (seg3(u, i) + seg3(w, i)) * t2;
+      if (P.windConfig == 3 && fallAny) q = V3(q.x * windFallOff[3 * i], q.y * windFallOff[3 * i + 1], q.z * windFallOff[3 * i + 2]);
+      tot += q;
+    }
     V3 windForce = P.wind * P.windNorm;
     double c = std::cos(P.windFrequency * rec.t + P.windPhase);
     for (int d = 0; d < 3; d++) out.dL_dwind[d] = tot[d] * rec.windFactor;

@@ -70,6 +70,8 @@ struct BackwardOut {      // BackwardInformation, Simulation.h:136-162 (hot-path
   double dL_dk[3] = {0, 0, 0};   // stretch, bend, attachment
   double dL_ddensity = 0;
   double dL_dwind[5] = {0, 0, 0, 0, 0};
+  std::vector<double> dL_dfext_vec;   // h^2 (I + dr_df)^T u* per vertex (Sim.cpp:1700-1760)
+  double dL_dwindtimestep = 0;       // this step's entry (Sim.cpp:1720-1729)
   bool converged = false;
   int backwardIters = 0;
   bool usedDirect = false;
@@ -83,7 +85,9 @@ struct Params {
   bool gravityEnabled = true, contactEnabled = true, selfcollisionEnabled = true, windEnabled = false;
   bool gradientClipping = true;                                          // Simulation.h:330-331
   double gradientClippingThreshold = 16.0;
-  int windConfig = 0;                   // 0 NO_WIND, 1 WIND_CONSTANT, 2 WIND_SIN (engine/Constants.h)
+  int windConfig = 0;                   // 0 NO_WIND, 1 WIND_CONSTANT, 2 WIND_SIN, 3 WIND_SIN_AND_FALLOFF, 4 WIND_FACTOR_PER_STEP (engine/Constants.h:55-61)
+  double perStepWindFactor = 1.0;       // perstepWindFactor[step] of the step being taken (Sim.cpp:80-82)
+  bool enableConstantForcefield = false;
   V3 wind = V3(0.01, 0, 1);             // Simulation.h:357
   double windNorm = 0.15, windFrequency = 14, windPhase = 0;   // Simulation.cpp:20-22
   bool calcSeparateAtp = false;         // calcualteSeperateAt_p
@@ -94,6 +98,8 @@ struct Params {
 struct Sim {
   Params P;
   int N = 0;
+  std::vector<double> windFallOff;          // 3N (Simulation.h:349), empty = ones
+  std::vector<double> external_force_field; // 3N (Simulation.h:418)
   std::vector<double> rest;                 // 3N rest positions (pos_rest)
   std::vector<std::array<int, 3>> tris_in;
   std::vector<TriRest> tris;

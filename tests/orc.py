@@ -93,6 +93,12 @@ class Oracle:
     def set_wind(self, enabled, config, wind, norm, freq, phase):
         self.L.orc_set_wind(self.h, C.c_int(int(enabled)), C.c_int(config), _d(f64([*wind, norm, freq, phase])))
 
+    def set_force_extras(self, falloff=None, field=None, per_step_factor=1.0):
+        """windFallOff (3N), constant force field (3N), perstepWindFactor of the next step (Simulation.cpp:55-116)"""
+        fo = None if falloff is None else f64(falloff).reshape(-1)
+        fi = None if field is None else f64(field).reshape(-1)
+        self.L.orc_set_force_extras(self.h, None if fo is None else _d(fo), None if fi is None else _d(fi), C.c_double(per_step_factor))
+
     def add_sphere(self, center, radius, mu, rotates=False):
         self.L.orc_add_sphere(self.h, _d(f64(center)), C.c_double(radius), C.c_double(mu), C.c_int(int(rotates)))
         self.nprim += 1
@@ -200,11 +206,12 @@ class Oracle:
         iv = f64(dL_dvinit if dL_dvinit is not None else z).reshape(-1)
         num_mu = self.nprim if num_mu is None else num_mu
         dx = f64(np.zeros(n3)); dv = f64(np.zeros(n3)); dxf = f64(np.zeros(max(3 * self.Af, 1)))
-        dmu = f64(np.zeros(max(num_mu, 1))); scal = f64(np.zeros(9)); info = i32(np.zeros(3))
+        dmu = f64(np.zeros(max(num_mu, 1))); scal = f64(np.zeros(10)); info = i32(np.zeros(3)); fvec = f64(np.zeros(n3))
         self.L.orc_step_backward(self.h, C.c_int(rid), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
-                                 C.c_int(int(direct)), _d(dx), _d(dv), _d(dxf), C.c_int(num_mu), _d(dmu), _d(scal), _i(info))
+                                 C.c_int(int(direct)), _d(dx), _d(dv), _d(dxf), C.c_int(num_mu), _d(dmu), _d(scal), _i(info), _d(fvec))
         return dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:3 * self.Af], dL_dmu=dmu[:num_mu], dL_dk=scal[0:3],
-                    dL_ddensity=scal[3], dL_dwind=scal[4:9], converged=bool(info[0]), iters=int(info[1]),
+                    dL_ddensity=scal[3], dL_dwind=scal[4:9], dL_dwindtimestep=float(scal[9]), dL_dfext_vec=fvec,
+                    converged=bool(info[0]), iters=int(info[1]),
                     used_direct=bool(info[2]))
 
     def detect(self, x, v):

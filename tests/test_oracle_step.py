@@ -238,3 +238,46 @@ def test_iterative_adjoint_matches_direct():
     assert it["converged"] and not it["used_direct"] and it["iters"] > 1
     np.testing.assert_allclose(it["dL_dx"], d["dL_dx"], atol=1e-8 * np.abs(d["dL_dx"]).max())
     np.testing.assert_allclose(it["dL_dv"], d["dL_dv"], atol=1e-8 * np.abs(d["dL_dv"]).max())
+
+
+def test_step_gradient_fd_force_field_and_wind_factors():
+    """fillForces' per-vertex terms (Simulation.cpp:87-105) and their gradients (:1714-1760): wind with fall-off and a
+    per-step factor, constant force field — dL_dfext_vec / dL_dwindtimestep / dL_dwind against central differences."""
+    V, F, o = make_sphere_case(nx=7, tol=1e-13, mu=0.3, k_bend=0.2)
+    x0, v0, xf, cx, cv = _loss_setup(o, V, 45)
+    rng = np.random.default_rng(17)
+    n3 = x0.size
+    fall = np.repeat(rng.uniform(0.2, 1.0, n3 // 3), 3)
+    field = 1e-3 * rng.standard_normal(n3)
+    wdir = np.array([0.3, 0.1, 0.9]); wdir /= np.linalg.norm(wdir)
+    h = o.params["h"]
+
+    def run(factor, fld, frozen=-1, config=4, freq=9.0, phase=0.4, norm=0.02, w=wdir):
+        o.set_wind(True, config, w, norm, freq, phase)
+        o.set_force_extras(fall, fld, factor)
+        return _L(o, x0, v0, xf, cx, cv, frozen)
+
+    # per-step factor (WIND_FACTOR_PER_STEP) + force field
+    L0, out = run(0.7, field)
+    bw = o.step_backward(out["id"], cx + cv / h, cv, is_start=True, direct=True)
+    eps = 1e-4
+    fd = (run(0.7 + eps, field, out["id"])[0] - run(0.7 - eps, field, out["id"])[0]) / (2 * eps)
+    assert abs(fd - bw["dL_dwindtimestep"]) <= 2e-4 * max(abs(fd), 1e-6), (fd, bw["dL_dwindtimestep"])   # (FD noise: L changes by 1e-10)
+    for i in (5, 40, 100):
+        e = np.zeros(n3); e[i] = 1e-5
+        fd = (run(0.7, field + e, out["id"])[0] - run(0.7, field - e, out["id"])[0]) / 2e-5
+        assert abs(fd - bw["dL_dfext_vec"][i]) <= 2e-4 * max(abs(fd), 1e-6), (i, fd, bw["dL_dfext_vec"][i])
+    # sin wind with fall-off: the five wind parameters (force vector = direction * norm, frequency, phase)
+    L0, out = run(1.0, None, config=3)
+    bw = o.step_backward(out["id"], cx + cv / h, cv, is_start=True, direct=True)
+    base = np.array([*(wdir * 0.02), 9.0, 0.4])
+    for k, eps in ((0, 1e-6), (2, 1e-6), (3, 1e-4), (4, 1e-5)):
+        vals = []
+        for sgn in (1, -1):
+            q = base.copy(); q[k] += sgn * eps
+            n = np.linalg.norm(q[:3])
+            vals.append(run(1.0, None, out["id"], config=3, freq=q[3], phase=q[4], norm=n, w=q[:3] / n)[0])
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(fd - bw["dL_dwind"][k]) <= 2e-3 * max(abs(fd), 1e-7), (k, fd, bw["dL_dwind"])     # (FD noise on 1e-6-sized slopes)
+    o.set_wind(False, 0, wdir, 0.0, 0.0, 0.0)
+    o.set_force_extras(None, None, 1.0)
