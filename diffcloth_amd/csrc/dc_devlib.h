@@ -174,7 +174,9 @@ __device__ __forceinline__ bool prim_in_contact(const DevPrim &p, f3 pos, f3 &no
 }
 // Simulation::isInContactWithObstacle (Simulation.cpp:153-191): t = 0, h/2, h; first primitive / first sample wins.
 // Children of one LowerLeg share a group and are tested, per sample, in child order (Primitive.cpp:410-418).
-__device__ __forceinline__ int detect_primitive(const DevSystem &S, f3 pos, f3 vel, f3 &normal) {
+// (not inlined: it runs once per vertex and step, and its plane / capsule branches must not weigh on the register allocation
+// of the PD / PCG loops of the kernels that call it)
+__device__ __attribute__((noinline)) int detect_primitive(const DevSystem &S, f3 pos, f3 vel, f3 &normal) {
   int p0 = 0;
   while (p0 < S.nprim) {
     int p1 = p0;
