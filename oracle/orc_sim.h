@@ -5,7 +5,8 @@
 //   Simulation::step()          /root/reference/src/code/simulation/Simulation.cpp:1043-1428
 //   Simulation::stepBackward()  Simulation.cpp:1455-1780
 // and their callees. Every function cites the reference lines it follows.
-// Parity status: pinned against output/tshirt-exampleopt (tests/test_golden_tshirt.py) and validated by
+// Parity status: pinned against output/tshirt-exampleopt — frames 0..40 of iter0 and the logged loss of evaluation 0
+// (tests/test_golden_tshirt.py) — and validated by
 // finite differences + an independent NumPy/SciPy single-step cross-check (tests/test_oracle_*.py).
 #pragma once
 #include "orc_math.h"

@@ -59,9 +59,14 @@ def main():
     flog = open(os.path.join(run, "forwardLog.txt")).read()
     losses = [float(v) for v in re.findall(r"Loss:([-\d.eE]+)", flog)]
     pditers = [int(v) for v in re.findall(r"Total PD Iters:(\d+)", flog)]
+    # parameters of every logged forward evaluation (forwardLog.txt prints them after each record)
+    log_k = [float(v) for v in re.findall(r"k_CONSTRAINT_TRIANGLE:([-\d.eE]+)", flog)]
+    log_wind = [[float(t) for t in m.split(",")] for m in re.findall(r"f_wind:\(([^)]*)\)", flog)]
+    assert len(log_k) == len(log_wind) == len(losses)
     np.savez_compressed(os.path.join(OUT, "tshirt_golden.npz"), frames=np.asarray(frames, dtype=np.float64),
                         frame250=last, k_stretch=k_stretch, f_wind=np.asarray(wind), clips=np.asarray(clips),
-                        losses=np.asarray(losses), pd_iters=np.asarray(pditers))
+                        losses=np.asarray(losses), pd_iters=np.asarray(pditers), log_k=np.asarray(log_k),
+                        log_wind=np.asarray(log_wind))
     print("golden frames", np.asarray(frames).shape, "k", k_stretch, "wind", wind, "clips", clips, "loss0", losses[0], "pd0", pditers[0])
 
 

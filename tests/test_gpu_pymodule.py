@@ -190,3 +190,25 @@ def test_optimize_helper_tshirt_system_identification_demo():
         fd = (h.runSimulationAndGetLoss(xp) - h.runSimulationAndGetLoss(xm)) / (2 * eps)
         print(f"\n[tshirt demo] {h.paramName[k]}: adjoint {g[k]:.4e} finite difference {fd:.4e}")
         assert abs(g[k] - fd) <= 0.25 * abs(fd)
+
+
+def test_tshirt_demo_reproduces_the_reference_loss_sequence():
+    """End to end against the reference's own log (output/tshirt-exampleopt/forwardLog.txt, frozen in
+    tests/golden/tshirt_golden.npz): the loss of the 250-step T-shirt rollout at the parameters of its logged L-BFGS
+    evaluations — ground-truth rollout, sinusoidal wind, self-collision, MATCH_TRAJECTORY loss, all through
+    diffcloth_py.OptimizeHelper on the GPU. The log keeps 6 decimals of the parameters and the rollouts are 250 chaotic
+    steps, so the comparison is at the few-percent level ("loss sequence at ~1e-2")."""
+    d = pytest.importorskip("diffcloth_py")
+    g = np.load(os.path.join(scenes.GOLDEN, "tshirt_golden.npz"))
+    V, F = scenes.load_mesh("tshirt")
+    sim = d.makeSimFromMesh("wind_tshirt", V.reshape(-1), F.reshape(-1).tolist())
+    h = d.makeOptimizeHelperWithSim("wind_tshirt", sim)
+    assert h.forward_steps == 250
+    rows = []
+    for rec in (0, 1, 2, 3, 8, 17):
+        x = np.array([*g["log_wind"][rec], g["log_k"][rec]])
+        L = h.runSimulationAndGetLoss(x)
+        rows.append((rec, L, float(g["losses"][rec])))
+    print("\n[tshirt log] evaluation: loss here / loss in the reference's log: " + ", ".join(f"{r}: {a:.5f} / {b:.5f}" for r, a, b in rows))
+    for rec, L, ref in rows:
+        assert abs(L - ref) <= 0.05 * ref + 2e-3, (rec, L, ref)
