@@ -5,7 +5,7 @@ The GPU box has no /root/reference, so everything the tests need from it is froz
   meshes.npz         raw OBJ vertices / triangles of the demo meshes (src/assets/meshes/remeshed/...)
   tshirt_golden.npz  the reference's only golden data: output/tshirt-exampleopt/iter0 — first frames of the
                      1426-vertex T-shirt rollout of L-BFGS evaluation 0, with the parameters of that run
-                     (iter0/param.txt) and the loss / iteration counts of forwardLog.txt
+                     (iter0/param.txt), the losses / parameters / iteration counts of forwardLog.txt and the gradients of backwardLog.txt
 """
 import os
 import re
@@ -63,10 +63,17 @@ def main():
     log_k = [float(v) for v in re.findall(r"k_CONSTRAINT_TRIANGLE:([-\d.eE]+)", flog)]
     log_wind = [[float(t) for t in m.split(",")] for m in re.findall(r"f_wind:\(([^)]*)\)", flog)]
     assert len(log_k) == len(log_wind) == len(losses)
+    # backwardLog.txt: gradients (4-5 decimals) and adjoint iteration totals of every backward sweep
+    blog = open(os.path.join(run, "backwardLog.txt")).read()
+    grad_k = [float(v) for v in re.findall(r"dL/dk_CONSTRAINT_TRIANGLE:([-\d.eE]+)", blog)]
+    grad_wind = [[float(t) for t in m.split(",")] for m in re.findall(r"dL/df_wind:\(([^)]*)\)", blog)]
+    bwd_iters = [int(v) for v in re.findall(r"Total Backward Iter:(\d+)", blog)]
+    bwd_fwd_idx = [int(v) for v in re.findall(r"Corresponding forward Idx: (\d+)", blog)]
     np.savez_compressed(os.path.join(OUT, "tshirt_golden.npz"), frames=np.asarray(frames, dtype=np.float64),
                         frame250=last, k_stretch=k_stretch, f_wind=np.asarray(wind), clips=np.asarray(clips),
                         losses=np.asarray(losses), pd_iters=np.asarray(pditers), log_k=np.asarray(log_k),
-                        log_wind=np.asarray(log_wind))
+                        log_wind=np.asarray(log_wind), grad_k=np.asarray(grad_k), grad_wind=np.asarray(grad_wind),
+                        bwd_iters=np.asarray(bwd_iters), bwd_fwd_idx=np.asarray(bwd_fwd_idx))
     print("golden frames", np.asarray(frames).shape, "k", k_stretch, "wind", wind, "clips", clips, "loss0", losses[0], "pd0", pditers[0])
 
 

@@ -193,7 +193,7 @@ def test_optimize_helper_tshirt_system_identification_demo():
 
 
 def test_tshirt_demo_reproduces_the_reference_loss_sequence():
-    """End to end against the reference's own log (output/tshirt-exampleopt/forwardLog.txt, frozen in
+    """End to end against the reference's own logs (output/tshirt-exampleopt/forwardLog.txt and backwardLog.txt, frozen in
     tests/golden/tshirt_golden.npz): the loss of the 250-step T-shirt rollout at the parameters of its logged L-BFGS
     evaluations — ground-truth rollout, sinusoidal wind, self-collision, MATCH_TRAJECTORY loss, all through
     diffcloth_py.OptimizeHelper on the GPU. The log keeps 6 decimals of the parameters and the rollouts are 250 chaotic
@@ -207,7 +207,23 @@ def test_tshirt_demo_reproduces_the_reference_loss_sequence():
     rows = []
     for rec in (0, 1, 2, 3, 8, 17):
         x = np.array([*g["log_wind"][rec], g["log_k"][rec]])
-        L = h.runSimulationAndGetLoss(x)
+        if rec <= 2:
+            # backwardLog.txt of the same run: gradients w.r.t. the 5 wind parameters and the stretching stiffness after the
+            # 250-step backward sweep (the reference's adjoint iteration at its 5e-4 threshold, gradient clipping on), and
+            # the total number of adjoint iterations of the sweep
+            recs = h.runSimulationAndGetLossGradient(x)
+            L = recs[0].loss
+            grad = h.gradientInfoToVecXd(recs[0])
+            ref_g = np.array([*g["grad_wind"][rec], g["grad_k"][rec]])
+            print(f"\n[tshirt log] evaluation {rec}: gradient here {np.round(grad, 5)} / logged {ref_g}; adjoint iterations "
+                  f"{recs[0].backwardTotalIters} / {int(g['bwd_iters'][rec])}")
+            big = np.abs(ref_g) > 0.05 * np.abs(ref_g).max()
+            assert np.all(np.abs(grad[big] - ref_g[big]) <= 0.05 * np.abs(ref_g[big])), (rec, grad, ref_g)      # dominant components to 5 %
+            assert np.all(np.sign(grad) == np.sign(ref_g)) and np.all(np.abs(grad - ref_g) <= 0.15 * np.abs(ref_g) + 2e-4), (rec, grad, ref_g)
+            assert abs(recs[0].backwardTotalIters - int(g["bwd_iters"][rec])) <= 0.02 * int(g["bwd_iters"][rec])
+            assert recs[0].convergedAccum == 250
+        else:
+            L = h.runSimulationAndGetLoss(x)
         rows.append((rec, L, float(g["losses"][rec])))
     print("\n[tshirt log] evaluation: loss here / loss in the reference's log: " + ", ".join(f"{r}: {a:.5f} / {b:.5f}" for r, a, b in rows))
     for rec, L, ref in rows:
