@@ -98,6 +98,9 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readonly("maxDeformation", &ForwardInformation::maxDeformation)
       .def_readonly("converged", &ForwardInformation::converged)
       .def_readonly("convergeIter", &ForwardInformation::convergeIter)
+      .def_readonly("cumulateIter", &ForwardInformation::cumulateIter)         // "Total PD Iters" of forwardLog.txt
+      .def_readonly("totalConverged", &ForwardInformation::totalConverged)     // "Total Frames Converged"
+      .def_readonly("totalRuntime", &ForwardInformation::totalRuntime)
       .def_property_readonly("collisionInfos", [](const ForwardInformation &r) {
         // completeCollisionInfo = ((primitive contacts, self contacts), layers)
         std::vector<SelfCollisionInformation> flat;

@@ -222,6 +222,9 @@ def test_tshirt_demo_reproduces_the_reference_loss_sequence():
             assert np.all(np.sign(grad) == np.sign(ref_g)) and np.all(np.abs(grad - ref_g) <= 0.15 * np.abs(ref_g) + 2e-4), (rec, grad, ref_g)
             assert abs(recs[0].backwardTotalIters - int(g["bwd_iters"][rec])) <= 0.02 * int(g["bwd_iters"][rec])
             assert recs[0].convergedAccum == 250
+            last = sim.getStateInfo()
+            print(f"[tshirt log] evaluation {rec}: PD iterations of the 250 steps {last.cumulateIter} / {int(g['pd_iters'][rec])}, frames converged {last.totalConverged}")
+            assert last.totalConverged == 250 and abs(last.cumulateIter - int(g["pd_iters"][rec])) <= 0.05 * int(g["pd_iters"][rec])
         else:
             L = h.runSimulationAndGetLoss(x)
         rows.append((rec, L, float(g["losses"][rec])))
