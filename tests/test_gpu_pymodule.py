@@ -231,3 +231,31 @@ def test_tshirt_demo_reproduces_the_reference_loss_sequence():
     print("\n[tshirt log] evaluation: loss here / loss in the reference's log: " + ", ".join(f"{r}: {a:.5f} / {b:.5f}" for r, a, b in rows))
     for rec, L, ref in rows:
         assert abs(L - ref) <= 0.05 * ref + 2e-3, (rec, L, ref)
+
+
+@pytest.mark.parametrize("demo,mesh,steps,nparam", [("wear_sock", "sock", 400, None), ("dress_twirl", "dress", 6, 2)])
+def test_remaining_demo_helpers_run_a_short_rollout_with_gradients(demo, mesh, steps, nparam):
+    """wear_sock (ASSISTED_DRESSING_KEYPOINTS loss, spline control points of four clips, LowerLeg capsules) and dress_twirl
+    (DRESS_ANGLE loss, density + bending stiffness, 31 twirling attachments, self-collision): helper construction, parameter
+    vector <-> ParamInfo round trip, a short rollout with its backward sweep, finite gradients of the right size, and a
+    finite-difference check of one parameter."""
+    d = pytest.importorskip("diffcloth_py")
+    V, F = scenes.load_mesh(mesh)
+    sim = d.makeSimFromMesh(demo, V.reshape(-1), F.reshape(-1).tolist())
+    h = d.makeOptimizeHelperWithSim(demo, sim)
+    h.forward_steps = steps          # (the sock's key-point targets sit at the scene's last frame, 400: full horizon there)
+    x = h.getRandomParam(3)
+    assert np.all(x >= np.array(h.paramLowerBound) - 1e-12) and np.all(x <= np.array(h.paramUpperBound) + 1e-12)
+    np.testing.assert_allclose(h.paramInfoToVecXd(h.vecXdToParamInfo(x)), x, rtol=1e-12, atol=1e-14)
+    if nparam is not None:
+        assert len(x) == nparam
+    recs = h.runSimulationAndGetLossGradient(x)
+    assert len(recs) == steps + 1 and np.isfinite(recs[0].loss) and recs[0].loss > 0
+    g = h.gradientInfoToVecXd(recs[0])
+    assert g.shape == x.shape and np.isfinite(g).all() and np.abs(g).max() > 0
+    k = int(np.argmax(np.abs(g)))
+    eps = 1e-3 * max(abs(x[k]), 1e-2)
+    xp = x.copy(); xp[k] += eps; xm = x.copy(); xm[k] -= eps
+    fd = (h.runSimulationAndGetLoss(xp) - h.runSimulationAndGetLoss(xm)) / (2 * eps)
+    print(f"\n[{demo}] {len(x)} parameters, loss {recs[0].loss:.5e}; d/d{h.paramName[k]}[{k}]: adjoint {g[k]:.4e} finite difference {fd:.4e}")
+    assert g[k] * fd > 0 and 0.5 <= g[k] / fd <= 2.0
