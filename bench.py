@@ -85,7 +85,7 @@ def cpu_baseline(args, V, F, center, x0, v0, mu, steps, gscale):
                        f"reference adjoint iteration")
 
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01f_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01g_traffic.json")
 
 
 def measured_traffic(args, K, W, B):
