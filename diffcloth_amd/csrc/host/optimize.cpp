@@ -137,7 +137,7 @@ void Simulation::resetSystemWithParams(BackwardTaskInformation &task, ParamInfo 
     for (int d = 0; d < 3; d++) wind[d] = n > 0 ? param.f_extwind[d] / n : 0.0;
     windFrequency = param.f_extwind[3]; windPhase = param.f_extwind[4];
   }
-  if (task.dL_dconstantForceField) external_force_field = param.f_constantForceField;   // Simulation.cpp:3524-3526
+  if (task.dL_dconstantForceField) external_force_field = param.f_constantForceField;   // Simulation.cpp:3524-3526 (enableConstantForcefield stays the caller's switch)
   if (task.dL_dwindFactor) perstepWindFactor = param.f_ext_timestep;                    // :3528-3530
   if (task.dL_dcontrolPoints && !param.controlPointSplines.empty()) controlPointSplines = param.controlPointSplines[0];
   if (task.dL_dmu)
@@ -232,6 +232,10 @@ void OptimizeHelper::setParameterBounds() {
     offset.dL_dx0 = totalParamNumber; totalParamNumber += 3 * system->getNumParticles();
     for (int i = 0; i < 3 * system->getNumParticles(); i++) add(-1e30, 1e30, false, "x0");   // the reference bounds x0 by the scene box
   }
+  if (taskInfo.dL_dconstantForceField) {     // OptimizeHelper.cpp:98-107
+    offset.dL_dconstantForceField = totalParamNumber; totalParamNumber += 3 * system->getNumParticles();
+    for (int i = 0; i < 3 * system->getNumParticles(); i++) add(-10, 10, false, "constantForceField");
+  }
   for (int i = 0; i < 4; i++)
     if (taskInfo.dL_dk_pertype[i]) { offset.dL_k[i] = totalParamNumber; totalParamNumber += 1; add(stiffnessBounds[i].first, stiffnessBounds[i].second, false, typeNames[i]); }
   if (taskInfo.dL_density) { offset.dL_density = totalParamNumber; totalParamNumber += 1; add(0.01, 1.0, false, "density"); }
@@ -258,6 +262,7 @@ VecXd OptimizeHelper::paramInfoToVecXd(const ParamInfo &param) const {
   if (taskInfo.dL_dfwind) for (int i = 0; i < 5; i++) x[offset.dL_dfwind + i] = param.f_extwind[i];
   if (taskInfo.dL_dfext) for (int i = 0; i < 3 && i < (int) param.f_ext.size(); i++) x[offset.dL_dfext + i] = param.f_ext[i];
   if (taskInfo.dL_dx0) for (size_t i = 0; i < param.x0.size(); i++) x[offset.dL_dx0 + i] = param.x0[i];
+  if (taskInfo.dL_dconstantForceField) for (size_t i = 0; i < param.f_constantForceField.size(); i++) x[offset.dL_dconstantForceField + i] = param.f_constantForceField[i];
   for (int i = 0; i < 4; i++) if (taskInfo.dL_dk_pertype[i]) x[offset.dL_k[i]] = param.k_pertype[i];
   if (taskInfo.dL_density) x[offset.dL_density] = param.density;
   if (taskInfo.dL_dmu) for (size_t i = 0; i < taskInfo.mu_primitives.size() && i < param.mu.size(); i++) x[offset.dL_dmu[i]] = param.mu[i].second;
@@ -274,6 +279,8 @@ ParamInfo OptimizeHelper::vecXdToParamInfo(const VecXd &x) const {
   if (taskInfo.dL_dfwind) for (int i = 0; i < 5; i++) param.f_extwind[i] = x[offset.dL_dfwind + i];
   if (taskInfo.dL_dfext) param.f_ext.assign(x.begin() + offset.dL_dfext, x.begin() + offset.dL_dfext + 3);
   if (taskInfo.dL_dx0) param.x0.assign(x.begin() + offset.dL_dx0, x.begin() + offset.dL_dx0 + 3 * system->getNumParticles());
+  if (taskInfo.dL_dconstantForceField)
+    param.f_constantForceField.assign(x.begin() + offset.dL_dconstantForceField, x.begin() + offset.dL_dconstantForceField + 3 * system->getNumParticles());
   for (int i = 0; i < 4; i++) if (taskInfo.dL_dk_pertype[i]) param.k_pertype[i] = x[offset.dL_k[i]];
   if (taskInfo.dL_density) param.density = x[offset.dL_density];
   if (taskInfo.dL_dmu) for (size_t i = 0; i < taskInfo.mu_primitives.size(); i++) param.mu.push_back({taskInfo.mu_primitives[i], x[offset.dL_dmu[i]]});
@@ -299,6 +306,7 @@ VecXd OptimizeHelper::gradientInfoToVecXd(const BackwardInformation &b) const {
   if (taskInfo.dL_dfwind) for (int i = 0; i < 5; i++) g[offset.dL_dfwind + i] = b.dL_dwind[i];
   if (taskInfo.dL_dx0) for (size_t i = 0; i < b.dL_dx.size(); i++) g[offset.dL_dx0 + i] = b.dL_dx[i];
   if (taskInfo.dL_dfext) for (int i = 0; i < 3; i++) g[offset.dL_dfext + i] = b.dL_dfext[i];
+  if (taskInfo.dL_dconstantForceField) for (size_t i = 0; i < b.dL_dconstantForceField.size(); i++) g[offset.dL_dconstantForceField + i] = b.dL_dconstantForceField[i];
   for (int i = 0; i < 4; i++) if (taskInfo.dL_dk_pertype[i]) g[offset.dL_k[i]] = b.dL_dk_pertype[i];
   if (taskInfo.dL_density) g[offset.dL_density] = b.dL_ddensity;
   if (taskInfo.dL_dmu) for (size_t i = 0; i < taskInfo.mu_primitives.size() && i < b.dL_dmu.size(); i++) g[offset.dL_dmu[i]] = b.dL_dmu[i].second;

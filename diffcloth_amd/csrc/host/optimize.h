@@ -11,7 +11,7 @@ namespace dchost {
 class OptimizeHelper {
  public:
   struct Offsets {
-    int dL_dfwind = 0, dL_dfext = 0, dL_density = 0, dL_dspline = 0, dL_dx0 = 0;
+    int dL_dfwind = 0, dL_dfext = 0, dL_density = 0, dL_dspline = 0, dL_dx0 = 0, dL_dconstantForceField = 0;
     int dL_k[4] = {0, 0, 0, 0};
     std::vector<int> dL_dmu;
   };
