@@ -132,7 +132,10 @@ __global__ __launch_bounds__(THREADS) void k_cg(const int4 *__restrict__ pk, con
       }
       ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
       part += px * ax + py * ay + pz * az;
-      __builtin_amdgcn_sched_barrier(0);
+#ifndef RPR
+#define RPR 1
+#endif
+      if ((k + 1) % RPR == 0) __builtin_amdgcn_sched_barrier(0);      // rows per scheduling region (experiment: -DRPR=2, 4)
     }
     if (MODE != 0) {
 #pragma unroll
