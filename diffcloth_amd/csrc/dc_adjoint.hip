@@ -549,10 +549,13 @@ static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, i
   if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
   size_t lds = (size_t) S.win_lds_bytes;
   if (DENSE) lds = std::max(lds, sizeof(float) * (size_t) (3 * S.dense_ld + dense_lds_floats(S.dense_ld, THREADS / 64)));
-  static size_t configured = 0;
-  if (lds > configured) {
+  static size_t configured[kMaxDevices] = {};        // the attribute is per device: one entry per device this process has used
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
+  if (lds > done || dev >= kMaxDevices) {
     (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    configured = lds;
+    done = lds;
   }
   hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }

@@ -24,6 +24,8 @@ constexpr int kMetaStride = 1024;  // ints per (slot, rollout): count, nlayers, 
 #define DC_C
 #endif
 
+constexpr int kMaxDevices = 64;       // launchers cache per-device kernel attributes
+
 struct DevPrim {
   int kind, group, rotates, pad;
   float cx, cy, cz, radius;

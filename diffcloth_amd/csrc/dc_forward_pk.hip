@@ -464,10 +464,13 @@ static void launch_pk_inst(const DevSystem &S, const DevWork &W, const FwdArgs &
   if (DENSE) lds += sizeof(float) * (size_t) dense_lds_floats(S.dense_ld, THREADS / 64);
   if (S.win_ok) lds = std::max(lds, (size_t) S.win_lds_bytes);
   if (A.inline_detect) lds = std::max(lds, sizeof(int) * (size_t) kSelfDetectLdsInts);
-  static size_t configured = 0;
-  if (lds > configured) {
+  static size_t configured[kMaxDevices] = {};        // the attribute is per device: one entry per device this process has used
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
+  if (lds > done || dev >= kMaxDevices) {
     (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    configured = lds;
+    done = lds;
   }
   hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }

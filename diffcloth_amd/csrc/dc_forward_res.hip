@@ -273,10 +273,12 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
 template <int THREADS, int VPT>
 static void launch_res(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   const size_t lds = (size_t) 3 * THREADS * VPT * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
+  static bool configured[kMaxDevices] = {};            // the attribute is per device
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDevices || !configured[dev]) {
     (void) hipFuncSetAttribute((const void *) k_pd_step_res<THREADS, VPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    configured = true;
+    if (dev >= 0 && dev < kMaxDevices) configured[dev] = true;
   }
   hipLaunchKernelGGL((k_pd_step_res<THREADS, VPT>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
