@@ -123,12 +123,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development switches for exercising the N > 1 control flow on a box with one GPU: all ranks on one device, gloo
+    # instead of RCCL (RCCL refuses two ranks on one device). Never set by the driver.
+    backend = os.environ.get("DC_BENCH_BACKEND", "nccl")
+    if "DC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["DC_BENCH_DEVICE"])
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the stepper has no CPU path")
 
@@ -174,7 +182,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
