@@ -115,7 +115,9 @@ def main():
     ap.add_argument("--adjoint-rel-tol", dest="adjoint_rel_tol", type=float, default=1e-6)
     ap.add_argument("--selfcollision", type=int, default=1,
                     help="self-collision detection + layered self friction (the reference's default: selfcollisionEnabled = true); 0 = off")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="steps of the CPU baseline sample (0 disables)")
+    ap.add_argument("--cpu-steps", type=int, default=10,
+                    help="steps of the CPU baseline sample: rollout 0 from its state after the warm-up steps (0 disables); the default, "
+                         "the 10 timed steps of that rollout, is ~0.5 s of wall time = 10-20 s of CPU work on 32 threads")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0: min(host cores, 32), the fastest setting measured on the MI355X host)")
     args = ap.parse_args()
