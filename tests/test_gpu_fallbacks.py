@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CORE = "test_forward_step_matches_oracle_with_contact or test_backward_step_matches_oracle or test_forward_and_backward_with_self_contacts " \
        "or test_parameter_gradients_match_oracle or test_free_running_tshirt or test_fused_rollout_with_self_contacts " \
-       "or test_two_contexts_agree"
+       "or test_two_contexts_agree or test_random_scene_step_matches_oracle"
 
 
 @pytest.mark.parametrize("env", [
@@ -27,7 +27,7 @@ def test_core_parity_on_fallback_kernels(env):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_selfcontact.py"), os.path.join(ROOT, "tests", "test_gpu_edge_cases.py"), "-q", "-x", "-k", CORE, "-p", "no:cacheprovider"],
+                        os.path.join(ROOT, "tests", "test_gpu_selfcontact.py"), os.path.join(ROOT, "tests", "test_gpu_edge_cases.py"), os.path.join(ROOT, "tests", "test_gpu_random_scenes.py"), "-q", "-x", "-k", CORE, "-p", "no:cacheprovider"],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0, f"{env}:\n{tail}\n{r.stderr[-2000:]}"
