@@ -20,7 +20,7 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(30))
 def test_random_scene_step_matches_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     nx, ny = int(rng.integers(5, 38)), int(rng.integers(5, 38))
@@ -71,7 +71,13 @@ def test_random_scene_step_matches_oracle(seed):
     st = e.step_forward(0, fixed_pts=XF)
     ref = o.step(x, v, None if xf is None else f32(xf))
     x1, v1 = e.get_state(1)
-    assert ref["converged"] and np.all(np.isin(st["converged"], (1, 2)))
+    if not ref["converged"]:
+        # a draw too stiff for the iteration cap ((-log10 tol) * 150, Simulation.cpp:1182): both sides return their best iterate
+        # (that path has its own test, test_gpu_parity.py); here only that the device agrees it did not converge
+        assert st["converged"][0] != 1 and st["pd_iters"][0] == ref["iters"]
+        assert np.abs(x1[0] - ref["x"]).max() <= 1e-3
+        return
+    assert np.all(np.isin(st["converged"], (1, 2)))
     assert st["prim_contacts"][0] == ref["nprim"] and st["self_contacts"][0] == ref["nself"]
     dx = np.abs(x1[0] - ref["x"]).max()
     gx = f32(rng.standard_normal(V.size)); gv = f32(0.01 * rng.standard_normal(V.size))
