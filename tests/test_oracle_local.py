@@ -155,3 +155,73 @@ def test_friction_branches_and_jacobian(case):
     np.testing.assert_allclose(J, Jfd, atol=1e-8)
     dfd = (orc.friction(n, f, mu + eps)[0] - orc.friction(n, f, mu - eps)[0]) / (2 * eps)
     np.testing.assert_allclose(dmu, dfd, atol=1e-8)
+
+
+def _plane_contact_np(q, ul, ur):
+    """Plane::isInContact (Primitive.cpp:66-130) re-stated with NumPy for a point q relative to the plane's centre."""
+    eps, edge_tol = 0.4, 0.0005
+    lr, ll = -ul, -ur
+    if np.linalg.norm(q) > max(np.linalg.norm(ul), np.linalg.norm(ur)) + eps:
+        return None
+    n = np.cross(ur, ul); n /= np.linalg.norm(n)
+    dist = n @ q
+    if abs(dist) > eps:
+        return None
+    pp = q - n * (n @ q)
+
+    def inside(a, b, c):
+        AB, AC, AP = b - a, c - a, pp - a
+        nn = np.cross(AB, AC); n2 = nn @ nn
+        al, be = np.cross(AB, AP) @ nn / n2, np.cross(AP, AC) @ nn / n2
+        ga = 1 - al - be
+        return al >= 0 and be >= 0 and ga >= 0 and ga <= 1 and al <= 1 and be <= 1
+    if inside(ul, ur, ll) or inside(ll, ur, lr):
+        return n
+    for a, b in ((ul, ur), (ur, lr), (ll, lr), (ul, ll)):
+        AB = b - a
+        P = a + AB * ((q - a) @ AB / (AB @ AB))
+        t = np.linalg.norm(P - a) / np.linalg.norm(AB)
+        if np.linalg.norm(P - b) > np.linalg.norm(AB):
+            t = -t
+        if np.linalg.norm(q - P) < edge_tol and -edge_tol < t < 1 + edge_tol:
+            w = q - a if t < 0 else (q - b if t > 1 else q - P)
+            return w / np.linalg.norm(w)
+    return None
+
+
+@pytest.mark.parametrize("kind", ["plane", "bowl"])
+def test_plane_and_bowl_contact_sets_match_an_independent_restatement(kind):
+    """The oracle's Plane / Bowl isInContact (orc_sim.cpp) against a NumPy restatement of Primitive.cpp:66-130 / :362-381 on a
+    cloud of vertices around the obstacle (zero velocities: the three time samples of isInContactWithObstacle coincide)."""
+    V, F = meshes.grid_cloth(17, 15, 3.0, 2.6, "DOWN")
+    rng = np.random.default_rng(3)
+    c = V.mean(axis=0) + np.array([0.1, -0.2, 0.05])
+    if kind == "plane":
+        ul, ur = np.array([-1.1, 0.25, -0.9]), np.array([1.1, 0.25, -0.9])
+        X = V + np.array([0, 1, 0]) * rng.uniform(-0.9, 0.5, (len(V), 1)) + 0.02 * rng.standard_normal(V.shape)
+        X[:6] = c + np.array([ur + (-ul - ur) * t for t in np.linspace(-0.0003, 1.0003, 6)]) + 1e-4 * rng.standard_normal((6, 3))   # on an edge
+    else:
+        R = 1.3
+        dirs = rng.standard_normal(V.shape); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        X = c + dirs * (R + rng.choice([-0.02, -0.004, 0.0, 0.004, 0.02], (len(V), 1)))
+    o = orc.Oracle(V, F, h=1 / 120, density=0.3, k_stretch=50.0, k_bend=0.01, fwd_tol=1e-3, bwd_tol=1e-3, selfcollision=False, pd_iter_cap=2)
+    if kind == "plane":
+        o.add_plane(c, ul, ur, 0.3)
+    else:
+        o.add_bowl(c, R, 0.3)
+    o.build()
+    out = o.step(X.reshape(-1), np.zeros(X.size))
+    con = o.prim_contacts(out["id"])
+    got = dict(zip(con["particle"].tolist(), con["normal"]))
+    want = {}
+    for i, p in enumerate(X):
+        if kind == "plane":
+            n = _plane_contact_np(p - c, ul, ur)
+        else:
+            d = np.linalg.norm(p - c)
+            n = (c - p) / d if (d - R <= 0.005 and p[1] <= c[1] and d > R - 0.005) else None
+        if n is not None:
+            want[i] = n
+    assert set(got) == set(want) and 10 < len(want) < len(X)
+    for i in want:
+        np.testing.assert_allclose(got[i], want[i], atol=1e-12)

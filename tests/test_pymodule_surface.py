@@ -87,3 +87,16 @@ def test_spline_trajectory_math():
     s = d.Spline(p0, p1, 8.0, 0)
     fd = (s.evalute(0.3 + 1e-6) - s.evalute(0.3 - 1e-6)) / 2e-6
     np.testing.assert_allclose(s.evalute(0.3, 1), fd, atol=1e-6)
+
+
+def test_batched_autograd_module_imports_without_a_device():
+    """diffcloth_amd.functional is importable on a CPU-only host; it refuses to wrap an engine without a batch."""
+    sys.path.insert(0, ROOT)
+    from diffcloth_amd import functional
+
+    class NoBatch:
+        B = 0
+        tape = 0
+    with pytest.raises(ValueError):
+        functional.BatchedSim(NoBatch(), 10)
+    assert callable(functional.sim_step)
