@@ -36,7 +36,7 @@ class dc_params(C.Structure):
 
 class dc_step_stats(C.Structure):
     _fields_ = [("converged", C.c_int), ("pd_iters", C.c_int), ("cg_iters", C.c_int), ("prim_contacts", C.c_int),
-                ("self_contacts", C.c_int), ("last_xdiff", C.c_float)]
+                ("self_contacts", C.c_int), ("last_xdiff", C.c_float), ("self_overflow", C.c_int)]
 
 
 class dc_bwd_stats(C.Structure):
@@ -50,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force", "dc_set_vertex_forces", "dc_get_force_gradient",
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
-    "dc_timer_stop", "dc_kernel_times",
+    "dc_timer_stop", "dc_kernel_times", "dc_get_cluster",
 ]
 
 _lib = None
@@ -225,7 +225,7 @@ class Engine:
         st = (dc_step_stats * self.B)() if want_stats else None
         self._chk(self.lib.dc_step_forward(self.h, C.c_int(slot), _d(fp), st))
         if want_stats:
-            return _stats_to_dict(st, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff"])
+            return _stats_to_dict(st, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff", "self_overflow"])
         return None
 
     def get_record(self, slot):
@@ -290,11 +290,17 @@ class Engine:
     def get_stats(self, slot):
         f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()
         self._chk(self.lib.dc_get_stats(self.h, C.c_int(slot), f, b))
-        return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff"]),
+        return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff", "self_overflow"]),
                 _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff"]))
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))
+
+    def cluster(self):
+        """workgroups per rollout the engine chose for this batch (dc_get_cluster); 1 = one workgroup per rollout"""
+        k = C.c_int(); nb = C.c_int()
+        self._chk(self.lib.dc_get_cluster(self.h, C.byref(k), C.byref(nb)))
+        return k.value
 
     def timer_start(self):
         self._chk(self.lib.dc_timer_start(self.h))

@@ -7,8 +7,11 @@
 namespace dc {
 
 constexpr int kMaxPrims = 8;
-constexpr int kMaxLayers = 1020;   // self-contact layers per step (contactSorting: a chain of L contacts takes L layers)
-constexpr int kMetaStride = 1024;  // ints per (slot, rollout): count, nlayers, layer offsets[nlayers + 1]
+constexpr int kMaxLayers = 4088;   // self-contact layers per step (contactSorting: a chain of L contacts takes L layers)
+// ints per (slot, rollout): count, nlayers, layer offsets[nlayers + 1] ... and at the end [kMetaStride - 3] = pairs found
+// (before clamping to the list capacity), [- 2] = overflow flags (1: more pairs than max_self_contacts, 2: more layers than
+// kMaxLayers), [- 1] = number of distinct vertices in the contacts
+constexpr int kMetaStride = 4096;
 
 // Table pointers of DevSystem carry the GLOBAL address space in device code: the struct itself lives in global memory
 // and is read through a pointer, so the compiler cannot infer the address space of the pointers stored in it and would
@@ -111,7 +114,7 @@ struct DevWork {
   float *sd_sx;                 // [B][3][N] positions in cell-sorted order
   int2 *sd_rawpair;             // [B][cap]
   float4 *sd_rawn;              // [B][cap]
-  int *sd_tmp;                  // [B][16 * cap] serial layering structures
+  int *sd_tmp;                  // [B][self_tmp_ints(cap)] layering structures (dc_selflib.h)
 };
 
 // Self contacts of one record, per rollout b: pair[b*cap + k] = (particleId1 < particleId2), nrm = contact normal,

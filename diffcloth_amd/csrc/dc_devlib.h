@@ -256,13 +256,23 @@ __device__ __forceinline__ int block_pcg(const DevSystem &S, float *cg_r, float 
 // Self contacts: the layers of Simulation::contactSorting applied in sequence (Gauss-Seidel over layers, contacts
 // of one layer are vertex-disjoint and run in parallel).
 // ---------------------------------------------------------------------------------------------------
+// Accessors of a rollout's planar [3][N] vector: PlainVec = ordinary global loads / stores; the split kernels pass BufVec
+// (dc_cluster.h: write-through / L1-bypassing accesses) for vectors that other workgroups read or write.
+struct PlainVec {
+  float *p;
+  __device__ __forceinline__ float ld(int idx) const { return p[idx]; }
+  __device__ __forceinline__ void st(int idx, float v) const { p[idx] = v; }
+};
+template <class V> __device__ __forceinline__ f3 ld3v(const V &a, int i, int n) { return mk(a.ld(i), a.ld(n + i), a.ld(2 * n + i)); }
+template <class V> __device__ __forceinline__ void st3v(const V &a, int i, int n, f3 v) { a.st(i, v.x); a.st(n + i, v.y); a.st(2 * n + i, v.z); }
+
 constexpr float kClothMu = 0.1f;    // clothFrictionalCoeff, hard-coded in the reference (Simulation.cpp:666, :729)
 
 // calculateDryFrictionVector, self part (Simulation.cpp:655-678): r += k * friction(d), d = (f+r)_A/m_A - (f+r)_B/m_B.
 // f, r are the rollout's planar [3][N] arrays in global memory; stores d per contact. Call with all threads; the
 // caller must have synchronised after writing f / r, this function ends with a barrier.
-template <int THREADS>
-__device__ __forceinline__ void self_friction_layers(const DevSystem &S, const SelfRec &R, int b, const float *f, float *r) {
+template <int THREADS, class FV, class RV>
+__device__ __forceinline__ void self_friction_layers_v(const DevSystem &S, const SelfRec &R, int b, const FV &f, const RV &r) {
   const int cap = S.self_cap, N = S.N;
   const int *meta = R.meta + (size_t) b * kMetaStride;
   const int nl = meta[1];
@@ -276,22 +286,26 @@ __device__ __forceinline__ void self_friction_layers(const DevSystem &S, const S
       const float4 n4 = nrm[k];
       const f3 n = mk(n4.x, n4.y, n4.z);
       const float mA = S.mass[ab.x], mB = S.mass[ab.y];
-      f3 rA = ld3(r, ab.x, N), rB = ld3(r, ab.y, N);
-      f3 d = (ld3(f, ab.x, N) + rA) * (1.0f / mA) - (ld3(f, ab.y, N) + rB) * (1.0f / mB);
+      f3 rA = ld3v(r, ab.x, N), rB = ld3v(r, ab.y, N);
+      f3 d = (ld3v(f, ab.x, N) + rA) * (1.0f / mA) - (ld3v(f, ab.y, N) + rB) * (1.0f / mB);
       dvec[k] = make_float4(d.x, d.y, d.z, 0.f);
       f3 ri = dry_friction(n, d, kClothMu) * ((mA * mB) / (mA + mB));
-      st3(r, ab.x, N, rA + ri);
-      st3(r, ab.y, N, rB - ri);
+      st3v(r, ab.x, N, rA + ri);
+      st3v(r, ab.y, N, rB - ri);
     }
     __syncthreads();
   }
+}
+template <int THREADS>
+__device__ __forceinline__ void self_friction_layers(const DevSystem &S, const SelfRec &R, int b, const float *f, float *r) {
+  self_friction_layers_v<THREADS>(S, R, b, PlainVec{(float *) f}, PlainVec{r});
 }
 
 // z <- (I + J_0)^T ... (I + J_L)^T z for the self layers (calculatedr_df, Simulation.cpp:713-760, transposed):
 // per contact (A,B): g = k D^T (z_A - z_B), z_A += g / m_A, z_B -= g / m_B, D = dri_dfi(n, d, 0.1).
 // z is the rollout's planar [3][N] array in global memory. Ends with a barrier.
-template <int THREADS>
-__device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec &R, int b, float *z) {
+template <int THREADS, class ZV>
+__device__ __forceinline__ void self_JT_layers_v(const DevSystem &S, const SelfRec &R, int b, const ZV &z) {
   const int cap = S.self_cap, N = S.N;
   const int *meta = R.meta + (size_t) b * kMetaStride;
   const int nl = meta[1];
@@ -304,13 +318,17 @@ __device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec
       const int2 ab = pair[k];
       const float4 n4 = nrm[k], d4 = dvec[k];
       const float mA = S.mass[ab.x], mB = S.mass[ab.y];
-      f3 zA = ld3(z, ab.x, N), zB = ld3(z, ab.y, N);
+      f3 zA = ld3v(z, ab.x, N), zB = ld3v(z, ab.y, N);
       f3 g = dri_dfi_T(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * ((mA * mB) / (mA + mB));
-      st3(z, ab.x, N, zA + g * (1.0f / mA));
-      st3(z, ab.y, N, zB - g * (1.0f / mB));
+      st3v(z, ab.x, N, zA + g * (1.0f / mA));
+      st3v(z, ab.y, N, zB - g * (1.0f / mB));
     }
     __syncthreads();
   }
+}
+template <int THREADS>
+__device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec &R, int b, float *z) {
+  self_JT_layers_v<THREADS>(S, R, b, PlainVec{z});
 }
 
 // ---- the same two passes inside LDS ----------------------------------------------------------------------------
@@ -322,9 +340,9 @@ __device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec
 // when the working set does not fit, and the caller takes the global-memory version.
 __device__ __forceinline__ int self_lds_need(int M, int C, int nl) { return 7 * M + 8 * C + nl + 2; }
 
-template <int THREADS>
-__device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, const SelfRec &R, int b, const float *f, float *r,
-                                                         float *lds, int lds_floats) {
+template <int THREADS, class FV, class RV>
+__device__ __forceinline__ bool self_friction_layers_lds_v(const DevSystem &S, const SelfRec &R, int b, const FV &f, const RV &r,
+                                                           float *lds, int lds_floats) {
   const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
   const int *meta = R.meta + (size_t) b * kMetaStride;
   const int C = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
@@ -340,8 +358,8 @@ __device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, con
   (void) pair;
   for (int s = tid; s < M; s += THREADS) {
     const int v = verts[s];
-    lf[s] = f[v]; lf[M + s] = f[N + v]; lf[2 * M + s] = f[2 * N + v];
-    lr[s] = r[v]; lr[M + s] = r[N + v]; lr[2 * M + s] = r[2 * N + v];
+    lf[s] = f.ld(v); lf[M + s] = f.ld(N + v); lf[2 * M + s] = f.ld(2 * N + v);
+    lr[s] = r.ld(v); lr[M + s] = r.ld(N + v); lr[2 * M + s] = r.ld(2 * N + v);
     lim[s] = 1.0f / S.mass[v];
   }
   for (int k = tid; k < C; k += THREADS) ln[k] = nrm[k];
@@ -367,14 +385,19 @@ __device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, con
     }
   }
   __syncthreads();
-  for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; r[v] = lr[s]; r[N + v] = lr[M + s]; r[2 * N + v] = lr[2 * M + s]; }
+  for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; r.st(v, lr[s]); r.st(N + v, lr[M + s]); r.st(2 * N + v, lr[2 * M + s]); }
   for (int k = tid; k < C; k += THREADS) dvec[k] = ld[k];
   __syncthreads();
   return true;
 }
-
 template <int THREADS>
-__device__ __forceinline__ bool self_JT_layers_lds(const DevSystem &S, const SelfRec &R, int b, float *z, float *lds, int lds_floats) {
+__device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, const SelfRec &R, int b, const float *f, float *r,
+                                                         float *lds, int lds_floats) {
+  return self_friction_layers_lds_v<THREADS>(S, R, b, PlainVec{(float *) f}, PlainVec{r}, lds, lds_floats);
+}
+
+template <int THREADS, class ZV>
+__device__ __forceinline__ bool self_JT_layers_lds_v(const DevSystem &S, const SelfRec &R, int b, const ZV &z, float *lds, int lds_floats) {
   const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
   const int *meta = R.meta + (size_t) b * kMetaStride;
   const int C = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
@@ -388,7 +411,7 @@ __device__ __forceinline__ bool self_JT_layers_lds(const DevSystem &S, const Sel
   int *loff = (int *) (ld + C);
   for (int s = tid; s < M; s += THREADS) {
     const int v = verts[s];
-    lz[s] = z[v]; lz[M + s] = z[N + v]; lz[2 * M + s] = z[2 * N + v];
+    lz[s] = z.ld(v); lz[M + s] = z.ld(N + v); lz[2 * M + s] = z.ld(2 * N + v);
     lim[s] = 1.0f / S.mass[v];
   }
   for (int k = tid; k < C; k += THREADS) { ln[k] = nrm[k]; ld[k] = dvec[k]; }
@@ -411,9 +434,13 @@ __device__ __forceinline__ bool self_JT_layers_lds(const DevSystem &S, const Sel
     }
   }
   __syncthreads();
-  for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; z[v] = lz[s]; z[N + v] = lz[M + s]; z[2 * N + v] = lz[2 * M + s]; }
+  for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; z.st(v, lz[s]); z.st(N + v, lz[M + s]); z.st(2 * N + v, lz[2 * M + s]); }
   __syncthreads();
   return true;
+}
+template <int THREADS>
+__device__ __forceinline__ bool self_JT_layers_lds(const DevSystem &S, const SelfRec &R, int b, float *z, float *lds, int lds_floats) {
+  return self_JT_layers_lds_v<THREADS>(S, R, b, PlainVec{z}, lds, lds_floats);
 }
 
 }  // namespace dc

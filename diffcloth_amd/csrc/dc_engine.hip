@@ -11,8 +11,24 @@
 #include "dc_windows.h"
 #include "dc_packets.h"
 #include "dc_dense.h"
+#include "dc_selftmp.h"
+#include "dc_cluster.h"
 
 using namespace dc;
+
+namespace dc {
+hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st);
+hipError_t launch_adjoint_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const BwdArgs &A, int b0, int nb, hipStream_t st);
+}
+
+// Tables of the split kernels (dc_cluster.h) for one K, built when the batch size is known (dc_alloc_batch).
+struct ClusterSet {
+  bool ok = false;
+  int K = 1, nb = 0;              // workgroups per rollout; rollouts per launch (K nb <= CUs)
+  DevCluster D;
+  std::vector<void *> allocs;
+  size_t xch_bytes = 0;
+};
 
 struct dc_ctx {
   int device = 0;
@@ -58,6 +74,9 @@ struct dc_ctx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   float fwd_ms = 0, bwd_ms = 0;
   int fwd_launches = 0, bwd_launches = 0;
+  ClusterSet cl;
+  int cus = 0;                      // compute units of the device
+  int bandwidth = 0;                // of the scalar system matrix in device numbering
 };
 
 namespace {
@@ -104,15 +123,16 @@ int pd_cap(const dc_ctx *c) {
   return (int) ((-std::log10(c->params.forward_tol)) * 150);   // Simulation.cpp:1182
 }
 
-int h2d_planar(dc_ctx *c, const double *src, float *dst, int n_per_rollout, int which_stage) {
+// per_vertex: the array is indexed by vertex (the device renumbering applies); false: by attachment / other index
+int h2d_planar(dc_ctx *c, const double *src, float *dst, int n_per_rollout, int which_stage, bool per_vertex) {
   size_t elems = (size_t) c->B * 3 * n_per_rollout;
   HIPCHK(c, hipMemcpyAsync(c->stage[which_stage], src, elems * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  launch_f64i_to_f32p(c->stage[which_stage], dst, c->B, n_per_rollout, n_per_rollout == c->host.N ? c->d_user_of : nullptr, c->stream);
+  launch_f64i_to_f32p(c->stage[which_stage], dst, c->B, n_per_rollout, per_vertex ? c->d_user_of : nullptr, c->stream);
   return DC_OK;
 }
-int d2h_planar(dc_ctx *c, const float *src, double *dst, int n_per_rollout, int which_stage) {
+int d2h_planar(dc_ctx *c, const float *src, double *dst, int n_per_rollout, int which_stage, bool per_vertex) {
   size_t elems = (size_t) c->B * 3 * n_per_rollout;
-  launch_f32p_to_f64i(src, c->stage[which_stage], c->B, n_per_rollout, n_per_rollout == c->host.N ? c->d_user_of : nullptr, c->stream);
+  launch_f32p_to_f64i(src, c->stage[which_stage], c->B, n_per_rollout, per_vertex ? c->d_user_of : nullptr, c->stream);
   HIPCHK(c, hipMemcpyAsync(dst, c->stage[which_stage], elems * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   return DC_OK;
 }
@@ -121,6 +141,17 @@ int check_batch(dc_ctx *c, int slot_lo, int slot_hi) {
   if (!c->built) return fail(c, DC_ERR_STATE, "dc_build has not been called");
   if (c->B <= 0) return fail(c, DC_ERR_STATE, "dc_alloc_batch has not been called");
   if (slot_lo < 0 || slot_hi > c->tape) return fail(c, DC_ERR_INVALID, "tape slot out of range");
+  return DC_OK;
+}
+
+// The reference's self-contact list has no limit (Simulation.cpp:281-352, 422-624); ours has, and says so: a step whose list
+// was cut is not the reference's step.
+int check_self_overflow(dc_ctx *c, const dc_step_stats *st, int slot) {
+  for (int b = 0; b < c->B; b++)
+    if (st[b].self_overflow)
+      return fail(c, DC_ERR_CAPACITY, "self-contact list overflow in the step that produced slot " + std::to_string(slot) + ", rollout " +
+                  std::to_string(b) + ((st[b].self_overflow & 1) ? ": more pairs than max_self_contacts = " + std::to_string(c->self_cap) : (st[b].self_overflow & 2) ? std::string(": more than 4088 contact layers") : std::string(": inconsistent contact tables (internal error)")) +
+                  " (raise dc_params::max_self_contacts and repeat the step)");
   return DC_OK;
 }
 
@@ -178,6 +209,158 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   return A;
 }
 
+
+// ---- split execution (dc_cluster.h): choice of K, tables, launches ------------------------------------------------------------
+static int round64(int v) { return (v + 63) / 64 * 64; }
+
+void free_cluster(dc_ctx *c) {
+  for (void *p : c->cl.allocs) (void) hipFree(p);
+  c->cl = ClusterSet();
+}
+
+template <typename T, typename U>
+int upload_cl(dc_ctx *c, const T **out, const std::vector<U> &src) {
+  std::vector<T> tmp(src.begin(), src.end());
+  T *p = nullptr;
+  int rc = dev_alloc(c, c->cl.allocs, &p, tmp.size());
+  if (rc) return rc;
+  if (!tmp.empty()) HIPCHK(c, hipMemcpy(p, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return DC_OK;
+}
+
+// Tables for K parts per rollout; returns DC_OK with c->cl.ok = false when K does not fit this mesh (the caller tries K - 1).
+int build_cluster(dc_ctx *c, int K) {
+  free_cluster(c);
+  const HostSystem &H = c->host;
+  const int N = H.N;
+  if (K < 2 || c->bandwidth <= 0 || c->bandwidth > 511) return DC_OK;
+  const int HB = std::max(64, round64(c->bandwidth));
+  static const int allowed[] = {1, 2, 3, 4, 6, 8, 12};
+  const int lds_cap = (160 * 1024 - 256) / 4 - kXchLdsFloats;      // floats
+  HostWindows HW;
+  int R = 0, wpp = 0, vpt = 0;
+  for (int w = 1; w <= 8 && R == 0; w++) {
+    const int own_w = round64((N + K * w - 1) / (K * w));
+    const int Rc = own_w * w;
+    if ((long long) (K - 1) * Rc >= N) break;           // a part would be empty
+    if (Rc < HB) break;                                  // halo rows must come from the direct neighbours only
+    int v = 0;
+    for (int a : allowed) if (a * 512 >= Rc) { v = a; break; }
+    if (v == 0) continue;                                // more rows per part than the kernel holds in registers: more windows do not help
+    if (!HW.build_own(H, own_w)) continue;
+    const int win_floats = (int) (HW.lds_bytes / 4);
+    const int fwd = std::max(std::max(3 * (Rc + 2 * HB), win_floats), kSelfDetectLdsInts);
+    const int bwd = (win_floats + 3) / 4 * 4 + 6 * HB;
+    if (fwd + 4 > lds_cap || bwd + 4 > lds_cap) continue;
+    // the element reach of every window must stay inside the boundary rows its part receives
+    bool reach_ok = true;
+    for (int q = 0; q < HW.nwin; q++) {
+      const int part = q / w, p0 = part * Rc;
+      const int lo = HW.win[8 * q + 2], vs = HW.win[8 * q + 3];
+      if (lo < p0 - HB || lo + vs > p0 + Rc + HB) reach_ok = false;
+    }
+    if (!reach_ok) continue;
+    R = Rc; wpp = w; vpt = v;
+  }
+  if (R == 0) return DC_OK;
+  HostPackets HP;
+  if (!HP.build_rows(H, K * R)) return DC_OK;
+  ClusterSet &cl = c->cl;
+  DevCluster &D = cl.D;
+  std::memset(&D, 0, sizeof(D));
+  D.K = K; D.R = R; D.HB = HB; D.wpp = wpp; D.xch_stride = 1 + 2 * HB; D.pk_vpt = vpt;
+  int rc;
+  const int *ip; const float *fp;
+  if ((rc = upload_cl<int>(c, &ip, HW.win))) return rc;
+  D.win = (const int4 *) ip;
+  if ((rc = upload_cl<int>(c, &ip, HW.tri_rec))) return rc;
+  D.wtri_rec = (const int4 *) ip;
+  if ((rc = upload_cl<float>(c, &fp, HW.tri_D))) return rc;
+  D.wtri_D = (const float4 *) fp;
+  if ((rc = upload_cl<int>(c, &ip, HW.bend_rec))) return rc;
+  D.wbend_rec = (const int4 *) ip;
+  if ((rc = upload_cl<float>(c, &fp, HW.bend_w))) return rc;
+  D.wbend_w = (const float4 *) fp;
+  if ((rc = upload_cl<int>(c, &ip, HW.inc))) return rc;
+  D.winc = (const int4 *) ip;
+  if ((rc = upload_cl<int>(c, &D.winc_ptr, HW.inc_ptr))) return rc;
+  if ((rc = upload_cl<int>(c, &D.winc_n, HW.inc_n))) return rc;
+  D.nwin = HW.nwin; D.win_vcap = HW.vcap; D.win_nrcap = HW.nrcap; D.win_lds_bytes = (int) HW.lds_bytes;
+  if ((rc = upload_cl<int>(c, &ip, HP.pk))) return rc;
+  D.pk = (const int4 *) ip;
+  if ((rc = upload_cl<int>(c, &D.pk_ptr, HP.pk_ptr))) return rc;
+  if ((rc = upload_cl<int>(c, &D.pk_n, HP.pk_n))) return rc;
+  if ((rc = upload_cl<float>(c, &D.sq_dinv, HP.sq_dinv))) return rc;
+  cl.K = K;
+  cl.nb = std::max(1, std::min(c->B, c->cus / K));
+  D.nb = cl.nb;
+  cl.xch_bytes = (size_t) cl.nb * K * 2 * D.xch_stride * sizeof(v4i);
+  if ((rc = dev_alloc(c, cl.allocs, &D.xch, cl.xch_bytes / sizeof(v4i)))) return rc;
+  if ((rc = dev_alloc(c, cl.allocs, &D.err, 4))) return rc;
+  DevCluster *dD = nullptr;
+  if ((rc = dev_alloc(c, cl.allocs, &dD, 1))) return rc;
+  D.self_dev = dD;
+  HIPCHK(c, hipMemcpy(dD, &D, sizeof(DevCluster), hipMemcpyHostToDevice));
+  cl.ok = true;
+  return DC_OK;
+}
+
+// K for this batch: enough parts to give every CU a workgroup (B rollouts x K <= CUs, K <= 8), at least as many as a mesh too
+// large for the one-workgroup kernel needs; DC_CLUSTER=k forces k (development switch; 0 / 1 = off).
+int choose_cluster(dc_ctx *c) {
+  free_cluster(c);
+  if (c->host_only || c->B <= 0) return DC_OK;
+  const char *env = getenv("DC_CLUSTER");
+  const int forced = env ? atoi(env) : -1;
+  if (forced == 0 || forced == 1) return DC_OK;
+  if (c->S.dense_inv) { if (forced < 2) return DC_OK; }     // small meshes: the explicit-inverse kernels are the faster ones
+  int K = 1;
+  while (K * 2 * c->B <= c->cus && K * 2 <= 8) K *= 2;
+  if (!c->S.pk_ok || !c->S.win_ok) K = std::max(K, std::min(8, (c->host.N + 6143) / 6144));
+  if (forced >= 2) K = std::min(forced, 8);
+  for (; K >= 2; K--) {
+    int rc = build_cluster(c, K);
+    if (rc) return rc;
+    if (c->cl.ok) break;
+  }
+  return DC_OK;
+}
+
+int cluster_begin(dc_ctx *c) {       // start of an API call that launches split kernels: clear the sticky error word
+  if (c->cl.ok) HIPCHK(c, hipMemsetAsync(c->cl.D.err, 0, 16, c->stream));
+  return DC_OK;
+}
+int cluster_check(dc_ctx *c) {       // after a synchronisation
+  if (!c->cl.ok) return DC_OK;
+  unsigned e[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpy(e, c->cl.D.err, sizeof(e), hipMemcpyDeviceToHost));
+  if (e[0]) return fail(c, DC_ERR_HIP, "split kernels: an inter-workgroup exchange timed out (waiting for sequence " + std::to_string(e[1]) + ", saw tag " +
+                        std::to_string(e[2]) + ", site " + std::to_string(e[3] & 255u) + ", part " + std::to_string((e[3] >> 8) & 15u) + ", granule " +
+                        std::to_string(e[3] >> 12) + "; set DC_CLUSTER=1 to run one workgroup per rollout)");
+  return DC_OK;
+}
+
+bool use_cluster_fwd(const dc_ctx *c) { return c->cl.ok; }
+bool use_cluster_bwd(const dc_ctx *c) { return c->cl.ok && c->params.adjoint_mode == 1; }
+
+int enqueue_pd_step(dc_ctx *c, const FwdArgs &A) {
+  if (!use_cluster_fwd(c)) { launch_pd_step(c->S, c->W, A, c->B, c->stream); HIPCHK(c, hipGetLastError()); return DC_OK; }
+  for (int b0 = 0; b0 < c->B; b0 += c->cl.nb) {
+    HIPCHK(c, hipMemsetAsync(c->cl.D.xch, 0, c->cl.xch_bytes, c->stream));
+    HIPCHK(c, launch_pd_step_cluster(c->S, c->cl.D, c->W, A, b0, std::min(c->cl.nb, c->B - b0), c->stream));
+  }
+  return DC_OK;
+}
+int enqueue_adjoint_step(dc_ctx *c, const BwdArgs &A) {
+  if (!use_cluster_bwd(c)) { launch_adjoint_step(c->S, c->W, A, c->B, c->stream); HIPCHK(c, hipGetLastError()); return DC_OK; }
+  for (int b0 = 0; b0 < c->B; b0 += c->cl.nb) {
+    HIPCHK(c, hipMemsetAsync(c->cl.D.xch, 0, c->cl.xch_bytes, c->stream));
+    HIPCHK(c, launch_adjoint_step_cluster(c->S, c->cl.D, c->W, A, b0, std::min(c->cl.nb, c->B - b0), c->stream));
+  }
+  return DC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,7 +376,7 @@ void dc_default_params(dc_params *p) {
   p->gradient_clipping = 1; p->gradient_clipping_threshold = 16.0;                                      // Simulation.h:330-331
   p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 0;
   p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6;
-  p->max_self_contacts = 2048;
+  p->max_self_contacts = 0;      /* sized from the mesh in dc_build */
 }
 
 int dc_create(int device_id, dc_ctx **out) {
@@ -217,8 +400,9 @@ int dc_create(int device_id, dc_ctx **out) {
   std::memset(&c->S, 0, sizeof(c->S));
   std::memset(&c->W, 0, sizeof(c->W));
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return DC_ERR_HIP; }
-  (void) hipEventCreate(&c->ev_a); (void) hipEventCreate(&c->ev_b);
-  (void) hipEventCreate(&c->ev_t0); (void) hipEventCreate(&c->ev_t1);
+  if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || c->cus <= 0) c->cus = 256;
+  if (hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess || hipEventCreate(&c->ev_t0) != hipSuccess ||
+      hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return DC_ERR_HIP; }
   *out = c;
   return DC_OK;
 }
@@ -228,6 +412,7 @@ int dc_destroy(dc_ctx *c) {
   if (c->host_only) { delete c; return DC_OK; }
   (void) hipSetDevice(c->device);
   (void) hipStreamSynchronize(c->stream);
+  free_cluster(c);
   free_pool(c->table_allocs);
   free_pool(c->batch_allocs);
   (void) hipEventDestroy(c->ev_a); (void) hipEventDestroy(c->ev_b);
@@ -283,6 +468,7 @@ int dc_set_params(dc_ctx *c, const dc_params *p) {
 
 int dc_set_primitives(dc_ctx *c, int count, const dc_primitive *prims) {
   if (!c || count < 0 || count > kMaxPrims) return fail(c, DC_ERR_INVALID, "dc_set_primitives: at most 8 flattened primitives");
+  if (count > 0 && !prims) return fail(c, DC_ERR_INVALID, "dc_set_primitives: null primitive array");
   c->prims.assign(prims, prims + count);
   // compact the caller's group ids to 0..ngroups-1 in order of first appearance
   std::vector<int> seen;
@@ -309,9 +495,13 @@ int dc_build(dc_ctx *c) {
     if (!c->dev_of.empty()) a = c->dev_of[a];
   }
   if (!H.build_numerics(p.time_step, p.density, p.k_stretch, p.k_bend, p.k_att)) return fail(c, DC_ERR_TOPOLOGY, H.error);
+  c->bandwidth = 0;
+  for (int r = 0; r < H.N; r++)
+    for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++) c->bandwidth = std::max(c->bandwidth, std::abs(H.P_col[k] - r));
   if (c->host_only) { c->built = true; return DC_OK; }
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_cluster(c);
   free_pool(c->table_allocs);
   DevSystem &S = c->S;
   std::memset(&S, 0, sizeof(S));
@@ -364,7 +554,9 @@ int dc_build(dc_ctx *c) {
     double mr = H.radii.empty() ? 0.0 : H.radii[0];
     for (double r : H.radii) mr = std::max(mr, r);
     S.max_radii = (float) mr;
-    S.self_cap = p.max_self_contacts > 0 ? p.max_self_contacts : 2048;
+    // capacity of the per-rollout contact list: the caller's, or sized from the mesh (a fold brings every vertex of the upper
+    // layer into contact with one of the lower: ~N/2 pairs). Slots of the working set are 16-bit: at most 16000 pairs.
+    S.self_cap = std::min(p.max_self_contacts > 0 ? p.max_self_contacts : std::max(2048, N), 16000);
     { const char *envs = getenv("DC_SELF_LDS"); S.self_lds = !(envs && envs[0] == '0'); }   // development switch: 0 = global-memory layer passes
   }
   {  // wave-sliced ELL copy of P for the LDS-resident PCG
@@ -576,7 +768,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
     if ((rc = dev_alloc(c, pool, &c->W.sd_sx, se))) return rc;
     if ((rc = dev_alloc(c, pool, &c->W.sd_rawpair, (size_t) B * cap))) return rc;
     if ((rc = dev_alloc(c, pool, &c->W.sd_rawn, (size_t) B * cap))) return rc;
-    if ((rc = dev_alloc(c, pool, &c->W.sd_tmp, (size_t) B * 24 * cap))) return rc;
+    if ((rc = dev_alloc(c, pool, &c->W.sd_tmp, (size_t) B * self_tmp_ints(cap)))) return rc;
   }
   if ((rc = dev_alloc(c, pool, &c->xf_cur, (size_t) B * 3 * Af))) return rc;
   if ((rc = dev_alloc(c, pool, &c->XF, (size_t) B * 3 * Af * slots))) return rc;
@@ -604,6 +796,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
         for (int d = 0; d < 3; d++) xf[((size_t) b * 3 + d) * Af + a] = (float) c->host.rest[3 * c->host.att_vertex[a] + d];
     HIPCHK(c, hipMemcpy(c->xf_cur, xf.data(), xf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  if ((rc = choose_cluster(c))) return rc;
   return dc_set_mu(c, nullptr);
 }
 
@@ -638,7 +831,7 @@ int dc_set_vertex_forces(dc_ctx *c, const double *f) {
   if (!c || c->B <= 0) return fail(c, DC_ERR_STATE, "dc_set_vertex_forces: no batch");
   if (!f) { c->fv_set = false; return DC_OK; }
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = h2d_planar(c, f, c->fv, c->host.N, 0);
+  int rc = h2d_planar(c, f, c->fv, c->host.N, 0, true);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->fv_set = true;
@@ -650,7 +843,7 @@ int dc_get_force_gradient(dc_ctx *c, double *dL_df) {
   if (rc) return rc;
   if (!dL_df) return fail(c, DC_ERR_INVALID, "dc_get_force_gradient: null output");
   // the adjoint kernel leaves y = (I + dr_df)^T u* of its last step in the work vector it shares with the forward kernel
-  if ((rc = d2h_planar(c, c->W.vbest, dL_df, c->host.N, 0))) return rc;
+  if ((rc = d2h_planar(c, c->W.vbest, dL_df, c->host.N, 0, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const double h2 = c->params.time_step * c->params.time_step;
   const size_t n = (size_t) c->B * 3 * c->host.N;
@@ -664,8 +857,8 @@ int dc_set_state(dc_ctx *c, int slot, const double *x, const double *v) {
   if (!x || !v) return fail(c, DC_ERR_INVALID, "dc_set_state: null state");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t se = slot_elems(c);
-  if ((rc = h2d_planar(c, x, c->X + se * slot, c->host.N, 0))) return rc;
-  if ((rc = h2d_planar(c, v, c->V + se * slot, c->host.N, 1))) return rc;
+  if ((rc = h2d_planar(c, x, c->X + se * slot, c->host.N, 0, true))) return rc;
+  if ((rc = h2d_planar(c, v, c->V + se * slot, c->host.N, 1, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host buffers may be reused by the caller
   return DC_OK;
 }
@@ -675,8 +868,8 @@ int dc_get_state(dc_ctx *c, int slot, double *x, double *v) {
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t se = slot_elems(c);
-  if (x && (rc = d2h_planar(c, c->X + se * slot, x, c->host.N, 0))) return rc;
-  if (v && (rc = d2h_planar(c, c->V + se * slot, v, c->host.N, 1))) return rc;
+  if (x && (rc = d2h_planar(c, c->X + se * slot, x, c->host.N, 0, true))) return rc;
+  if (v && (rc = d2h_planar(c, c->V + se * slot, v, c->host.N, 1, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DC_OK;
 }
@@ -687,15 +880,17 @@ int dc_step_forward(dc_ctx *c, int slot, const double *fixed_pts, dc_step_stats 
   HIPCHK(c, hipSetDevice(c->device));
   const int Af = c->S.Af;
   if (fixed_pts && Af > 0) {
-    if ((rc = h2d_planar(c, fixed_pts, c->xf_cur, Af, 2))) return rc;
+    if ((rc = h2d_planar(c, fixed_pts, c->xf_cur, Af, 2, false))) return rc;
   }
   if (Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * Af * (slot + 1), c->xf_cur, sizeof(float) * c->B * 3 * Af, hipMemcpyDeviceToDevice, c->stream));
   if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
-  launch_pd_step(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
-  HIPCHK(c, hipGetLastError());
+  if ((rc = cluster_begin(c))) return rc;
+  if ((rc = enqueue_pd_step(c, fwd_args(c, slot)))) return rc;
   if (stats) {
     HIPCHK(c, hipMemcpyAsync(stats, c->fstats + (size_t) c->B * (slot + 1), sizeof(dc_step_stats) * c->B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = cluster_check(c))) return rc;
+    if ((rc = check_self_overflow(c, stats, slot + 1))) return rc;
   } else if (fixed_pts && Af > 0) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
@@ -707,8 +902,8 @@ int dc_get_record(dc_ctx *c, int slot, double *f, double *r) {
   if (rc) return rc;
   if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_get_record: slot 0 has no record");
   const size_t se = slot_elems(c);
-  if (f && (rc = d2h_planar(c, c->F + se * slot, f, c->host.N, 0))) return rc;
-  if (r && (rc = d2h_planar(c, c->R + se * slot, r, c->host.N, 1))) return rc;
+  if (f && (rc = d2h_planar(c, c->F + se * slot, f, c->host.N, 0, true))) return rc;
+  if (r && (rc = d2h_planar(c, c->R + se * slot, r, c->host.N, 1, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return DC_OK;
 }
@@ -718,7 +913,7 @@ int dc_get_contacts(dc_ctx *c, int slot, int *prim_group, double *normal) {
   if (rc) return rc;
   if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_get_contacts: slot 0 has no record");
   const size_t se = slot_elems(c), sp = (size_t) c->B * c->host.N;
-  if (normal && (rc = d2h_planar(c, c->NRM + se * slot, normal, c->host.N, 0))) return rc;
+  if (normal && (rc = d2h_planar(c, c->NRM + se * slot, normal, c->host.N, 0, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (prim_group) {
     std::vector<int> dev(sp);
@@ -770,24 +965,25 @@ int dc_step_backward(dc_ctx *c, int slot, const double *dL_dxnew, const double *
   if (!dL_dxnew || !dL_dvnew || !dL_dx || !dL_dv) return fail(c, DC_ERR_INVALID, "dc_step_backward: null gradient");
   HIPCHK(c, hipSetDevice(c->device));
   const int N = c->host.N, Af = c->S.Af, G = c->S.ngroups;
-  if ((rc = h2d_planar(c, dL_dxnew, c->GX, N, 0))) return rc;
-  if ((rc = h2d_planar(c, dL_dvnew, c->GV, N, 1))) return rc;
+  if ((rc = h2d_planar(c, dL_dxnew, c->GX, N, 0, true))) return rc;
+  if ((rc = h2d_planar(c, dL_dvnew, c->GV, N, 1, true))) return rc;
   const bool with_init = dL_dxinit && dL_dvinit;
   if (with_init) {
-    if ((rc = h2d_planar(c, dL_dxinit, c->IX, N, 2))) return rc;
-    if ((rc = h2d_planar(c, dL_dvinit, c->IV, N, 3))) return rc;
+    if ((rc = h2d_planar(c, dL_dxinit, c->IX, N, 2, true))) return rc;
+    if ((rc = h2d_planar(c, dL_dvinit, c->IV, N, 3, true))) return rc;
   }
   HIPCHK(c, hipMemsetAsync(c->DMU, 0, sizeof(float) * c->B * G, c->stream));
   if (Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF, 0, sizeof(float) * c->B * 3 * Af, c->stream));
-  launch_adjoint_step(c->S, c->W, bwd_args(c, slot, is_start != 0, with_init), c->B, c->stream);
-  HIPCHK(c, hipGetLastError());
-  if ((rc = d2h_planar(c, c->GX, dL_dx, N, 0))) return rc;
-  if ((rc = d2h_planar(c, c->GV, dL_dv, N, 1))) return rc;
-  if (dL_dxfixed && Af > 0 && (rc = d2h_planar(c, c->DXF, dL_dxfixed, Af, 2))) return rc;
+  if ((rc = cluster_begin(c))) return rc;
+  if ((rc = enqueue_adjoint_step(c, bwd_args(c, slot, is_start != 0, with_init)))) return rc;
+  if ((rc = d2h_planar(c, c->GX, dL_dx, N, 0, true))) return rc;
+  if ((rc = d2h_planar(c, c->GV, dL_dv, N, 1, true))) return rc;
+  if (dL_dxfixed && Af > 0 && (rc = d2h_planar(c, c->DXF, dL_dxfixed, Af, 2, false))) return rc;
   std::vector<float> dmu((size_t) c->B * G);
   HIPCHK(c, hipMemcpyAsync(dmu.data(), c->DMU, dmu.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (stats) HIPCHK(c, hipMemcpyAsync(stats, c->bstats + (size_t) c->B * slot, sizeof(dc_bwd_stats) * c->B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((rc = cluster_check(c))) return rc;
   if (dL_dmu) for (size_t k = 0; k < dmu.size(); k++) dL_dmu[k] = dmu[k];
   return DC_OK;
 }
@@ -799,7 +995,8 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
   const bool self_on = c->S.contact_enabled && c->S.self_enabled;
   static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
-  const bool fused = fuse_ok && nsteps > 1 && pd_step_fusable(c->S);
+  const bool fused = fuse_ok && nsteps > 1 && (use_cluster_fwd(c) || pd_step_fusable(c->S));
+  if ((rc = cluster_begin(c))) return rc;
   if (fused) {
     // all steps of a rollout run inside ONE launch (self-collision detection inlined per step), so a rollout never waits
     // for the slowest rollout of the batch between steps
@@ -807,12 +1004,12 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
       HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
     FwdArgs A = fwd_args(c, slot);
     A.nsteps = nsteps; A.inline_detect = self_on ? 1 : 0;
-    launch_pd_step(c->S, c->W, A, c->B, c->stream);
+    if ((rc = enqueue_pd_step(c, A))) return rc;
   } else {
     for (int k = 0; k < nsteps; k++) {
       if (c->S.Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
       if (self_on) launch_self_detect(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
-      launch_pd_step(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
+      if ((rc = enqueue_pd_step(c, fwd_args(c, slot + k)))) return rc;
     }
   }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
@@ -821,8 +1018,9 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventSynchronize(c->ev_b));
   float ms = 0;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-  c->fwd_ms += ms; c->fwd_launches += fused ? 1 : nsteps;
-  return DC_OK;
+  const int chunks = use_cluster_fwd(c) ? (c->B + c->cl.nb - 1) / c->cl.nb : 1;
+  c->fwd_ms += ms; c->fwd_launches += (fused ? 1 : nsteps) * chunks;
+  return cluster_check(c);
 }
 
 int dc_seed_gradient(dc_ctx *c, int slot, const double *target, double scale_x) {
@@ -848,14 +1046,15 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
   static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
+  if ((rc = cluster_begin(c))) return rc;
   if (fuse_ok && nsteps > 1) {
     BwdArgs A = bwd_args(c, slot, slot == 1, false);
     A.nsteps = nsteps;                       // the whole sweep of a rollout in one launch
-    launch_adjoint_step(c->S, c->W, A, c->B, c->stream);
+    if ((rc = enqueue_adjoint_step(c, A))) return rc;
   } else {
     for (int k = 0; k < nsteps; k++) {
       const int s = slot - k;
-      launch_adjoint_step(c->S, c->W, bwd_args(c, s, s == 1, false), c->B, c->stream);   // isStart: Simulation.cpp:3947
+      if ((rc = enqueue_adjoint_step(c, bwd_args(c, s, s == 1, false)))) return rc;   // isStart: Simulation.cpp:3947
     }
   }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
@@ -863,16 +1062,17 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventSynchronize(c->ev_b));
   float ms = 0;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
-  c->bwd_ms += ms; c->bwd_launches += (fuse_ok && nsteps > 1) ? 1 : nsteps;
-  return DC_OK;
+  const int chunks = use_cluster_bwd(c) ? (c->B + c->cl.nb - 1) / c->cl.nb : 1;
+  c->bwd_ms += ms; c->bwd_launches += ((fuse_ok && nsteps > 1) ? 1 : nsteps) * chunks;
+  return cluster_check(c);
 }
 
 int dc_get_gradient(dc_ctx *c, double *dL_dx, double *dL_dv, double *dL_dmu) {
   int rc = check_batch(c, 0, 0);
   if (rc) return rc;
   const int N = c->host.N, G = c->S.ngroups;
-  if (dL_dx && (rc = d2h_planar(c, c->GX, dL_dx, N, 0))) return rc;
-  if (dL_dv && (rc = d2h_planar(c, c->GV, dL_dv, N, 1))) return rc;
+  if (dL_dx && (rc = d2h_planar(c, c->GX, dL_dx, N, 0, true))) return rc;
+  if (dL_dv && (rc = d2h_planar(c, c->GV, dL_dv, N, 1, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (dL_dmu) {
     std::vector<float> dmu((size_t) c->B * G);
@@ -898,6 +1098,7 @@ int dc_get_stats(dc_ctx *c, int slot, dc_step_stats *fwd, dc_bwd_stats *bwd) {
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (fwd) HIPCHK(c, hipMemcpy(fwd, c->fstats + (size_t) c->B * slot, sizeof(dc_step_stats) * c->B, hipMemcpyDeviceToHost));
+  if (fwd && slot >= 1 && (rc = check_self_overflow(c, fwd, slot))) return rc;
   if (bwd) HIPCHK(c, hipMemcpy(bwd, c->bstats + (size_t) c->B * slot, sizeof(dc_bwd_stats) * c->B, hipMemcpyDeviceToHost));
   return DC_OK;
 }
@@ -906,6 +1107,13 @@ int dc_sync(dc_ctx *c) {
   if (!c) return DC_ERR_INVALID;
   if (c->host_only) return DC_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return cluster_check(c);
+}
+
+int dc_get_cluster(const dc_ctx *c, int *workgroups_per_rollout, int *rollouts_per_launch) {
+  if (!c) return DC_ERR_INVALID;
+  if (workgroups_per_rollout) *workgroups_per_rollout = c->cl.ok ? c->cl.K : 1;
+  if (rollouts_per_launch) *rollouts_per_launch = c->cl.ok ? c->cl.nb : c->B;
   return DC_OK;
 }
 

@@ -1,0 +1,365 @@
+// CDNA4 (gfx950) forward step, split variant: one rollout is run by K workgroups (dc_cluster.h), part p owning the vertex rows
+// [p R, (p + 1) R). Same algorithm as dc_forward_pk.hip (Simulation::step, Simulation.cpp:1043-1428; global solve :1267 replaced
+// by Jacobi-PCG on the symmetrically scaled packet matrix), same per-part data placement (search direction in LDS, residual /
+// A p / iterate in registers, element windows in LDS); what is new is what crosses the parts:
+//   * PD level: the velocity iterate v is written and read write-through (sc1), its hand-over flag is the exchange that carries
+//     the convergence norm; per time step the tape state changes hands under an agent-scope release / acquire pair;
+//   * PCG level, two exchanges per iteration: [p.Ap partials] and [r.r partial + the HB boundary rows of the new residual]; every
+//     part keeps the neighbours' boundary rows of the search direction in its LDS gather array and updates them itself
+//     (p_halo = r_halo + beta p_halo), so the direction never travels;
+//   * self contacts couple arbitrary vertices: detection + layering and the layered friction pass of an iteration run on part 0
+//     over the rollout's global arrays, bracketed by fence barriers.
+// All parts take identical control-flow decisions: every scalar that steers a loop is a sum over the parts in part order.
+#define DC_KERNEL_TU
+#include "dc_devlib.h"
+#include "dc_winlib.h"
+#include "dc_selflib.h"
+#include "dc_pklib.h"
+#include "dc_cluster.h"
+#include <algorithm>
+
+namespace dc {
+
+template <int THREADS, int VPT, bool DETECT>
+__global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
+                                                        FwdArgs A, int b0, int tail_off) {
+  const DevSystem &S = *Sp;
+  const DevCluster &CL = *Cp;
+  constexpr int WAVES = THREADS / 64;
+  constexpr int HPT = (1024 + THREADS - 1) / THREADS;      // halo rows per thread: 2 HB <= 1024
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ double red[THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = CL.K, R = CL.R, HB = CL.HB, GL = R + 2 * HB;
+  int lb, part;
+  cluster_map(K, lb, part);
+  const int b = b0 + lb;
+  Xch X = xch_init(CL, lb, part, lds + tail_off);
+  float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
+  float *gz = lds + 2 * GL;
+  const int N = S.N;
+  const int r0 = part * R, r1 = min(N, r0 + R);
+  const int nch = R >> 6, cbase = r0 >> 6;
+  const size_t off = (size_t) b * 3 * N;
+  float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off, *scr = W.cg_r + off;
+  const BufVec vnb = buf_vec(vnow, N);
+  const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
+  const int w0 = part * CL.wpp, w1 = min(CL.nwin, w0 + CL.wpp);
+
+  for (int step = 0; step < A.nsteps; step++) {
+  // the previous step's state (written by every part with plain stores) changes hands
+  X.site = 1;
+  if (step > 0) { if (!xch_fence_barrier<THREADS>(X)) return; }
+  const size_t so = (size_t) step * A.slot_state;
+  // the tape state and f / r are read across parts: write-through stores, L1-bypassing loads (xnb, vinb, rfb, rrb, xob, vob)
+  const BufVec xnb = buf_vec(A.x_in + off + so, N), vinb = buf_vec(A.v_in + off + so, N);
+  const BufVec rfb = buf_vec(A.rec_f + off + so, N), rrb = buf_vec(A.rec_r + off + so, N);
+  float *rec_n = A.rec_n + off + so;
+  int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
+  SelfRec srec = A.self;
+  srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
+  srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
+  if constexpr (DETECT) {                     // detection + layering of this step: part 0, then the lists change hands
+    X.site = 2;
+    if (part == 0) self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, A.fv, (int *) lds);
+    if (!xch_fence_barrier<THREADS>(X)) return;
+  }
+  // number of self contacts of this step: part 0 knows it (its own detection, or the stand-alone detection kernel's record) and
+  // hands it to the others inside an exchange, so that no part ever has to read it from memory another part wrote
+  int nself = 0;
+  {
+    double ns[3] = {0, 0, 0};
+    if (part == 0 && S.contact_enabled && S.self_enabled) ns[0] = (double) srec.meta[(size_t) b * kMetaStride];
+    if (!xch_sums<THREADS>(X, ns)) return;
+    nself = (int) (ns[0] + 0.5);
+  }
+  const float *mu = A.mu + (size_t) b * S.ngroups;
+  const float h = S.h;
+  const f3 grav = mk(S.gx, S.gy, S.gz);
+  const f3 fu = A.fu ? mk(A.fu[3 * b], A.fu[3 * b + 1], A.fu[3 * b + 2]) : mk(0, 0, 0);
+
+  // ---- step set-up on the own rows: s_n, initial guess, contact detection (Simulation.cpp:1097-1160, :1254-1256) ----
+  float part_s = 0.f;
+  int ncontact = 0;
+  for (int i = r0 + tid; i < r1; i += THREADS) {
+    const float m = S.mass[i];
+    f3 v = ld3c(vinb, i);
+    f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
+    if (A.fv) fext = fext + ld3(A.fv + off, i, N);
+    f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
+    st3c(vnb, i, v0);
+    st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h
+    part_s += dot(v0, v0);
+    int prim = -1;
+    f3 nrm = mk(0, 0, 0);
+    if (S.contact_enabled) prim = detect_primitive(S, ld3c(xnb, i), v0, nrm);
+    rec_prim[i] = prim;
+    st3(rec_n, i, N, nrm);
+    ncontact += (prim >= 0);
+  }
+  xch_drain();                                    // v is read by the neighbours' windows: its stores must have left the CU
+  double sums[3];
+  X.site = 3;
+  sums[0] = block_sum<THREADS>((double) part_s, red); sums[1] = block_sum<THREADS>((double) ncontact, red); sums[2] = 0;
+  if (!xch_sums<THREADS>(X, sums)) return;
+  double min_xdiff = (double) h * sqrt(sums[0]) / (double) N;
+  const int total_contacts = (int) (sums[1] + 0.5);
+  bool improved = false, converged = false, stalled = false, best_is_current = false;
+  int iters = 0, cg_total = 0, since_progress = 0;
+  double xdiff = 0;
+
+  for (int iter = 0; iter < A.pd_cap; iter++) {
+    int zp;                                       // opaque zero against LICM of the unrolled row indices (dc_forward_pk.hip)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zp));
+    const int tq = tid + zp;
+    auto vertex_body = [&](int i, f3 fint) -> f3 {
+      f3 f = ld3(g, i, N) + fint;
+      f3 v = ld3c(vnb, i);
+      const int a = S.att_of_vertex[i];
+      if (a >= 0) f = f + ((ld3(xfix, a, S.Af) - ld3c(xnb, i)) - v * h) * (h * S.k_att);   // AttachmentSpring.cpp:25-29
+      const float m = S.mass[i];
+      f3 r = mk(0, 0, 0);
+      const int prim = rec_prim[i];
+      if (prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
+        f3 n = ld3(rec_n, i, N);
+        f3 d = f - prim_vout(S.prims[prim], n) * m;
+        r = dry_friction(n, d, mu[S.prims[prim].group]);
+      }
+      st3c(rfb, i, f);
+      st3c(rrb, i, r);
+      return (f + r - v * m) * CL.sq_dinv[i];       // scaled residual D^-1/2 rhs
+    };
+    // ---- local step + vertex pass through this part's element windows ----
+    float psum = 0.f;
+    element_windows_t<THREADS>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, FwdTriOp{h}, FwdBendOp{h}, [&](int i, f3 sum, f3) {
+      f3 rhs = vertex_body(i, sum);
+      st3(scr, i, N, rhs);
+      psum += dot(rhs, rhs);
+    });
+    __syncthreads();
+    X.site = 4;
+    if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) on part 0 over the rollout's f / r, then the right-hand side again
+      if (!xch_fence_barrier<THREADS>(X)) return;
+      if (part == 0) {
+        if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, tail_off)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
+      }
+      if (!xch_fence_barrier<THREADS>(X)) return;
+      psum = 0.f;
+      for (int i = r0 + tid; i < r1; i += THREADS) {
+        f3 rhs = (ld3c(rfb, i) + ld3c(rrb, i) - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i];
+        st3(scr, i, N, rhs);
+        psum += dot(rhs, rhs);
+      }
+      __syncthreads();
+    }
+    // ---- residual into registers, search direction p0 = r0 into the gather array, boundary rows to the neighbours ----
+    float rr[VPT][3], ap[VPT][3], xx[VPT][3];
+    X.site = 5;
+    xch_begin(X);
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      const int l = tq + k * THREADS, i = r0 + l;
+      const bool on = l < R && i < N;
+      const int ic = on ? i : r0;
+      const float okf = on ? 1.f : 0.f;
+      rr[k][0] = scr[ic] * okf; rr[k][1] = scr[N + ic] * okf; rr[k][2] = scr[2 * N + ic] * okf;
+#pragma unroll
+      for (int c = 0; c < 3; c++) xx[k][c] = 0.f;
+      if (l < R) {
+        gxy[HB + l] = make_float2(rr[k][0], rr[k][1]); gz[HB + l] = rr[k][2];
+        xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
+      }
+    }
+    double rz;
+    {
+      const double ps = block_sum<THREADS>((double) psum, red);
+      if (tid == 0) xch_publish_sums(X, (float) ps, 0.f, 0.f);
+      f3 hv[HPT];
+      if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
+#pragma unroll
+      for (int q = 0; q < HPT; q++) {
+        const int j = tid + q * THREADS;
+        if (j < 2 * HB) { const int li = j < HB ? j : R + j; gxy[li] = make_float2(hv[q].x, hv[q].y); gz[li] = hv[q].z; }
+      }
+      rz = sums[0];
+    }
+    // ap = Ahat p on the own rows (p incl. halo in the gather array), part2 += <p, ap>
+    auto spmv = [&](int wz, float &part2) {
+      int4 nxt[PB];
+      load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
+#pragma unroll
+      for (int k = 0; k < VPT; k++) {
+        const int lc = wz + k * WAVES;          // wave-uniform local chunk
+        const int lcc = min(lc, nch - 1);
+        const float onf = lc < nch ? 1.f : 0.f;
+        const int chunk = cbase + lcc;
+        const int np = CL.pk_n[chunk];
+        const int4 *row = CL.pk + CL.pk_ptr[chunk] + lane;
+        int4 cur[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) cur[j] = nxt[j];
+        if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
+        const int li = HB + lcc * 64 + lane;
+        const float2 pxy = gxy[li];
+        const float pz = gz[li];
+        float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
+        const int base = li - 512;
+        consume_p(cur, gxy, gz, base, ax, ay, az);
+        for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
+          load_batch(cur, row, s0);
+          consume_p(cur, gxy, gz, base, ax, ay, az);
+        }
+        ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
+        part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    __syncthreads();
+    // ---- global step: plain CG on the scaled system = Jacobi PCG on P dv = rhs ----
+    if (rz > 1e-300) {
+      const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+      for (int it = 0; it < A.cg_max;) {
+        float part2 = 0.f;
+        int zs;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+        const int wz = wv + zs, tz = tid + zs;
+        spmv(wz, part2);
+        X.site = 6;
+        sums[0] = block_sum_f<THREADS>(part2, red); sums[1] = 0; sums[2] = 0;
+        if (!xch_sums<THREADS>(X, sums)) return;
+        const float alpha = (float) (rz / sums[0]);
+        part2 = 0.f;
+        X.site = 7;
+        xch_begin(X);
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int l = tz + k * THREADS;
+          const int lc = min(l, R - 1);
+          const float2 pxy = gxy[HB + lc];
+          const float pv[3] = {pxy.x, pxy.y, gz[HB + lc]};
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            xx[k][c] = fmaf(alpha, pv[c], xx[k][c]);
+            rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
+            part2 = fmaf(rr[k][c], rr[k][c], part2);
+          }
+          if (l < R) xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
+        }
+        const double ps = block_sum_f<THREADS>(part2, red);
+        if (tid == 0) xch_publish_sums(X, (float) ps, 0.f, 0.f);
+        f3 hv[HPT];
+        if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
+        const double rz_new = sums[0];
+        it++; cg_total++;
+        if (!(rz_new > stop)) break;
+        const float beta = (float) (rz_new / rz);
+        rz = rz_new;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int l = tz + k * THREADS;
+          if (l < R) {
+            const float2 pxy = gxy[HB + l];
+            gxy[HB + l] = make_float2(fmaf(beta, pxy.x, rr[k][0]), fmaf(beta, pxy.y, rr[k][1]));
+            gz[HB + l] = fmaf(beta, gz[HB + l], rr[k][2]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < HPT; q++) {         // the neighbours' boundary rows of p, updated here from their residual rows
+          const int j = tid + q * THREADS;
+          if (j < 2 * HB) {
+            const int li = j < HB ? j : R + j;
+            const float2 pxy = gxy[li];
+            gxy[li] = make_float2(fmaf(beta, pxy.x, hv[q].x), fmaf(beta, pxy.y, hv[q].y));
+            gz[li] = fmaf(beta, gz[li], hv[q].z);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- update + convergence (Simulation.cpp:1268, 1310-1373); delta v replaces A p in its registers ----
+    psum = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+      const int l = tq + k * THREADS, i = r0 + l;
+      const bool on = l < R && i < N;
+      const int ic = on ? i : r0;
+      const float sq = CL.sq_dinv[ic];
+      const f3 vq = ld3c(vnb, ic);
+      ap[k][0] = xx[k][0] * sq; ap[k][1] = xx[k][1] * sq; ap[k][2] = xx[k][2] * sq;
+      if (on) {
+        st3c(vnb, i, mk(vq.x + ap[k][0], vq.y + ap[k][1], vq.z + ap[k][2]));
+        psum = fmaf(ap[k][0], ap[k][0], psum); psum = fmaf(ap[k][1], ap[k][1], psum); psum = fmaf(ap[k][2], ap[k][2], psum);
+      }
+    }
+    X.site = 8;
+    xch_drain();                                  // the new v must have left the CU before the norm (= its hand-over flag) is published
+    sums[0] = block_sum<THREADS>((double) psum, red); sums[1] = 0; sums[2] = 0;
+    if (!xch_sums<THREADS>(X, sums)) return;
+    xdiff = (double) h * sqrt(sums[0]) / (double) N;
+    iters = iter + 1;
+    converged = xdiff < (double) A.fwd_tol;
+    if (xdiff < min_xdiff) {
+      since_progress = 0;
+      min_xdiff = xdiff;
+      improved = true;
+      best_is_current = true;
+    } else if (best_is_current) {
+      // first non-improving iteration after a minimum: the best iterate is the previous one = v - delta (delta is still in registers)
+      best_is_current = false;
+#pragma unroll
+      for (int k = 0; k < VPT; k++) {
+        const int l = tq + k * THREADS, i = r0 + l;
+        if (l < R && i < N) {
+          const f3 v = ld3c(vnb, i);
+          vbest[i] = v.x - ap[k][0]; vbest[N + i] = v.y - ap[k][1]; vbest[2 * N + i] = v.z - ap[k][2];
+        }
+      }
+    }
+    if (converged) break;
+    if (++since_progress >= A.stall_window) { stalled = true; break; }
+  }
+  // ---- write the new state of the own rows (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
+  const BufVec xob = buf_vec(A.x_out + off + so, N), vob = buf_vec(A.v_out + off + so, N);
+  for (int i = r0 + tid; i < r1; i += THREADS) {
+    f3 x = ld3c(xnb, i);
+    if (converged) { f3 v = ld3c(vnb, i); st3c(vob, i, v); st3c(xob, i, x + v * h); }
+    else if (improved) { f3 v = best_is_current ? ld3c(vnb, i) : ld3(vbest, i, N); st3c(vob, i, v); st3c(xob, i, x + v * h); }
+    else { st3c(vob, i, ld3c(vinb, i)); st3c(xob, i, x); }
+  }
+  if (tid == 0 && part == 0) {
+    dc_step_stats s;
+    s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
+    s.self_contacts = nself; s.last_xdiff = (float) xdiff;
+    s.self_overflow = (S.contact_enabled && S.self_enabled) ? srec.meta[(size_t) b * kMetaStride + kMetaStride - 2] : 0;
+    A.stats[b + (size_t) step * A.slot_stats] = s;
+  }
+  }   // step
+}
+
+template <int VPT, bool DETECT>
+static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
+  constexpr int THREADS = 512;
+  const int GL = CL.R + 2 * CL.HB;
+  int floats = std::max(3 * GL, CL.win_lds_bytes / 4);
+  if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
+  const int tail_off = (floats + 3) / 4 * 4;
+  const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
+  if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, tail_off);
+  return hipGetLastError();
+}
+
+// nb rollouts starting at b0, K workgroups each; the caller has zeroed the exchange area and made sure K nb <= CUs.
+hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
+#define DC_CL_CASE(V) case V: return A.inline_detect ? launch_cl_inst<V, true>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false>(S, CL, W, A, b0, nb, st);
+  switch (CL.pk_vpt) {
+    DC_CL_CASE(1) DC_CL_CASE(2) DC_CL_CASE(3) DC_CL_CASE(4) DC_CL_CASE(6) DC_CL_CASE(8) DC_CL_CASE(12)
+    default: return hipErrorInvalidValue;
+  }
+#undef DC_CL_CASE
+}
+
+}  // namespace dc

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
     dc_step_stats s;
     s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
     s.self_contacts = nself; s.last_xdiff = (float) xdiff;
+    s.self_overflow = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride + kMetaStride - 2] : 0;
     A.stats[b] = s;
   }
   PH_PRINT

@@ -7,15 +7,28 @@
 namespace dc {
 
 bool HostPackets::build(const HostSystem &H) {
+  static const int allowed[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20};      // instantiated rows-per-thread of k_pd_step_pk
+  const int need = (H.N + 511) / 512;
+  int v = 0;
+  for (int a : allowed) if (a >= need) { v = a; break; }
+  if (v == 0) {          // too large for the one-workgroup kernel: report the bandwidth, no tables
+    *this = HostPackets();
+    for (int r = 0; r < H.N; r++)
+      for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++) bandwidth = std::max(bandwidth, std::abs(H.P_col[k] - r));
+    return false;
+  }
+  if (!build_rows(H, 512 * v)) return false;
+  vpt = v;
+  return true;
+}
+
+bool HostPackets::build_rows(const HostSystem &H, int rows_padded) {
   *this = HostPackets();
   const int N = H.N;
-  static const int allowed[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20};      // instantiated rows-per-thread of k_pd_step_pk
-  const int need = (N + 511) / 512;
-  for (int a : allowed) if (a >= need) { vpt = a; break; }
   for (int r = 0; r < N; r++)
     for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++) bandwidth = std::max(bandwidth, std::abs(H.P_col[k] - r));
-  if (vpt == 0 || bandwidth > 511) return false;
-  const int NPk = 512 * vpt, nch = NPk / 64, PBk = 4;
+  if (bandwidth > 511 || rows_padded < N || rows_padded % 64 != 0) return false;
+  const int NPk = rows_padded, nch = NPk / 64, PBk = 4;
   std::vector<double> sq(N);
   sq_dinv.assign(NPk, 0.f);
   for (int i = 0; i < N; i++) {

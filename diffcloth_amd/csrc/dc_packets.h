@@ -19,6 +19,8 @@ struct HostPackets {
 
   // false when the tables cannot be used: N > 10 240 rows or bandwidth > 511
   bool build(const HostSystem &H);
+  // the same tables padded to `rows_padded` rows (a multiple of 64, >= N), any N; false when the bandwidth exceeds 511
+  bool build_rows(const HostSystem &H, int rows_padded);
 };
 
 }  // namespace dc

@@ -3,6 +3,7 @@
 // (Simulation.cpp:225-373, self part :281-352), isSelfCollision (:194-220), contactSorting (:422-624).
 #pragma once
 #include "dc_devlib.h"
+#include "dc_selftmp.h"
 
 namespace dc {
 
@@ -46,100 +47,90 @@ __device__ __forceinline__ bool connected(const DevSystem &S, int i, int j) {   
   return false;
 }
 
-// Simulation::contactSorting (Simulation.cpp:422-624), serial. Contacts are given sorted by (p1, p2).
-// tmp layout (ints): ids[2C] | adj_ptr[2C+1] | adj_other[2C] | adj_contact[2C] | deg[2C] | frontier[2C] | newf[2C] |
-//                    involved[2C] | layer[C] | alive[C]
-__device__ void contact_sorting_serial(int C, const int2 *pair, const int *rec_prim, const int *dev_of, int *tmp, int cap, int *meta, int *layer_out) {
-  int *ids = tmp, *adj_ptr = ids + 2 * cap, *adj_other = adj_ptr + 2 * cap + 1, *adj_contact = adj_other + 2 * cap;
-  int *deg = adj_contact + 2 * cap, *frontier = deg + 2 * cap, *newf = frontier + 2 * cap, *involved = newf + 2 * cap;
-  int *layer = involved + 2 * cap, *alive = layer + cap;
-  // unique sorted particle ids (std::map iteration order)
-  int M = 0;
-  {
-    // merge of the p1 sequence (sorted) and all p2 values: insertion into a sorted array (C is small)
-    for (int k = 0; k < C; k++) {
-      const int vals[2] = {pair[k].x, pair[k].y};
-      for (int q = 0; q < 2; q++) {
-        int v = vals[q], lo = 0, hi = M;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (ids[mid] < v) lo = mid + 1; else hi = mid; }
-        if (lo < M && ids[lo] == v) continue;
-        for (int t = M; t > lo; t--) ids[t] = ids[t - 1];
-        ids[lo] = v; M++;
-      }
-    }
+// Exclusive prefix sum of a[0, n) in place (a in global memory or LDS); returns the total to every thread. `scratch` =
+// THREADS / 64 ints of LDS. Call with all threads; starts and ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ int block_scan_excl(int *a, int n, int *scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (n + THREADS - 1) / THREADS, c0 = min(n, tid * chunk), c1 = min(n, c0 + chunk);
+  __syncthreads();                               // a[] was written by other threads
+  int sum = 0;
+  for (int c = c0; c < c1; c++) sum += a[c];
+  int v = sum;                                   // inclusive scan of the chunk totals inside the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+  __syncthreads();
+  if (lane == 63) scratch[wave] = v;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; w++) { const int t = scratch[w]; base += (w < wave) ? t : 0; total += t; }
+  int run = base + v - sum;
+  for (int c = c0; c < c1; c++) { const int t = a[c]; a[c] = run; run += t; }
+  __syncthreads();
+  return total;
+}
+
+// Layout of the per-rollout layering scratch (DevWork::sd_tmp), in ints; U = 2 cap + 2 entries per per-vertex array
+// (a contact list of C pairs has at most 2 C distinct vertices).
+struct SelfTmp {
+  int *ids, *adj_ptr, *adj_other, *adj_contact, *deg, *frontier, *newf, *involved, *c2, *act, *layer, *alive;
+  int2 *spair;
+  __device__ SelfTmp(int *tmp, int cap) {
+    const int U = 2 * cap + 2;
+    ids = tmp; adj_ptr = tmp + U; adj_other = tmp + 2 * U; adj_contact = tmp + 3 * U; deg = tmp + 4 * U; frontier = tmp + 5 * U;
+    newf = tmp + 6 * U; involved = tmp + 7 * U; c2 = tmp + 8 * U; act = tmp + 9 * U; layer = tmp + 10 * U; alive = layer + cap;
+    spair = (int2 *) (alive + cap);              // 10 U + 2 cap is even: 8-byte aligned
   }
-  auto local = [&](int v) { int lo = 0, hi = M; while (lo < hi) { int mid = (lo + hi) >> 1; if (ids[mid] < v) lo = mid + 1; else hi = mid; } return lo; };
-  for (int m = 0; m <= M; m++) adj_ptr[m] = 0;
-  for (int k = 0; k < C; k++) { adj_ptr[local(pair[k].x) + 1]++; adj_ptr[local(pair[k].y) + 1]++; }
-  for (int m = 0; m < M; m++) adj_ptr[m + 1] += adj_ptr[m];
-  for (int m = 0; m < M; m++) deg[m] = 0;
-  // neighbours ascending: for vertex q first the contacts where q is id2 (others < q, ascending in k), then id1
-  for (int k = 0; k < C; k++) { int b = local(pair[k].y); int o = adj_ptr[b] + deg[b]++; adj_other[o] = local(pair[k].x); adj_contact[o] = k; }
-  for (int k = 0; k < C; k++) { int a = local(pair[k].x); int o = adj_ptr[a] + deg[a]++; adj_other[o] = local(pair[k].y); adj_contact[o] = k; }
-  for (int k = 0; k < C; k++) { alive[k] = 1; layer[k] = -1; }
-  for (int m = 0; m < M; m++) { frontier[m] = 0; newf[m] = 0; involved[m] = 0; }
-  int processed = 0, maxLayer = 0, nfront = 0;
-  // primitive contacts go into the first layer: they seed the frontier when they also have self contacts
-  for (int m = 0; m < M; m++) if (rec_prim[dev_of ? dev_of[ids[m]] : ids[m]] >= 0 && deg[m] > 0) { frontier[m] = 1; nfront++; }
-  auto first_alive = [&](int m) { for (int o = adj_ptr[m]; o < adj_ptr[m + 1]; o++) if (alive[adj_contact[o]]) return o; return -1; };
-  // lonely pairs (O-O) -> layer 0
-  for (int m = 0; m < M; m++) {
-    if (deg[m] != 1) continue;
-    int o = first_alive(m);
-    int other = adj_other[o];
-    if (deg[other] != 1) continue;
-    if (frontier[m] || frontier[other]) continue;
-    int k = adj_contact[o];
-    alive[k] = 0; deg[m]--; deg[other]--; processed++; layer[k] = 0;
-  }
-  int currentLayer = 1;
-  while (processed != C) {
+};
+
+// Simulation::contactSorting (Simulation.cpp:422-624), the frontier propagation: everything that is order independent
+// (vertex table, adjacency, the lonely pairs of layer 0) has been built by the whole workgroup (self_detect_rollout);
+// what is left here, on ONE thread exactly as the reference's std::map / std::set code does it, is the greedy walk over
+// the `nact` vertices that still have contacts (act[] ascending = std::map iteration order). Returns maxLayer.
+__device__ int contact_layering_rest(const SelfTmp &t, int nact, int remaining) {
+  int maxLayer = 0, nfront = 0, currentLayer = 1;
+  for (int q = 0; q < nact; q++) nfront += t.frontier[t.act[q]];
+  while (remaining > 0) {
     while (nfront > 0) {
-      for (int m = 0; m < M; m++) { newf[m] = 0; involved[m] = 0; }
+      for (int q = 0; q < nact; q++) { const int m = t.act[q]; t.newf[m] = 0; t.involved[m] = 0; }
       int nnew = 0;
       if (currentLayer > maxLayer) maxLayer = currentLayer;
-      for (int m = 0; m < M; m++) {
-        if (!frontier[m]) continue;
-        if (deg[m] == 0) continue;
-        if (involved[m]) continue;
-        for (int o = adj_ptr[m]; o < adj_ptr[m + 1]; o++) {
-          int k = adj_contact[o];
-          if (!alive[k]) continue;
-          int other = adj_other[o];
-          if (involved[other]) continue;
-          alive[k] = 0; deg[m]--; deg[other]--; processed++;
-          involved[m] = 1; involved[other] = 1;
-          layer[k] = currentLayer;
-          if (deg[other] > 0 && !newf[other]) { newf[other] = 1; nnew++; }
+      for (int q = 0; q < nact; q++) {
+        const int m = t.act[q];
+        if (!t.frontier[m]) continue;
+        if (t.deg[m] == 0) continue;
+        if (t.involved[m]) continue;
+        for (int o = t.adj_ptr[m]; o < t.adj_ptr[m + 1]; o++) {
+          const int k = t.adj_contact[o];
+          if (!t.alive[k]) continue;
+          const int other = t.adj_other[o];
+          if (t.involved[other]) continue;
+          t.alive[k] = 0; t.deg[m]--; t.deg[other]--; remaining--;
+          t.involved[m] = 1; t.involved[other] = 1;
+          t.layer[k] = currentLayer;
+          if (t.deg[other] > 0 && !t.newf[other]) { t.newf[other] = 1; nnew++; }
           break;
         }
       }
       currentLayer++;
-      for (int m = 0; m < M; m++) frontier[m] = newf[m];
+      for (int q = 0; q < nact; q++) { const int m = t.act[q]; t.frontier[m] = t.newf[m]; }
       nfront = nnew;
     }
-    if (processed != C) {
+    if (remaining > 0) {
       int pick = -1;
-      for (int m = 0; m < M; m++) if (deg[m] == 1) { pick = m; break; }      // prioritise a chain head
-      if (pick < 0) for (int m = 0; m < M; m++) if (deg[m] > 0) { pick = m; break; }   // a loop
+      for (int q = 0; q < nact; q++) if (t.deg[t.act[q]] == 1) { pick = t.act[q]; break; }      // prioritise a chain head
+      if (pick < 0) for (int q = 0; q < nact; q++) if (t.deg[t.act[q]] > 0) { pick = t.act[q]; break; }   // a loop
       if (pick < 0) break;
-      frontier[pick] = 1; nfront = 1;
+      t.frontier[pick] = 1; nfront = 1;
     }
   }
-  int nlayers = maxLayer + 1;
-  if (nlayers > kMaxLayers) nlayers = kMaxLayers;        // overflow layers are merged into the last one
-  meta[0] = C; meta[1] = nlayers;
-  for (int l = 0; l <= nlayers; l++) meta[2 + l] = 0;
-  for (int k = 0; k < C; k++) { int l = min(layer[k] < 0 ? 0 : layer[k], nlayers - 1); layer[k] = l; meta[2 + l + 1]++; }
-  for (int l = 0; l < nlayers; l++) meta[2 + l + 1] += meta[2 + l];
-  for (int k = 0; k < C; k++) layer_out[k] = layer[k];
+  return maxLayer;
 }
 
 
 // Detection + layering of one rollout for the step that reads (xn, vn); `lds` = kSelfDetectLdsInts ints of LDS scratch.
 // rec_prim / self / fu are the step's record pointers of the whole batch (indexed by b inside). Call with all threads.
-constexpr int kSelfCells = 4096;               // bins of the 2-D broad-phase grid
-constexpr int kSelfDetectLdsInts = 16 + (kSelfCells + 1) + kSelfCells + 1 + 2048;
 template <int THREADS>
 __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const DevWork &W, int b, const float *x_in, const float *v_in,
                                                     int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, const float *fv_all, int *lds) {
@@ -156,7 +147,7 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
   float *sx = W.sd_sx + off;
   int2 *raw = W.sd_rawpair + (size_t) b * cap;
   float4 *rawn = W.sd_rawn + (size_t) b * cap;
-  int *tmp = W.sd_tmp + (size_t) b * 24 * cap;
+  int *tmp = W.sd_tmp + (size_t) b * self_tmp_ints(cap);
   int2 *opair = selfrec.pair + (size_t) b * cap;
   float4 *onrm = selfrec.nrm + (size_t) b * cap;
   int *meta = selfrec.meta + (size_t) b * kMetaStride;
@@ -172,7 +163,7 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
   };
 
   if (!S.contact_enabled || !S.self_enabled) {
-    if (tid == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; meta[kMetaStride - 1] = 0; }
+    if (tid == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; meta[kMetaStride - 1] = 0; meta[kMetaStride - 2] = 0; meta[kMetaStride - 3] = 0; }
     return;
   }
   // ---- 1. bounding box / longest axis / cells (Simulation.cpp:283-300) ----
@@ -277,11 +268,11 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
     }
   }
   __syncthreads();
-  const int C = min(s_count, cap);
+  const int raw_count = s_count;
+  const int C = min(raw_count, cap);
   // ---- 4. deterministic order: rank sort by key id1 * N + id2 ----
-  // tmp (24*cap ints): [0, 18cap+1) serial layering structures | [19cap, 20cap) layer of each sorted contact |
-  //                     [20cap, 22cap) pairs in sorted order
-  int2 *spair = (int2 *) (tmp + 20 * cap);
+  const SelfTmp t(tmp, cap);
+  int2 *spair = t.spair;
   if (C <= 2048) {
     for (int k = tid; k < C; k += THREADS) s_keys[k] = (unsigned) raw[k].x * (unsigned) N + (unsigned) raw[k].y;
     __syncthreads();
@@ -302,37 +293,122 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
     }
   }
   __syncthreads();
-  // ---- 5. layering (serial, thread 0) then a stable partition by layer ----
-  int *layer_of = tmp + 19 * cap;
-  if (tid == 0) contact_sorting_serial(C, spair, rec_prim_all + (size_t) b * N, dev_of, tmp, cap, meta, layer_of);
+  // ---- 5. layering (Simulation::contactSorting, Simulation.cpp:422-624) ----
+  // 5a. vertex table: local id of a vertex = its rank among the distinct vertices of the contacts (std::map order);
+  //     lid[] lives in the cell-sort scratch `order` (free since step 3), indexed by the caller's vertex id
+  int *lid = order;
+  for (int i = tid; i < N; i += THREADS) lid[i] = 0;
   __syncthreads();
-  // position inside the layer = number of earlier (sorted) contacts of the same layer
+  int bad = 0;                                   // internal consistency (never expected): reported through the overflow flags, bit 2
   for (int k = tid; k < C; k += THREADS) {
-    const int l = layer_of[k];
+    const int2 ab = spair[k];
+    if ((unsigned) ab.x >= (unsigned) N || (unsigned) ab.y >= (unsigned) N) { bad = 1; spair[k] = make_int2(0, 0); }
+  }
+  __syncthreads();
+  for (int k = tid; k < C; k += THREADS) { lid[spair[k].x] = 1; lid[spair[k].y] = 1; }
+  const int M = block_scan_excl<THREADS>(lid, N, hist);
+  for (int k = tid; k < C; k += THREADS) { t.ids[lid[spair[k].x]] = spair[k].x; t.ids[lid[spair[k].y]] = spair[k].y; }
+  for (int m = tid; m <= M; m += THREADS) { t.deg[m] = 0; t.c2[m] = 0; }
+  __syncthreads();
+  // 5b. degrees, adjacency in the reference's order: the neighbours of q ascending = first the contacts where q is id2
+  //     (their id1 < q, ascending in the sorted list), then those where q is id1
+  for (int k = tid; k < C; k += THREADS) {
+    const int a = lid[spair[k].x], bb = lid[spair[k].y];
+    atomicAdd(&t.deg[a], 1); atomicAdd(&t.deg[bb], 1); atomicAdd(&t.c2[bb], 1);
+  }
+  __syncthreads();
+  for (int m = tid; m <= M; m += THREADS) t.adj_ptr[m] = (m < M) ? t.deg[m] : 0;
+  block_scan_excl<THREADS>(t.adj_ptr, M + 1, hist);
+  for (int k = tid; k < C; k += THREADS) {
+    const int2 ab = spair[k];
+    const int a = lid[ab.x], bb = lid[ab.y];
+    int r2 = 0;                                  // earlier contacts with the same id2
+    for (int q = 0; q < k; q++) r2 += (spair[q].y == ab.y) ? 1 : 0;
+    int r1 = 0;                                  // earlier contacts with the same id1 (contiguous in the sorted list)
+    while (k - r1 - 1 >= 0 && spair[k - r1 - 1].x == ab.x) r1++;
+    const int ob = t.adj_ptr[bb] + r2, oa = t.adj_ptr[a] + t.c2[a] + r1;
+    if ((unsigned) ob < (unsigned) (2 * C) && (unsigned) oa < (unsigned) (2 * C)) {
+      t.adj_other[ob] = a; t.adj_contact[ob] = k;
+      t.adj_other[oa] = bb; t.adj_contact[oa] = k;
+    } else bad = 1;
+    t.alive[k] = 1; t.layer[k] = -1;
+  }
+  // primitive contacts go into the first layer: they seed the frontier when they also have self contacts (:455-460)
+  for (int m = tid; m < M; m += THREADS) {
+    const int v = t.ids[m];
+    t.frontier[m] = (rec_prim_all[(size_t) b * N + (dev_of ? dev_of[v] : v)] >= 0 && t.deg[m] > 0) ? 1 : 0;
+    t.newf[m] = 0; t.involved[m] = 0;
+  }
+  __syncthreads();
+  // 5c. lonely pairs (O-O) -> layer 0 (:462-480): both ends have no other contact, so no two threads touch one vertex
+  int lonely = 0;
+  for (int k = tid; k < C; k += THREADS) {
+    const int a = lid[spair[k].x], bb = lid[spair[k].y];
+    if (t.deg[a] == 1 && t.deg[bb] == 1 && !t.frontier[a] && !t.frontier[bb]) {
+      t.alive[k] = 0; t.layer[k] = 0; t.deg[a] = 0; t.deg[bb] = 0; lonely++;
+    }
+  }
+  __syncthreads();
+  for (int m = tid; m <= M; m += THREADS) t.act[m] = (m < M && t.deg[m] > 0) ? 1 : 0;
+  const int nact = block_scan_excl<THREADS>(t.act, M + 1, hist);       // act[m] = position of m among the active vertices
+  {
+    // compaction in place is a race (act[] is read as positions and written as the list): go through newf-free scratch c2
+    for (int m = tid; m < M; m += THREADS) if (t.deg[m] > 0) t.c2[t.act[m]] = m;
+    __syncthreads();
+    for (int q = tid; q < nact; q += THREADS) t.act[q] = t.c2[q];
+  }
+  int nl_total = 0;
+  for (int k = tid; k < C; k += THREADS) nl_total += (t.alive[k]) ? 1 : 0;
+  (void) lonely;
+  __syncthreads();
+  if (tid == 0) { hist[16] = 0; hist[17] = 0; }  // remaining contacts: block sum through an LDS atomic
+  __syncthreads();
+  if (nl_total) atomicAdd(&hist[16], nl_total);
+  if (bad) atomicOr(&hist[17], 4);
+  __syncthreads();
+  const int remaining = hist[16];
+  // 5d. frontier propagation on one thread (the contacts that are not lonely pairs; typically a small fraction)
+  if (tid == 0) {
+    int maxLayer = 0;
+    if (remaining > 0) maxLayer = contact_layering_rest(t, nact, remaining);
+    int nlayers = maxLayer + 1, flags = ((raw_count > cap) ? 1 : 0) | hist[17];
+    if (nlayers > kMaxLayers) { nlayers = kMaxLayers; flags |= 2; }       // reported: dc_step_stats::self_overflow
+    meta[0] = C; meta[1] = nlayers;
+    meta[kMetaStride - 1] = M; meta[kMetaStride - 2] = flags; meta[kMetaStride - 3] = raw_count;
+  }
+  __syncthreads();
+  const int nlayers = meta[1];
+  for (int l = tid; l <= nlayers; l += THREADS) meta[2 + l] = 0;
+  __syncthreads();
+  for (int k = tid; k < C; k += THREADS) {
+    const int l = min(t.layer[k] < 0 ? 0 : t.layer[k], nlayers - 1);
+    t.layer[k] = l;
+    atomicAdd(&meta[2 + l + 1], 1);
+  }
+  __syncthreads();
+  if (tid == 0) for (int l = 0; l < nlayers; l++) meta[2 + l + 1] += meta[2 + l];
+  __syncthreads();
+  // stable partition by layer: position inside the layer = number of earlier (sorted) contacts of the same layer
+  for (int k = tid; k < C; k += THREADS) {
+    const int l = t.layer[k];
     int pos = 0;
-    for (int q = 0; q < k; q++) pos += (layer_of[q] == l) ? 1 : 0;
-    const int dst = meta[2 + l] + pos;
-    opair[dst] = dev_of ? make_int2(dev_of[spair[k].x], dev_of[spair[k].y]) : spair[k];   // stored in device numbering
-    rawn[dst] = onrm[k];                         // raw buffer reused as the destination of the normals
+    for (int q = 0; q < k; q++) pos += (t.layer[q] == l) ? 1 : 0;
+    const int dst = min(meta[2 + l] + pos, C - 1);
+    const int2 ab = spair[k];
+    opair[dst] = dev_of ? make_int2(dev_of[ab.x], dev_of[ab.y]) : ab;   // stored in device numbering
+    // ---- 6. working set of the layered friction passes: the distinct vertices of the contacts are slots 0..M-1 (their
+    // rank, 5a) so that those passes can run inside LDS; slots ride in nrm.w, the vertex list in selfrec.verts
+    float4 nq = onrm[k];
+    nq.w = __int_as_float(lid[ab.x] | (lid[ab.y] << 16));
+    rawn[dst] = nq;                              // raw buffer reused as the destination of the normals
+  }
+  {
+    int *verts = selfrec.verts + (size_t) b * 2 * cap;
+    for (int m = tid; m < M; m += THREADS) { const int v = t.ids[m]; verts[m] = dev_of ? dev_of[v] : v; }
   }
   __syncthreads();
   for (int k = tid; k < C; k += THREADS) onrm[k] = rawn[k];
   __syncthreads();
-  // ---- 6. working set of the layered friction passes: the distinct vertices of the contacts get slots 0..M-1 (in order
-  // of first appearance) so that those passes can run inside LDS; slots ride in nrm.w, the vertex list in selfrec.verts
-  if (tid == 0) {
-    int *slot_of = cell;                       // [N] scratch of the detection, free again
-    int *verts = selfrec.verts + (size_t) b * 2 * cap;
-    for (int k = 0; k < C; k++) { slot_of[opair[k].x] = -1; slot_of[opair[k].y] = -1; }
-    int M = 0;
-    for (int k = 0; k < C; k++) {
-      const int2 ab = opair[k];
-      if (slot_of[ab.x] < 0) { slot_of[ab.x] = M; verts[M++] = ab.x; }
-      if (slot_of[ab.y] < 0) { slot_of[ab.y] = M; verts[M++] = ab.y; }
-      onrm[k].w = __int_as_float(slot_of[ab.x] | (slot_of[ab.y] << 16));
-    }
-    meta[kMetaStride - 1] = M;
-  }
 }
 
 

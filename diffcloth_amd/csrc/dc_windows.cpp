@@ -96,6 +96,26 @@ bool HostWindows::build(const HostSystem &H, size_t lds_budget) {
     Plan p = plan_for(H, rounded, emin, emax);
     best = p; best_own = rounded;
   }
+  return build_own(H, best_own);
+}
+
+bool HostWindows::build_own(const HostSystem &H, int own_size) {
+  *this = HostWindows();
+  const int N = H.N, T = H.T, E = H.E;
+  if (N <= 0 || T <= 0 || own_size <= 0 || own_size % 64 != 0) return false;
+  std::vector<int> emin(T + E), emax(T + E);
+  for (int t = 0; t < T; t++) {
+    emin[t] = std::min({H.tri[3 * t], H.tri[3 * t + 1], H.tri[3 * t + 2]});
+    emax[t] = std::max({H.tri[3 * t], H.tri[3 * t + 1], H.tri[3 * t + 2]});
+  }
+  for (int e = 0; e < E; e++) {
+    const int *q = &H.bend_v[4 * e];
+    emin[T + e] = std::min({q[0], q[1], q[2], q[3]});
+    emax[T + e] = std::max({q[0], q[1], q[2], q[3]});
+  }
+  const Plan best = plan_for(H, own_size, emin, emax);
+  if (best.vcap > 65535 || best.nrcap > 65535) return false;
+  const int best_own = own_size;
   own = best_own; nwin = best.nwin; vcap = best.vcap; nrcap = best.nrcap;
   lds_bytes = sizeof(float) * ((size_t) 6 * vcap + (size_t) 3 * nrcap);
 

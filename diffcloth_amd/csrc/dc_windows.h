@@ -38,6 +38,8 @@ struct HostWindows {
   std::vector<int> inc_ptr, inc_n;
 
   bool build(const HostSystem &H, size_t lds_budget);
+  // the same tables for a given window size (`own_size` owned vertices per window, a multiple of 64); no LDS check
+  bool build_own(const HostSystem &H, int own_size);
 };
 
 }  // namespace dc

@@ -11,7 +11,8 @@ struct WinLds {
   float *a1z, *a2z, *erz;       // z planes
 };
 
-__device__ __forceinline__ WinLds win_lds(const DevSystem &S, float *lds) {
+template <class TB>
+__device__ __forceinline__ WinLds win_lds(const TB &S, float *lds) {
   const int vc = S.win_vcap, nr = S.win_nrcap;
   WinLds L;
   L.a1xy = (float2 *) lds; L.a2xy = (float2 *) (lds + 2 * vc); L.erxy = (float2 *) (lds + 4 * vc);
@@ -28,12 +29,20 @@ __device__ __forceinline__ void stw(float2 *xy, float *z, int j, f3 v) { xy[j] =
 // input 2 (b) at the element's vertices; vert_op(i, sum, a_i) receives sum_corners coef * result and input 1 at the
 // vertex, for every vertex exactly once. Call with all threads; starts with a barrier (LDS may still be in use by the
 // caller) and ends WITHOUT one.
-template <int THREADS, class Stage1, class TriOp, class BendOp, class VertOp>
-__device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, Stage1 stage1,
-                                                const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
-  const int N = S.N, tid = threadIdx.x, lane = tid & 63;
+// TB = the table set (DevSystem's own windows, or the DevCluster tables of the split kernels: same member names); the windows
+// [w0, w1) are processed; in2(i) returns input 2 at vertex i (In2Plain: a planar [3][N] vector in global memory; the split
+// kernels read vectors other workgroups write through In2Sc1, dc_cluster.h).
+struct In2Plain {
+  const float *__restrict__ v;
+  int N;
+  __device__ __forceinline__ f3 operator()(int i) const { return mk(v[i], v[N + i], v[2 * N + i]); }
+};
+template <int THREADS, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
+__device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, float *lds, Stage1 stage1,
+                                                  In2 in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const WinLds L = win_lds(S, lds);
-  for (int w = 0; w < S.nwin; w++) {
+  for (int w = w0; w < w1; w++) {
     const int4 d0 = S.win[2 * w], d1 = S.win[2 * w + 1];
     const int v0 = d0.x, v1 = d0.y, lo = d0.z, vs = d0.w, toff = d1.x, nt = d1.y, boff = d1.z, nb = d1.w;
     __syncthreads();
@@ -42,12 +51,11 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
       const int jb = j0 + THREADS;
       const bool vb = jb < vs;
       const int ia = lo + j0, ib = lo + (vb ? jb : j0);
-      const float2 qa = make_float2(in2[ia], in2[N + ia]), qb = make_float2(in2[ib], in2[N + ib]);
-      const float za = in2[2 * N + ia], zb = in2[2 * N + ib];
+      const f3 ua = in2(ia), ub = in2(ib);
       const f3 sa = stage1(ia), sb = stage1(ib);
-      L.a2xy[j0] = qa; L.a2z[j0] = za;
+      stw(L.a2xy, L.a2z, j0, ua);
       stw(L.a1xy, L.a1z, j0, sa);
-      if (vb) { L.a2xy[jb] = qb; L.a2z[jb] = zb; stw(L.a1xy, L.a1z, jb, sb); }
+      if (vb) { stw(L.a2xy, L.a2z, jb, ub); stw(L.a1xy, L.a1z, jb, sb); }
     }
     __syncthreads();
     // per-element phase: up to 4 elements of a thread at a time, their records loaded up front (clamped index, no
@@ -156,6 +164,12 @@ __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, 
       }
     }
   }
+}
+
+template <int THREADS, class Stage1, class TriOp, class BendOp, class VertOp>
+__device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, Stage1 stage1,
+                                                const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
+  element_windows_t<THREADS>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
 }
 
 // ---- forward local step: a = x_n, b = v (current iterate); x = x_n + h v, edges formed as differences first ----

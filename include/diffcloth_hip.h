@@ -24,7 +24,7 @@ extern "C" {
 
 typedef struct dc_ctx dc_ctx;
 
-enum { DC_OK = 0, DC_ERR_INVALID = 1, DC_ERR_HIP = 2, DC_ERR_STATE = 3, DC_ERR_TOPOLOGY = 4 };
+enum { DC_OK = 0, DC_ERR_INVALID = 1, DC_ERR_HIP = 2, DC_ERR_STATE = 3, DC_ERR_TOPOLOGY = 4, DC_ERR_CAPACITY = 5 };
 
 /* Primitive kinds (Primitive.h PrimitiveType; only the analytic isInContact family is on the hot path). */
 enum { DC_PRIM_SPHERE = 0, DC_PRIM_CAPSULE = 1, DC_PRIM_PLANE = 2, DC_PRIM_BOWL = 3 };
@@ -76,7 +76,8 @@ typedef struct dc_params {
    * block-Jacobi preconditioned BiCGSTAB on (P - dP^T) run to adjoint_rel_tol (relative residual; <=0: 1e-6). */
   int adjoint_mode;
   double adjoint_rel_tol;
-  int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: 2048 */
+  int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: sized from the mesh,
+                                       max(2048, N) pairs (at most 16000); overflow is reported, never silent: dc_step_stats */
 } dc_params;
 
 /* Per-rollout statistics of one forward step (ForwardInformation::converged/convergeIter). */
@@ -87,6 +88,10 @@ typedef struct dc_step_stats {
   int prim_contacts;
   int self_contacts;
   float last_xdiff;      /* |x_new - x_now|_2 / N of the final iteration */
+  int self_overflow;     /* 0: the self-contact list is complete (the reference has no limit, Simulation.cpp:281-352, 422-624);
+                            bit 0: more pairs than dc_params::max_self_contacts were found and the list was cut (the step's
+                            result is NOT the reference's: raise max_self_contacts and repeat the step); bit 1: more layers
+                            than the layer table holds (4088). Calls that return these statistics fail with DC_ERR_CAPACITY */
 } dc_step_stats;
 
 /* Per-rollout statistics of one backward step (BackwardInformation::converged/backwardIters). */
@@ -197,6 +202,12 @@ int dc_rollout_backward(dc_ctx *ctx, int slot, int nsteps);
 int dc_get_gradient(dc_ctx *ctx, double *dL_dx, double *dL_dv, double *dL_dmu /*B*num_groups or NULL*/);
 int dc_get_stats(dc_ctx *ctx, int slot, dc_step_stats *fwd /*B or NULL*/, dc_bwd_stats *bwd /*B or NULL*/);
 int dc_sync(dc_ctx *ctx);
+/* Split execution: with fewer rollouts than compute units (BASELINE C4 sharded over 8 GPUs: 32 per GPU; hatController.py: 20 rollouts)
+ * or a mesh too large for one workgroup's LDS, a rollout is run by K workgroups that own K contiguous vertex ranges and exchange
+ * boundary rows and partial sums inside the launch (csrc/dc_cluster.h). K is chosen in dc_alloc_batch from the batch size, the mesh
+ * and the device (environment DC_CLUSTER=k forces k; 0 or 1 = one workgroup per rollout). Results agree with the one-workgroup
+ * kernels to solver tolerance (different summation order), not bitwise. Reports K and how many rollouts one launch covers. */
+int dc_get_cluster(const dc_ctx *ctx, int *workgroups_per_rollout, int *rollouts_per_launch);
 /* HIP-event timing of everything enqueued between the two calls on the context's stream (ms). */
 int dc_timer_start(dc_ctx *ctx);
 int dc_timer_stop(dc_ctx *ctx, float *ms);

@@ -76,3 +76,18 @@ def sphere_scene_center(verts, radius=2.0):
     center_low[1] = mn[1]
     plane_center = center_low - np.array([0, radius * 2 + 0.1, 0])
     return plane_center + np.array([radius * 0.3, radius, radius * 0.1])
+
+
+def fold_flap(verts, nx, ny, rows, gap):
+    """Folds the last `rows` grid rows of a grid_cloth() mesh back over the cloth: row i_f + d (i_f = ny - 1 - rows)
+    is laid exactly above row i_f - d, `gap` higher — a flap resting on the cloth, every flap vertex within contact
+    distance of the vertex below it when gap < r_a + r_b (Simulation.cpp:194-220, radii :2407-2431). Returns the folded
+    positions and the boolean flap mask."""
+    V = np.array(verts, dtype=np.float64).reshape(ny, nx, 3).copy()
+    i_f = ny - 1 - rows
+    assert rows >= 1 and i_f - rows >= 0
+    flap = np.zeros((ny, nx), dtype=bool)
+    for d in range(1, rows + 1):
+        V[i_f + d] = V[i_f - d] + np.array([0.0, gap, 0.0])
+        flap[i_f + d] = True
+    return V.reshape(-1, 3), flap.reshape(-1)

@@ -1,0 +1,152 @@
+"""Parity gate AT THE CONFIGURATION bench.py MEASURES: the C4 workload (100 x 100 grid, N = 10 000, 256 rollouts, flap folded
+back so that every step carries ~500 loaded self contacts), bench.py's own solver settings (forward_tol 1e-8, cg_rel_tol 1e-4,
+adjoint_mode 1 with adjoint_rel_tol 1e-6, gradient clipping on, self-collision on) and its own code path (dc_rollout_forward /
+dc_seed_gradient / dc_rollout_backward). Eight sampled rollouts over three consecutive time steps are compared, teacher-forced
+(each step from the GPU's own previous state / carried gradient), against the fp64 oracle run with the direct adjoint solve:
+positions <= 4.5e-5 (1e-5 L), gradients <= 1e-4 relative — BASELINE.json's stated tolerance.
+
+Plus the capacity case of VERDICT r01 #7: a 17k-vertex grid with a fold of more than 2048 contacts, pair set and layers
+identical to Simulation::collisionDetection / contactSorting (Simulation.cpp:281-352, 422-624) as restated by the oracle.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench                      # noqa: E402  (the workload definition under test is bench.py's)
+import meshes                     # noqa: E402
+import orc                        # noqa: E402
+from diffcloth_amd import capi    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def bench_args(**over):
+    """bench.py's defaults, without touching sys.argv."""
+    d = dict(grid=100, fold_rows=5, fold_gap=0.02, flap_force=2.0, h=1.0 / 180, fwd_tol=1e-8, bwd_tol=5e-4, cg_tol=1e-4, cg_max=500,
+             adjoint_mode=1, adjoint_rel_tol=1e-6, selfcollision=1, warmup=5, cpu_threads=0)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+@pytest.mark.parametrize("cluster", [None])
+def test_bench_configuration_matches_oracle(cluster):
+    args = bench_args()
+    B, W, S = 256, 5, 3
+    sample = (0, 37, 64, 101, 128, 170, 201, 255)
+    if cluster is not None:
+        os.environ["DC_CLUSTER"] = str(cluster)
+    V, F, V0, flap, center = bench.scene(args)
+    e = bench.make_engine(0, args, V, F, center)
+    assert e.N == 10000
+    e.alloc_batch(B, W + S)
+    X0, MU = bench.rollout_inputs(V0, np.arange(B))
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    field = bench.flap_force(args, e.vertex_data()[0], flap)
+    e.set_vertex_forces(np.tile(field, (B, 1)))
+    e.rollout_forward(0, W)
+    e.rollout_forward(W, S)                                   # the timed path of bench.py: all steps of a rollout in one launch
+    states = [e.get_state(W + s) for s in range(S + 1)]
+    gscale = 2.0 / ((S + 1) * e.N)
+    e.seed_gradient(W + S, None, gscale)
+    carried = [e.get_gradient()[:2]]
+    for s in range(S):
+        e.rollout_backward(W + S - s, 1)
+        carried.append(e.get_gradient()[:2])
+    stats = [e.get_stats(W + s + 1) for s in range(S)]
+    for s in range(S):
+        fs, bs = stats[s]
+        assert np.all(fs["converged"] == 1) and np.all(np.isin(bs["converged"], (1, 2)))
+        assert fs["self_contacts"].min() >= 100 * args.fold_rows - 60, "the flap must rest on the cloth in every rollout"
+    threads = min(os.cpu_count() or 1, 32)
+    o = orc.Oracle(V, F, h=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, fwd_tol=args.fwd_tol, bwd_tol=args.bwd_tol,
+                   selfcollision=True, gradient_clipping=True, threads=threads)
+    o.add_sphere(center, 2.0, 0.9)
+    o.build()
+    o.set_force_extras(None, field, 1.0)
+    worst_x = worst_g = 0.0
+    for b in sample:
+        o.set_mu(0, float(f32(MU[b, 0])))
+        o.clear_records()
+        for s in range(S):
+            xs, vs = states[s]
+            ref = o.step(xs[b], vs[b])
+            fs, bs = stats[s]
+            assert ref["converged"]
+            assert fs["prim_contacts"][b] == ref["nprim"] and fs["self_contacts"][b] == ref["nself"], (b, s, fs["prim_contacts"][b], ref["nprim"], fs["self_contacts"][b], ref["nself"])
+            dx = np.abs(states[s + 1][0][b] - ref["x"]).max()
+            gin, gout = carried[S - 1 - s], carried[S - s]
+            rb = o.step_backward(ref["id"], gin[0][b], gin[1][b], is_start=False, direct=True)
+            ex, ev = rel(gout[0][b], rb["dL_dx"]), rel(gout[1][b], rb["dL_dv"])
+            print(f"\n[bench parity] rollout {b} step {W + s}: contacts prim {ref['nprim']} self {ref['nself']} ({ref['nlayers']} layers), PD iterations gpu "
+                  f"{fs['pd_iters'][b]} / oracle {ref['iters']}, BiCGSTAB {bs['adjoint_iters'][b]}, max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
+            worst_x, worst_g = max(worst_x, dx), max(worst_g, ex, ev)
+            assert dx <= 4.5e-5
+            assert ex <= 1e-4 and ev <= 1e-4
+    print(f"\n[bench parity] worst over {len(sample)} rollouts x {S} steps: max|dx| {worst_x:.2e}, gradient rel err {worst_g:.2e}")
+
+
+def test_fold_with_more_than_2048_self_contacts_matches_contactSorting():
+    """132 x 132 grid (17 424 vertices), a flap of 24 rows folded back: ~3 170 contacts, more than the old fixed list size. The
+    pair set, the layer of every pair and the count must be the oracle's; nothing is cut, nothing is flagged."""
+    nx = 132
+    V, F = meshes.grid_cloth(nx, nx, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    c = f32(meshes.sphere_scene_center(V, 2.0))
+    V0, flap = meshes.fold_flap(V, nx, nx, 24, 0.012)
+    x0 = f32(V0.reshape(-1)); v0 = np.zeros_like(x0)
+    kw = dict(h=1 / 180, density=0.3, k_stretch=150.0, k_bend=1e-5)
+    o = orc.Oracle(V, F, fwd_tol=1e-6, bwd_tol=1e-6, selfcollision=True, contact=True, gradient_clipping=False, pd_iter_cap=3,
+                   threads=min(os.cpu_count() or 1, 32), **kw)
+    o.add_sphere(c, 2.0, 0.5)
+    o.build()
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_params(time_step=kw["h"], density=kw["density"], k_stretch=kw["k_stretch"], k_bend=kw["k_bend"], forward_tol=1e-6,
+                 pd_iter_cap=3, selfcollision_enabled=1)
+    e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=c, radius=2.0, mu=0.5)])
+    e.build()
+    e.alloc_batch(2, 1)
+    e.set_state(0, np.stack([x0, x0]), np.stack([v0, v0]))
+    st = e.step_forward(0)
+    ref = o.step(x0, v0)
+    assert ref["nself"] > 2048
+    got = e.get_self_contacts(1, rollout=1, cap=8192)
+    assert st["self_overflow"].max() == 0
+    assert st["self_contacts"][1] == ref["nself"] == got["count"] and got["layers"] == ref["nlayers"]
+    sc = o.self_contacts(ref["id"])
+    want = sorted((int(l), int(a), int(b)) for l, a, b in zip(sc["layer"], sc["p1"], sc["p2"]))
+    have = sorted((int(l), int(a), int(b)) for l, (a, b) in zip(got["layer"], got["pairs"]))
+    assert have == want
+
+
+def test_self_contact_overflow_is_reported_not_silent():
+    """With a list capacity below the number of pairs the step must fail loudly (DC_ERR_CAPACITY), never cut silently."""
+    nx = 40
+    V, F = meshes.grid_cloth(nx, nx, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    V0, flap = meshes.fold_flap(V, nx, nx, 8, 0.03)
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_params(time_step=1 / 180, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_tol=1e-6, pd_iter_cap=2, selfcollision_enabled=1,
+                 max_self_contacts=100)
+    e.build()
+    e.alloc_batch(1, 1)
+    x0 = f32(V0.reshape(-1))
+    e.set_state(0, x0, np.zeros_like(x0))
+    with pytest.raises(capi.DcError, match="self-contact list overflow"):
+        e.step_forward(0)

@@ -1,0 +1,178 @@
+"""GPU parity of the SPLIT kernels (csrc/dc_cluster.h, dc_forward_cl.hip, dc_adjoint_cl.hip): one rollout run by K workgroups
+that own K contiguous vertex ranges and exchange boundary rows / partial sums inside the launch. Same gates as the one-workgroup
+kernels — positions <= 1e-5 L, gradients <= 1e-4 relative against the fp64 oracle (Simulation::step / stepBackward,
+Simulation.cpp:1043-1428, 1455-1780) — for every K, with primitive contacts, with self contacts (whose layered passes run on part 0
+between fence barriers), for fused multi-step launches, and for a mesh beyond the one-workgroup kernels' size limit."""
+import os
+
+import numpy as np
+import pytest
+
+import meshes
+import orc
+from diffcloth_amd import capi
+
+pytestmark = pytest.mark.gpu
+H = 1.0 / 180
+FABRIC = dict(density=0.3, k_stretch=150.0, k_bend=1e-5)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+class cluster_env:
+    def __init__(self, k):
+        self.k = k
+
+    def __enter__(self):
+        self.old = os.environ.get("DC_CLUSTER")
+        os.environ["DC_CLUSTER"] = str(self.k)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("DC_CLUSTER", None)
+        else:
+            os.environ["DC_CLUSTER"] = self.old
+
+
+def sphere_scene(nx, selfcollision=False, fwd_tol=1e-8, k_bend=1e-5):
+    V, F = meshes.grid_cloth(nx, nx, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    c = f32(meshes.sphere_scene_center(V, 2.0))
+    fab = dict(FABRIC, k_bend=k_bend)
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_params(time_step=H, forward_tol=fwd_tol, backward_tol=1e-9, cg_rel_tol=1e-6, cg_max_iter=3000, gradient_clipping=0,
+                 selfcollision_enabled=int(selfcollision), adjoint_mode=1, adjoint_rel_tol=1e-8, **fab)
+    e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=c, radius=2.0, mu=0.9)])
+    e.build()
+    o = orc.Oracle(V, F, h=H, fwd_tol=fwd_tol, bwd_tol=1e-9, selfcollision=bool(selfcollision), gradient_clipping=False,
+                   threads=min(os.cpu_count() or 1, 32), **fab)
+    o.add_sphere(c, 2.0, 0.9)
+    o.build()
+    return V, F, e, o
+
+
+def starts(V, B):
+    X = np.empty((B, V.size)); MU = np.empty((B, 1))
+    for b in range(B):
+        rng = np.random.default_rng(2000 + b)
+        shift = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.09, -0.03), rng.uniform(-0.4, 0.4)])
+        X[b] = f32((V + shift).reshape(-1)); MU[b, 0] = rng.uniform(0.1, 0.9)
+    return X, f32(MU)
+
+
+def check_step(o, e, slot, MU, gx, gv, st, gb, rollouts, tag):
+    xs, vs = e.get_state(slot)
+    x1, v1 = e.get_state(slot + 1)
+    for b in rollouts:
+        o.set_mu(0, float(MU[b, 0]))
+        ref = o.step(xs[b], vs[b])
+        assert ref["converged"] and st["converged"][b] == 1
+        assert st["prim_contacts"][b] == ref["nprim"] and st["self_contacts"][b] == ref["nself"]
+        rb = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
+        dx = np.abs(x1[b] - ref["x"]).max()
+        ex, ev = rel(gb["dL_dx"][b], rb["dL_dx"]), rel(gb["dL_dv"][b], rb["dL_dv"])
+        print(f"\n[{tag}] rollout {b}: contacts {ref['nprim']}/{ref['nself']}, PD gpu {st['pd_iters'][b]} / oracle {ref['iters']}, BiCGSTAB "
+              f"{gb['adjoint_iters'][b]}, max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
+        assert dx <= 4.5e-5
+        assert ex <= 1e-4 and ev <= 1e-4
+
+
+@pytest.mark.parametrize("K", [2, 4, 8])
+def test_split_kernels_match_oracle(K):
+    B, W = 3, 4
+    V, F, e, o = sphere_scene(48)
+    X0, MU = starts(V, B)
+    with cluster_env(K):
+        e.alloc_batch(B, W + 1)
+    assert e.cluster() == K
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    e.rollout_forward(0, W)                      # all steps of a rollout in one launch of K workgroups
+    st = e.step_forward(W)
+    assert st["prim_contacts"].min() > 0
+    rng = np.random.default_rng(21)
+    gx = f32(rng.standard_normal(X0.shape)); gv = f32(0.01 * rng.standard_normal(X0.shape))
+    gb = e.step_backward(W + 1, gx, gv, is_start=False)
+    assert np.all(gb["converged"] == 1)
+    check_step(o, e, W, MU, gx, gv, st, gb, range(B), f"split K={K}")
+
+
+def test_split_agrees_with_one_workgroup_per_rollout():
+    """Same inputs through K = 1 and K = 4: different summation order, same answer to solver tolerance; parameter gradients too."""
+    B, S = 4, 3
+    V, F, e1, o = sphere_scene(48)
+    _, _, e4, _ = sphere_scene(48)
+    X0, MU = starts(V, B)
+    with cluster_env(1):
+        e1.alloc_batch(B, S)
+    with cluster_env(4):
+        e4.alloc_batch(B, S)
+    assert e1.cluster() == 1 and e4.cluster() == 4
+    outs = []
+    for e in (e1, e4):
+        e.set_mu(MU)
+        e.set_state(0, X0, np.zeros_like(X0))
+        e.rollout_forward(0, S)
+        e.seed_gradient(S, None, 1e-3)
+        e.rollout_backward(S, S)
+        x, v = e.get_state(S)
+        dx, dv, dmu = e.get_gradient()
+        pg = e.get_param_gradients(S)
+        outs.append((x, v, dx, dv, dmu, pg))
+    a, b = outs
+    assert np.abs(a[0] - b[0]).max() <= 2e-5
+    assert rel(b[2], a[2]) <= 5e-5 and rel(b[3], a[3]) <= 5e-5
+    np.testing.assert_allclose(b[4], a[4], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(b[5]["dL_dk"], a[5]["dL_dk"], rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(b[5]["dL_ddensity"], a[5]["dL_ddensity"], rtol=2e-3, atol=1e-9)
+    np.testing.assert_allclose(b[5]["sum_dfext"], a[5]["sum_dfext"], rtol=2e-3, atol=1e-9)
+
+
+def test_split_kernels_with_self_contacts():
+    """A folded flap pressed onto the cloth: detection + layering and the layered friction passes run on part 0."""
+    nx, B = 40, 2
+    V, F, e, o = sphere_scene(nx, selfcollision=True)
+    V0, flap = meshes.fold_flap(V, nx, nx, 6, 0.05)
+    X0, MU = starts(f32(V0), B)
+    field = np.zeros((V.shape[0], 3))
+    with cluster_env(4):
+        e.alloc_batch(B, 4)
+    assert e.cluster() == 4
+    mass = e.vertex_data()[0]
+    field[flap, 1] = -2.0 * 9.8 * mass[flap]
+    field = f32(field.reshape(-1))
+    e.set_vertex_forces(np.tile(field, (B, 1)))
+    o.set_force_extras(None, field, 1.0)
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    e.rollout_forward(0, 3)                      # fused: detection inlined on part 0
+    st = e.step_forward(3)                       # per-step: stand-alone detection kernel, then the split step kernel
+    assert st["self_contacts"].min() > 100
+    rng = np.random.default_rng(22)
+    gx = f32(rng.standard_normal(X0.shape)); gv = f32(0.01 * rng.standard_normal(X0.shape))
+    gb = e.step_backward(4, gx, gv, is_start=False)
+    check_step(o, e, 3, MU, gx, gv, st, gb, range(B), "split K=4 self contacts")
+
+
+def test_split_lifts_the_mesh_size_limit():
+    """128 x 128 grid (N = 16 384 > 10 240): too large for one workgroup's LDS; split over K workgroups it stays resident."""
+    B, W = 2, 3
+    V, F, e, o = sphere_scene(128)
+    X0, MU = starts(V, B)
+    e.alloc_batch(B, W + 1)
+    assert e.cluster() >= 3
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    e.rollout_forward(0, W)
+    st = e.step_forward(W)
+    rng = np.random.default_rng(23)
+    gx = f32(rng.standard_normal(X0.shape)); gv = f32(0.01 * rng.standard_normal(X0.shape))
+    gb = e.step_backward(W + 1, gx, gv, is_start=False)
+    check_step(o, e, W, MU, gx, gv, st, gb, (1,), f"split K={e.cluster()} N=16384")

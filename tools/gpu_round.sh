@@ -1,0 +1,31 @@
+#!/bin/bash
+# Developer script: a sequence of independent GPU checks, each under its own timeout, logs under gpurun_out/$1/
+TAG=$1; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+run() { name=$1; shift; echo "=== $name: $*"; ( timeout 420 "$@" > $OUT/$name.log 2>&1; echo "rc=$?" >> $OUT/$name.log ); tail -${TAILN:-6} $OUT/$name.log | cut -c1-400; }
+for item in "$@"; do
+  case $item in
+    selfc) run selfc python -m pytest tests/test_gpu_selfcontact.py -x -q ;;
+    debug)
+      i=0
+      while read -r cl cfg; do
+        i=$((i+1)); export DC_CLUSTER=$cl; TAILN=7 run debug$i python tools/debug_fold.py $cfg; unset DC_CLUSTER
+      done <<'CFG'
+4 2 40 1 6 1
+4 2 40 0 6 1
+4 2 40 1 0 0
+2 2 40 1 6 1
+8 2 40 1 6 1
+4 8 40 1 6 1
+CFG
+      ;;
+    cluster) TAILN=30 run cluster python -m pytest tests/test_gpu_cluster.py -q -s ;;
+    parity) TAILN=40 run parity python -m pytest tests/test_gpu_bench_parity.py -q -s ;;
+    all) TAILN=15 run all python -m pytest tests -m gpu -q -x ;;
+    rest) TAILN=15 run rest python -m pytest tests -m gpu -q --deselect tests/test_gpu_bench_parity.py --deselect tests/test_gpu_cluster.py ;;
+    bench) TAILN=3 run bench python bench.py --steps 20 --warmup 5 ;;
+    bench32) TAILN=3 run bench32 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 ;;
+    bench32k1) TAILN=3 run bench32k1 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 1 ;;
+    *) echo "unknown item $item" ;;
+  esac
+done
