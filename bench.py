@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--cg-max", dest="cg_max", type=int, default=500)
     ap.add_argument("--adjoint-mode", dest="adjoint_mode", type=int, default=1,
                     help="1: direct adjoint solve (reference's solveDirect semantics); 0: reference fixed-point iteration")
-    ap.add_argument("--adjoint-rel-tol", dest="adjoint_rel_tol", type=float, default=1e-6)
+    ap.add_argument("--adjoint-rel-tol", dest="adjoint_rel_tol", type=float, default=2e-7)
     ap.add_argument("--selfcollision", type=int, default=1,
                     help="self-collision detection + layered self friction (the reference's default: selfcollisionEnabled = true); 0 = off")
     ap.add_argument("--cluster", type=int, default=-1, help="workgroups per rollout: -1 = engine's choice, 1 = one workgroup per rollout")

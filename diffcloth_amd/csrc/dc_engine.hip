@@ -230,7 +230,7 @@ int upload_cl(dc_ctx *c, const T **out, const std::vector<U> &src) {
 }
 
 // Tables for K parts per rollout; returns DC_OK with c->cl.ok = false when K does not fit this mesh (the caller tries K - 1).
-int build_cluster(dc_ctx *c, int K) {
+int build_cluster(dc_ctx *c, int K, bool forced) {
   free_cluster(c);
   const HostSystem &H = c->host;
   const int N = H.N;
@@ -245,6 +245,7 @@ int build_cluster(dc_ctx *c, int K) {
     const int Rc = own_w * w;
     if ((long long) (K - 1) * Rc >= N) break;           // a part would be empty
     if (Rc < HB) break;                                  // halo rows must come from the direct neighbours only
+    if (Rc < 512 && !forced) break;                      // fewer rows than threads: splitting further only adds exchanges
     int v = 0;
     for (int a : allowed) if (a * 512 >= Rc) { v = a; break; }
     if (v == 0) continue;                                // more rows per part than the kernel holds in registers: more windows do not help
@@ -320,7 +321,7 @@ int choose_cluster(dc_ctx *c) {
   if (!c->S.pk_ok || !c->S.win_ok) K = std::max(K, std::min(8, (c->host.N + 6143) / 6144));
   if (forced >= 2) K = std::min(forced, 8);
   for (; K >= 2; K--) {
-    int rc = build_cluster(c, K);
+    int rc = build_cluster(c, K, forced >= 2);
     if (rc) return rc;
     if (c->cl.ok) break;
   }

@@ -22,7 +22,7 @@ namespace dc {
 
 template <int THREADS, int VPT, bool DETECT>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
-                                                        FwdArgs A, int b0, int tail_off) {
+                                                        FwdArgs A, int b0, int tail_off, int fric_floats) {
   const DevSystem &S = *Sp;
   const DevCluster &CL = *Cp;
   constexpr int WAVES = THREADS / 64;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) on part 0 over the rollout's f / r, then the right-hand side again
       if (!xch_fence_barrier<THREADS>(X)) return;
       if (part == 0) {
-        if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, tail_off)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
+        if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
       }
       if (!xch_fence_barrier<THREADS>(X)) return;
       psum = 0.f;
@@ -342,13 +342,14 @@ static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const
   constexpr int THREADS = 512;
   const int GL = CL.R + 2 * CL.HB;
   int floats = std::max(3 * GL, CL.win_lds_bytes / 4);
+  const int fric_floats = floats;      // LDS offered to the layered friction pass: the same with and without the inlined detection
   if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
   const int tail_off = (floats + 3) / 4 * 4;
   const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
   if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, tail_off);
+  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, tail_off, fric_floats);
   return hipGetLastError();
 }
 

@@ -20,6 +20,11 @@ for item in "$@"; do
 CFG
       ;;
     cluster) TAILN=30 run cluster python -m pytest tests/test_gpu_cluster.py -q -s ;;
+    garment) TAILN=30 run garment python -m pytest tests/test_gpu_cluster.py -q -s -k garment ;;
+    pym) TAILN=30 run pym python -m pytest tests/test_gpu_pymodule.py -q -x ;;
+    pymk1) export DC_CLUSTER=1; TAILN=12 run pymk1 python -m pytest tests/test_gpu_pymodule.py -q -x -k "dress_twirl" -s; unset DC_CLUSTER ;;
+    pymdress) TAILN=12 run pymdress python -m pytest tests/test_gpu_pymodule.py -q -x -k "dress_twirl" -s ;;
+    fallb) TAILN=30 run fallb python -m pytest tests/test_gpu_fallbacks.py -q ;;
     parity) TAILN=40 run parity python -m pytest tests/test_gpu_bench_parity.py -q -s ;;
     all) TAILN=15 run all python -m pytest tests -m gpu -q -x ;;
     rest) TAILN=15 run rest python -m pytest tests -m gpu -q --deselect tests/test_gpu_bench_parity.py --deselect tests/test_gpu_cluster.py ;;
