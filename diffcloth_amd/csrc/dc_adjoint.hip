@@ -22,6 +22,8 @@
 
 namespace dc {
 
+constexpr int kCycles = 1;      // BiCGSTAB cycles of the direct adjoint solve (see the comment at the loop)
+
 #ifdef DC_PROFILE_PHASES
 #define PH_DECL long long ph_t = clock64(); long long ph_acc[4] = {0, 0, 0, 0};
 #define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
@@ -334,8 +336,16 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     used_direct = 1;
     constexpr int VB = 4;
     PH(0)
-    float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = gin;
+    float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = W.sd_sx + off;    // (detection scratch, idle in the backward pass)
     float d1, d2;
+    const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
+    const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
+    double rr = 0;
+    // kCycles > 1: when the recurrence residual says "converged", recompute g - K u and restart from u if that is not below the
+    // tolerance. Measured on the C4 workload (r02m): +4 iterations of 41, gradient error against the fp64 oracle unchanged to three
+    // digits (7.31e-5 -> 7.31e-5) — the fp32 floor of this solve is eps * cond(K) in the operator's coefficients, not residual
+    // drift — so one cycle is the default.
+    for (int cycle = 0, kdone = 0; cycle < kCycles; cycle++) {
     adjoint_operator<THREADS, WIN>(S, C, u, false, v, nullptr, d1, d2);
     __syncthreads();            // (as above; inside the loop the block reductions that follow every application do this)
     part = 0.f;
@@ -345,13 +355,13 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       part += dot(q, q);
     }
     double rho = block_sum<THREADS>((double) part, red);   // rhat.r = r.r
-    double rr = rho;
-    const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
+    rr = rho;
     double best_rr = rr;
     int since_progress = 0;
     status = (rr <= stop) ? 1 : 0;
-    const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
-    for (int k = 0; k < kcap && status == 0; k++) {
+    if (status == 0 && cycle > 0 && cycle == kCycles - 1) status = 2;      // still above the tolerance after two restarts: the fp32 floor of this system
+    if (status != 0) break;
+    for (int k = kdone; k < kcap && status == 0; k++, kdone++) {
       // v = K D^-1 p ;  alpha = rho / (rhat . v)
       PH(2)
       adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
@@ -431,7 +441,10 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       }
       __syncthreads();
     }
-    udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual
+    if (status != 1) break;       // cap, breakdown or stall: no further cycle
+    __syncthreads();
+    }   // cycle
+    udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual (of the last recomputed or recurrence residual)
   }
   __syncthreads();
   PH(2)

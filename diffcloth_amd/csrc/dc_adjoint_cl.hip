@@ -17,6 +17,8 @@
 
 namespace dc {
 
+constexpr int kCycles = 1;      // BiCGSTAB cycles of the direct adjoint solve (see the comment at the loop)
+
 namespace {
 
 struct AdjCl {
@@ -74,11 +76,11 @@ __device__ __forceinline__ bool adjoint_operator_cl(const DevSystem &S, const De
       if (precond) z = z * S.dinv[i];
       st3c(C.yb, i, z);
     }
-    if (!xch_fence_barrier<THREADS>(X)) return false;
+    if (!xch_barrier<THREADS>(X)) return false;
     if (C.part == 0) {
       if (!self_JT_layers_lds_v<THREADS>(S, C.self, C.b, C.yb, C.lds, C.lds_floats)) self_JT_layers_v<THREADS>(S, C.self, C.b, C.yb);
     }
-    if (!xch_fence_barrier<THREADS>(X)) return false;
+    if (!xch_barrier<THREADS>(X)) return false;
     element_windows_t<THREADS>(CL, C.w0, C.w1, C.lds, [&](int i) {
       f3 z = ld3c(C.yb, i);
       return z + contact_JT_cl(S, C, i, z);
@@ -107,13 +109,13 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   const DevCluster &CL = *Cp;
   constexpr int HPT = (1024 + THREADS - 1) / THREADS;
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
-  __shared__ double red[2 * (THREADS / 64)];
   const int tid = threadIdx.x;
   const int N = S.N, K = CL.K, R = CL.R, HB = CL.HB;
   int lb, part;
   cluster_map(K, lb, part);
   const int b = b0 + lb;
   Xch X = xch_init(CL, lb, part, dyn_lds + tail_off);
+  if (!xch_hello<THREADS>(X)) return;
   const int r0 = part * R, r1 = min(N, r0 + R);
   const size_t off = (size_t) b * 3 * N;
   double sums[3];
@@ -135,20 +137,19 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   C.xnew = A.x_new + off; C.rec_f = A.rec_f + off; C.rec_n = A.rec_n + off;
   C.rec_prim = A.rec_prim + (size_t) b * N;
   C.mu = A.mu + (size_t) b * S.ngroups;
-  C.yb = buf_vec(W.vbest + off, N);
+  C.yb = buf_vec(W.vbest + off, N, X.same_xcd);
   C.self = A.self; C.b = b; C.part = part; C.r0 = r0; C.r1 = r1; C.R = R; C.HB = HB;
   C.w0 = part * CL.wpp; C.w1 = min(CL.nwin, C.w0 + CL.wpp);
   C.nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;
   float *gx = A.gx + off, *gv = A.gv + off;
   float *gin = W.g + off, *u = W.vnow + off;
-  float *r = W.cg_r + off, *p = W.cg_p + off, *v = W.cg_ap + off, *t = W.cg_x + off, *rhat = gin;
+  float *r = W.cg_r + off, *p = W.cg_p + off, *v = W.cg_ap + off, *t = W.cg_x + off, *rhat = W.sd_sx + off;   // (detection scratch, idle here)
   const float h = S.h, h2 = S.h * S.h;
 
   // ---- gradient clipping (Simulation.cpp:1460-1466), u = 0, r = rhat = p = g ----
   float part_s = 0.f;
   for (int i = r0 + tid; i < r1; i += THREADS) { f3 q = ld3(gx, i, N); part_s += dot(q, q); }
-  sums[0] = block_sum<THREADS>((double) part_s, red); sums[1] = 0; sums[2] = 0;
-  if (!xch_sums<THREADS>(X, sums)) return;
+  if (!xch_allsum<THREADS>(X, part_s, 0.f, 0.f, sums)) return;
   double gnorm = sqrt(sums[0]);
   float gscale = 1.f;
   int clipped = 0;
@@ -156,41 +157,63 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   int status = 0;          // 1 converged, 2 stalled at the fp32 floor / breakdown, 0 cap hit
   int iters = 0;
   double udiff = 0;
-  // K u = 0 for u = 0: the start residual is g itself (the one-workgroup kernel applies K to the zero vector to the same effect)
-  xch_begin(X);
-  part_s = 0.f;
-  for (int l = tid; l < R; l += THREADS) {
-    const int i = r0 + l;
-    f3 q = mk(0, 0, 0);
-    if (i < N) {
-      q = ld3(gx, i, N) * gscale;
-      st3(gin, i, N, q); st3(u, i, N, mk(0, 0, 0)); st3(r, i, N, q); st3(p, i, N, q);
-      part_s += dot(q, q);
-    }
-    xch_publish_boundary(X, l, R, q.x, q.y, q.z);
-  }
-  {
-    const double ps = block_sum<THREADS>((double) part_s, red);
-    if (tid == 0) xch_publish_sums(X, (float) ps, 0.f, 0.f);
-    if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
-    halo_to_cache<THREADS, HPT>(C, hv);
-    __syncthreads();
-  }
-  double rho = sums[0];
-  double rr = rho;
+  for (int i = r0 + tid; i < r1; i += THREADS) { st3(gin, i, N, ld3(gx, i, N) * gscale); st3(u, i, N, mk(0, 0, 0)); }
+  double rr = 0;
   if (gnorm > 0) {
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
+    const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
+    constexpr int VB = 4;
+    // kCycles > 1: when the recurrence residual says "converged", recompute g - K u and restart from u if that is not below the
+    // tolerance. Measured on the C4 workload (r02m): +4 iterations of 41, gradient error against the fp64 oracle unchanged to three
+    // digits (7.31e-5 -> 7.31e-5) — the fp32 floor of this solve is eps * cond(K) in the operator's coefficients, not residual
+    // drift — so one cycle is the default.
+    for (int cycle = 0, kdone = 0; cycle < kCycles; cycle++) {
+    // r = rhat = p = g - K u (u = 0 in the first cycle: K u = 0 without applying the operator)
+    if (cycle > 0) {
+      // u travels as the operator's input: its boundary rows first
+      xch_begin(X);
+      for (int l = tid; l < R; l += THREADS) {
+        const int i = r0 + l;
+        f3 q = i < N ? ld3(u, i, N) : mk(0, 0, 0);
+        xch_publish_boundary(X, l, R, q.x, q.y, q.z);
+      }
+      xch_publish_sums(X, 0.f, 0.f, 0.f);
+      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+      halo_to_cache<THREADS, HPT>(C, hv);
+      __syncthreads();
+      float e1, e2;
+      if (!adjoint_operator_cl<THREADS>(S, CL, C, X, u, false, v, nullptr, e1, e2)) return;
+      __syncthreads();
+    }
+    xch_begin(X);
+    part_s = 0.f;
+    for (int l = tid; l < R; l += THREADS) {
+      const int i = r0 + l;
+      f3 q = mk(0, 0, 0);
+      if (i < N) {
+        q = ld3(gin, i, N);
+        if (cycle > 0) q = q - ld3(v, i, N);
+        st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
+        part_s += dot(q, q);
+      }
+      xch_publish_boundary(X, l, R, q.x, q.y, q.z);
+    }
+    xch_publish_sums(X, part_s, 0.f, 0.f);
+    if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+    halo_to_cache<THREADS, HPT>(C, hv);
+    __syncthreads();
+    double rho = sums[0];
+    rr = rho;
     double best_rr = rr;
     int since_progress = 0;
     status = (rr <= stop) ? 1 : 0;
-    const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
-    constexpr int VB = 4;
-    for (int k = 0; k < kcap && status == 0; k++) {
+    if (status == 0 && cycle > 0 && cycle == kCycles - 1) status = 2;      // still above the tolerance after two restarts: the fp32 floor of this system
+    if (status != 0) break;
+    for (int k = kdone; k < kcap && status == 0; k++, kdone++) {
       float d1, d2;
       // v = K D^-1 p ;  alpha = rho / (rhat . v)
       if (!adjoint_operator_cl<THREADS>(S, CL, C, X, p, true, v, rhat, d1, d2)) return;
-      sums[0] = block_sum<THREADS>((double) d1, red); sums[1] = 0; sums[2] = 0;
-      if (!xch_sums<THREADS>(X, sums)) return;
+      if (!xch_allsum<THREADS>(X, d1, 0.f, 0.f, sums)) return;
       const double rv = sums[0];
       if (!(fabs(rv) > 1e-300)) { status = 2; break; }
       const float alpha = (float) (rho / rv);
@@ -211,9 +234,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
         }
       }
       {
-        const double ps = block_sum<THREADS>((double) part_s, red);
-        if (tid == 0) xch_publish_sums(X, (float) ps, 0.f, 0.f);
-        if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
+        xch_publish_sums(X, part_s, 0.f, 0.f);
+        if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
         halo_to_cache<THREADS, HPT>(C, hv);
         __syncthreads();
       }
@@ -225,12 +247,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       }
       // t = K D^-1 s ;  omega = (t . s) / (t . t)
       if (!adjoint_operator_cl<THREADS>(S, CL, C, X, r, true, t, r, d1, d2)) return;
-      {
-        double ts = (double) d1, tt = (double) d2;
-        ts = block_sum<THREADS>(ts, red); tt = block_sum<THREADS>(tt, red);
-        sums[0] = ts; sums[1] = tt; sums[2] = 0;
-      }
-      if (!xch_sums<THREADS>(X, sums)) return;
+      if (!xch_allsum<THREADS>(X, d1, d2, 0.f, sums)) return;
       const double ts = sums[0], tt = sums[1];
       if (!(tt > 1e-300)) { status = 2; break; }
       const float omega = (float) (ts / tt);
@@ -256,8 +273,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
           }
         }
       }
-      sums[0] = block_sum<THREADS>((double) pa, red); sums[1] = block_sum<THREADS>((double) pb, red); sums[2] = 0;
-      if (!xch_sums<THREADS>(X, sums)) return;
+      if (!xch_allsum<THREADS>(X, pa, pb, 0.f, sums)) return;
       const double rho_new = sums[0];
       rr = sums[1];
       if (rr <= stop) { status = 1; break; }
@@ -281,24 +297,26 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
           if (l < R) xch_publish_boundary(X, l, R, pn.x, pn.y, pn.z);
         }
       }
-      __syncthreads();
-      if (tid == 0) xch_publish_sums(X, 0.f, 0.f, 0.f);
-      if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
+      xch_publish_sums(X, 0.f, 0.f, 0.f);
+      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
       halo_to_cache<THREADS, HPT>(C, hv);
       __syncthreads();
     }
-    udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual
+    if (status != 1) break;       // cap, breakdown or stall: no further cycle
+    __syncthreads();
+    }   // cycle
   }
+  udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual (of the last recomputed or recurrence residual)
   __syncthreads();
   // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650) ----
   // y = (I + dr_df)^T u* in global memory (own rows; with self contacts the layered pass on part 0)
   if (C.nself > 0) {
     for (int i = r0 + tid; i < r1; i += THREADS) st3c(C.yb, i, ld3(u, i, N));
-    if (!xch_fence_barrier<THREADS>(X)) return;
+    if (!xch_barrier<THREADS>(X)) return;
     if (part == 0) {
       if (!self_JT_layers_lds_v<THREADS>(S, C.self, b, C.yb, C.lds, C.lds_floats)) self_JT_layers_v<THREADS>(S, C.self, b, C.yb);
     }
-    if (!xch_fence_barrier<THREADS>(X)) return;
+    if (!xch_barrier<THREADS>(X)) return;
     for (int i = r0 + tid; i < r1; i += THREADS) { f3 z = ld3c(C.yb, i); st3c(C.yb, i, z + contact_JT_cl(S, C, i, z)); }
   } else {
     for (int i = r0 + tid; i < r1; i += THREADS) { f3 z = ld3(u, i, N); st3c(C.yb, i, z + contact_JT_cl(S, C, i, z)); }
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   float pacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (A.d_param) {
     // the element sums read y at arbitrary vertices: y changes hands; elements are dealt to the parts in contiguous ranges
-    if (!xch_fence_barrier<THREADS>(X)) return;
+    if (!xch_barrier<THREADS>(X)) return;
     const int T = S.T, E = S.E;
     const float *xnew = C.xnew;
     const BufVec &yv = C.yb;
@@ -377,14 +395,14 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   // sums over the parts, three values per exchange
   if (A.d_mu) {
     for (int k0 = 0; k0 < S.ngroups; k0 += 3) {
+      float val[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        float val = 0.f;
+        val[c] = 0.f;
 #pragma unroll
-        for (int k = 0; k < kMaxPrims; k++) val += (k == k0 + c) ? dmu_part[k] : 0.f;
-        sums[c] = block_sum<THREADS>((double) val, red);
+        for (int k = 0; k < kMaxPrims; k++) val[c] += (k == k0 + c) ? dmu_part[k] : 0.f;
       }
-      if (!xch_sums<THREADS>(X, sums)) return;
+      if (!xch_allsum<THREADS>(X, val[0], val[1], val[2], sums)) return;
       if (tid == 0 && part == 0)
         for (int c = 0; c < 3 && k0 + c < S.ngroups; c++) A.d_mu[(size_t) b * S.ngroups + k0 + c] += (float) sums[c];
     }
@@ -394,9 +412,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     const float scale[9] = {S.k_stretch > 0.f ? h2 / S.k_stretch : 0.f, S.k_bend > 0.f ? h2 / S.k_bend : 0.f,
                             S.k_att > 0.f ? h2 / S.k_att : 0.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f};
     for (int k0 = 0; k0 < 7; k0 += 3) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) sums[c] = block_sum<THREADS>((double) (k0 + c < 7 ? pacc[min(k0 + c, 6)] : 0.f), red);
-      if (!xch_sums<THREADS>(X, sums)) return;
+      if (!xch_allsum<THREADS>(X, pacc[k0], k0 + 1 < 7 ? pacc[min(k0 + 1, 6)] : 0.f, k0 + 2 < 7 ? pacc[min(k0 + 2, 6)] : 0.f, sums)) return;
       if (tid == 0 && part == 0)
         for (int c = 0; c < 3 && k0 + c < 7; c++) dp[k0 + c] = (float) (sums[c] * scale[k0 + c]);
     }

@@ -27,7 +27,7 @@ struct DevCluster {
   int HB;             // boundary rows exchanged each side (multiple of 64, >= bandwidth of P, <= R)
   int wpp;            // element windows per part
   int nb;             // rollouts per launch (K nb <= CUs)
-  int xch_stride;     // granules per (part, parity): 1 + 2 HB
+  int xch_stride;     // granules per (part, parity): kXchWaves + 2 HB
   // element windows of size R / wpp (same member names as DevSystem's set: dc_winlib.h is generic over both)
   const int4 DC_C *win;
   const int4 DC_G *wtri_rec;
@@ -52,24 +52,28 @@ struct DevCluster {
 constexpr long long kSpinLimit = 200000000ll;     // 2 s of the 100 MHz wall clock
 
 // ---- sc1 (write-through / L1-bypassing) access to a planar [3][N] vector of one rollout through a buffer resource ----
+// Loads always bypass the L1 (sc1: served by the XCD's L2, or by memory when the line is not there). Stores are write-through
+// (sc1: the line goes to memory and leaves the L2) unless `same_xcd`: when every part of the rollout was found on ONE XCD
+// (xch_hello), that XCD's L2 is the coherence point and an ordinary store, which keeps the line in the L2, is both sufficient and
+// faster (the readers' loads then hit the L2 instead of going to memory).
 struct BufVec {
   __amdgpu_buffer_rsrc_t rs;
   int N;
+  bool same_xcd;
   __device__ __forceinline__ float ld(int idx) const { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, idx * 4, 0, 16)); }
-  __device__ __forceinline__ void st(int idx, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs, idx * 4, 0, 16); }
+  __device__ __forceinline__ void st(int idx, float v) const {
+    if (same_xcd) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs, idx * 4, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs, idx * 4, 0, 16);
+  }
 };
-__device__ __forceinline__ BufVec buf_vec(const float *p, int N) {
+__device__ __forceinline__ BufVec buf_vec(const float *p, int N, bool same_xcd) {
   BufVec b;
   b.rs = __builtin_amdgcn_make_buffer_rsrc((void *) p, 0, 3 * N * 4, 0x00020000);
-  b.N = N;
+  b.N = N; b.same_xcd = same_xcd;
   return b;
 }
-__device__ __forceinline__ float ldc1(const BufVec &b, int idx) {
-  return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.rs, idx * 4, 0, 16));
-}
-__device__ __forceinline__ void stc1(const BufVec &b, int idx, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), b.rs, idx * 4, 0, 16);
-}
+__device__ __forceinline__ float ldc1(const BufVec &b, int idx) { return b.ld(idx); }
+__device__ __forceinline__ void stc1(const BufVec &b, int idx, float v) { b.st(idx, v); }
 __device__ __forceinline__ f3 ld3c(const BufVec &b, int i) { return mk(ldc1(b, i), ldc1(b, b.N + i), ldc1(b, 2 * b.N + i)); }
 __device__ __forceinline__ void st3c(const BufVec &b, int i, f3 v) { stc1(b, i, v.x); stc1(b, b.N + i, v.y); stc1(b, 2 * b.N + i, v.z); }
 struct In2Sc1 {       // input loader of element_windows_t (stage1 / in2) for a vector other workgroups write (dc_winlib.h)
@@ -78,12 +82,14 @@ struct In2Sc1 {       // input loader of element_windows_t (stage1 / in2) for a 
 };
 
 // ---- exchange state of one workgroup ----
+constexpr int kXchWaves = 16;          // sum granules per (part, parity): one per wave of the publishing workgroup (<= 1024 threads)
 struct Xch {
   __amdgpu_buffer_rsrc_t rs;    // the rollout's exchange area
   unsigned seq;                 // sequence number of the current exchange (tag); starts at 0 = "nothing yet"
   int part, K, HB, stride;
   int site;                     // diagnostic: which exchange of the kernel is running (recorded when a poll gives up)
-  float *lsum;                  // LDS [4 * 8]: partial sums of all parts of the current exchange
+  bool same_xcd;                // every part of this rollout runs on one XCD (xch_hello): granules may stay in its L2
+  float *lsum;                  // LDS [2][4]: the totals of the current exchange, double-buffered by sequence parity
   int *ldead;                   // LDS flag: an exchange of this workgroup timed out
   unsigned *err;
 };
@@ -100,26 +106,47 @@ __device__ __forceinline__ Xch xch_init(const DevCluster &CL, int lb, int part, 
   Xch X;
   const size_t per = (size_t) CL.K * 2 * CL.xch_stride;
   X.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (CL.xch + (size_t) lb * per), 0, (int) (per * 16), 0x00020000);
-  X.seq = 0; X.site = 0; X.part = part; X.K = CL.K; X.HB = CL.HB; X.stride = CL.xch_stride;
-  X.lsum = lds_tail; X.ldead = (int *) (lds_tail + 32); X.err = CL.err;
+  X.seq = 0; X.site = 0; X.same_xcd = false; X.part = part; X.K = CL.K; X.HB = CL.HB; X.stride = CL.xch_stride;
+  X.lsum = lds_tail; X.ldead = (int *) (lds_tail + 8); X.err = CL.err;
   if (threadIdx.x == 0) *X.ldead = 0;
   return X;
 }
-constexpr int kXchLdsFloats = 48;      // tail of the dynamic LDS the exchange uses (lsum[32], ldead, padding)
+constexpr int kXchLdsFloats = 16;      // tail of the dynamic LDS the exchange uses (lsum[2][4], ldead, padding)
 
 __device__ __forceinline__ int xch_off(const Xch &X, int part, int g) { return ((part * 2 + (int) (X.seq & 1u)) * X.stride + g) * 16; }
 
+// Wave-wide sum through DPP row operations (VALU only); the total is returned in every lane.
+__device__ __forceinline__ float xch_wave_sum(float v) {
+#define DC_DPP(x, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xF, true))
+  v += DC_DPP(v, 0xB1, 0xF);     // quad_perm [1,0,3,2]
+  v += DC_DPP(v, 0x4E, 0xF);     // quad_perm [2,3,0,1]
+  v += DC_DPP(v, 0x141, 0xF);    // row_half_mirror
+  v += DC_DPP(v, 0x140, 0xF);    // row_mirror
+  v += DC_DPP(v, 0x142, 0xA);    // row_bcast:15
+  v += DC_DPP(v, 0x143, 0xC);    // row_bcast:31
+#undef DC_DPP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // start the next exchange (all threads, uniformly)
 __device__ __forceinline__ void xch_begin(Xch &X) { X.seq++; }
-// this part's partial sums (ONE thread)
+__device__ __forceinline__ void xch_store(const Xch &X, v4i g, int off) {
+  if (X.same_xcd) __builtin_amdgcn_raw_buffer_store_b128(g, X.rs, off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(g, X.rs, off, 0, 16);
+}
+// Every thread hands in its partial sums; each wave reduces them (DPP) and its first lane publishes ONE granule — no workgroup
+// barrier, no LDS: a wave's contribution is on its way as soon as that wave is done.
 __device__ __forceinline__ void xch_publish_sums(const Xch &X, float a, float b, float c) {
-  v4i g = {__float_as_int(a), __float_as_int(b), __float_as_int(c), (int) X.seq};
-  __builtin_amdgcn_raw_buffer_store_b128(g, X.rs, xch_off(X, X.part, 0), 0, 16);
+  a = xch_wave_sum(a); b = xch_wave_sum(b); c = xch_wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    v4i g = {__float_as_int(a), __float_as_int(b), __float_as_int(c), (int) X.seq};
+    xch_store(X, g, xch_off(X, X.part, (int) (threadIdx.x >> 6)));
+  }
 }
 // one boundary row: slot in [0, HB) = this part's first HB rows (read by part - 1), [HB, 2 HB) = its last HB rows (part + 1)
 __device__ __forceinline__ void xch_publish_row(const Xch &X, int slot, float x, float y, float z) {
   v4i g = {__float_as_int(x), __float_as_int(y), __float_as_int(z), (int) X.seq};
-  __builtin_amdgcn_raw_buffer_store_b128(g, X.rs, xch_off(X, X.part, 1 + slot), 0, 16);
+  xch_store(X, g, xch_off(X, X.part, kXchWaves + slot));
 }
 // publish the boundary rows held by this thread: local row l = tid + k THREADS of a part of R rows, value v
 __device__ __forceinline__ void xch_publish_boundary(const Xch &X, int l, int R, float x, float y, float z) {
@@ -142,22 +169,34 @@ __device__ __forceinline__ bool xch_poll(const Xch &X, int off, v4i &g) {
         return false;
       }
     }
-    __builtin_amdgcn_s_sleep(1);
+    if (spins > 16u) __builtin_amdgcn_s_sleep(1);
   }
 }
 
-// Wait for the partial sums of all parts and (HALO) for the neighbours' boundary rows. hv[q] receives halo row j = tid + q THREADS
-// (j in [0, HB): rows r0 - HB + j from part - 1; j in [HB, 2 HB): rows r0 + R + (j - HB) from part + 1; zero where there is no
-// neighbour). sums[c] = sum over the parts in part order (identical in every part). Call with all threads; ends with a barrier.
-// Returns false when the exchange timed out (the caller leaves the kernel).
+// Wait for the wave sums of all parts (wave 0 polls them, one or two granules per lane, adds them up in a fixed order and leaves
+// the totals in LDS) and (HALO) for the neighbours' boundary rows. hv[q] receives halo row j = tid + q THREADS (j in [0, HB): rows
+// r0 - HB + j from part - 1; j in [HB, 2 HB): rows r0 + R + (j - HB) from part + 1; zero where there is no neighbour). sums[c] are
+// identical in every part (same granules, same order). Call with all threads; contains ONE workgroup barrier (the LDS totals are
+// double-buffered by sequence parity). Returns false when the exchange timed out (the caller leaves the kernel).
 template <int THREADS, int HPT, bool HALO>
-__device__ __forceinline__ bool xch_consume(const Xch &X, double (&sums)[3], f3 (&hv)[HPT]) {
+__device__ __forceinline__ bool xch_finish(const Xch &X, double (&sums)[3], f3 (&hv)[HPT]) {
+  constexpr int NW = THREADS / 64;
   const int tid = threadIdx.x;
   bool ok = true;
-  if (tid < X.K) {
-    v4i g;
-    ok = xch_poll(X, xch_off(X, tid, 0), g);
-    X.lsum[4 * tid] = __int_as_float(g.x); X.lsum[4 * tid + 1] = __int_as_float(g.y); X.lsum[4 * tid + 2] = __int_as_float(g.z);
+  float *slot = X.lsum + 4 * (int) (X.seq & 1u);
+  if (tid < 64) {
+    float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int j = tid + 64 * q;                // granule j = wave (j % NW) of part (j / NW)
+      if (j < X.K * NW) {
+        v4i g;
+        ok = xch_poll(X, xch_off(X, j / NW, j % NW), g) && ok;
+        a += __int_as_float(g.x); b += __int_as_float(g.y); c += __int_as_float(g.z);
+      }
+    }
+    a = xch_wave_sum(a); b = xch_wave_sum(b); c = xch_wave_sum(c);
+    if (tid == 0) { slot[0] = a; slot[1] = b; slot[2] = c; }
   }
   if constexpr (HALO) {
 #pragma unroll
@@ -169,7 +208,7 @@ __device__ __forceinline__ bool xch_consume(const Xch &X, double (&sums)[3], f3 
         const int src = lower ? X.part - 1 : X.part + 1;
         if (src >= 0 && src < X.K) {
           v4i g;
-          ok = xch_poll(X, xch_off(X, src, 1 + (lower ? X.HB + j : j - X.HB)), g) && ok;
+          ok = xch_poll(X, xch_off(X, src, kXchWaves + (lower ? X.HB + j : j - X.HB)), g) && ok;
           hv[q] = mk(__int_as_float(g.x), __int_as_float(g.y), __int_as_float(g.z));
         }
       }
@@ -177,30 +216,47 @@ __device__ __forceinline__ bool xch_consume(const Xch &X, double (&sums)[3], f3 
   }
   if (!ok) *X.ldead = 1;
   __syncthreads();
-  sums[0] = sums[1] = sums[2] = 0;
-  for (int p = 0; p < X.K; p++) { sums[0] += (double) X.lsum[4 * p]; sums[1] += (double) X.lsum[4 * p + 1]; sums[2] += (double) X.lsum[4 * p + 2]; }
-  const bool alive = *X.ldead == 0;
-  __syncthreads();            // lsum is rewritten by the next exchange
-  return alive;
+  sums[0] = (double) slot[0]; sums[1] = (double) slot[1]; sums[2] = (double) slot[2];
+  return *X.ldead == 0;
 }
 
-// sums only: every thread passes the workgroup's partial sums (already reduced over the workgroup)
+// all-parts sum of three per-thread partial values (a complete exchange)
 template <int THREADS>
-__device__ __forceinline__ bool xch_sums(Xch &X, double (&s)[3]) {
+__device__ __forceinline__ bool xch_allsum(Xch &X, float a, float b, float c, double (&s)[3]) {
   xch_begin(X);
-  if (threadIdx.x == 0) xch_publish_sums(X, (float) s[0], (float) s[1], (float) s[2]);
+  xch_publish_sums(X, a, b, c);
   f3 none[1];
-  return xch_consume<THREADS, 1, false>(X, s, none);
+  return xch_finish<THREADS, 1, false>(X, s, none);
 }
 
-// every store of the workgroup so far has left the CU (needed before a granule that tells others "my sc1 stores are done")
+// First exchange of a kernel (write-through stores): the parts tell each other which XCD they run on (HW_REG_XCC_ID). When all
+// K are on the same one, its L2 is their coherence point and the stores of every later exchange may stay there.
+template <int THREADS>
+__device__ __forceinline__ bool xch_hello(Xch &X) {
+  const float id = (float) (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15);
+  const bool one = threadIdx.x == 0;
+  double s[3];
+  if (!xch_allsum<THREADS>(X, one ? id : 0.f, one ? id * id : 0.f, 0.f, s)) return false;
+  X.same_xcd = (s[0] * s[0] == (double) X.K * s[1]);       // sum^2 == K * sum of squares  <=>  all equal
+  return true;
+}
+
+// every store of the workgroup so far has left the CU (needed before granules that tell others "my sc1 stores are done")
 __device__ __forceinline__ void xch_drain() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
 
-// Hand-over of arrays written with PLAIN stores: agent-scope release, an all-parts exchange, agent-scope acquire (one lane each;
-// the acquire drops this CU's L1 and scalar cache so that plain / scalar loads see the other parts' data).
+// Barrier over the parts of the rollout for data written with write-through (sc1) stores and read with sc1 loads: drain, exchange.
+template <int THREADS>
+__device__ __forceinline__ bool xch_barrier(Xch &X) {
+  xch_drain();
+  double z[3];
+  return xch_allsum<THREADS>(X, 0.f, 0.f, 0.f, z);
+}
+
+// The same for arrays written with PLAIN stores (the self-contact lists of the inlined detection): agent-scope release before,
+// agent-scope acquire after (one lane each; the acquire drops this CU's L1 and scalar cache).
 template <int THREADS>
 __device__ __forceinline__ bool xch_fence_barrier(Xch &X) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -209,8 +265,9 @@ __device__ __forceinline__ bool xch_fence_barrier(Xch &X) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // restated where the compiler cannot drop it (visibility guide, hazard 12)
   }
-  double z[3] = {0, 0, 0};
-  const bool ok = xch_sums<THREADS>(X, z);
+  __syncthreads();                                        // the release precedes every wave's granule
+  double z[3];
+  const bool ok = xch_allsum<THREADS>(X, 0.f, 0.f, 0.f, z);
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __builtin_amdgcn_s_dcache_inv();

@@ -270,7 +270,7 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   ClusterSet &cl = c->cl;
   DevCluster &D = cl.D;
   std::memset(&D, 0, sizeof(D));
-  D.K = K; D.R = R; D.HB = HB; D.wpp = wpp; D.xch_stride = 1 + 2 * HB; D.pk_vpt = vpt;
+  D.K = K; D.R = R; D.HB = HB; D.wpp = wpp; D.xch_stride = kXchWaves + 2 * HB; D.pk_vpt = vpt;
   int rc;
   const int *ip; const float *fp;
   if ((rc = upload_cl<int>(c, &ip, HW.win))) return rc;

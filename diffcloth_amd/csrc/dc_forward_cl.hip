@@ -28,7 +28,6 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   constexpr int WAVES = THREADS / 64;
   constexpr int HPT = (1024 + THREADS - 1) / THREADS;      // halo rows per thread: 2 HB <= 1024
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ double red[THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = CL.K, R = CL.R, HB = CL.HB, GL = R + 2 * HB;
@@ -36,6 +35,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   cluster_map(K, lb, part);
   const int b = b0 + lb;
   Xch X = xch_init(CL, lb, part, lds + tail_off);
+  if (!xch_hello<THREADS>(X)) return;
   float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
   float *gz = lds + 2 * GL;
   const int N = S.N;
@@ -43,18 +43,21 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   const int nch = R >> 6, cbase = r0 >> 6;
   const size_t off = (size_t) b * 3 * N;
   float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off, *scr = W.cg_r + off;
-  const BufVec vnb = buf_vec(vnow, N);
+  const BufVec vnb = buf_vec(vnow, N, X.same_xcd);
   const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
   const int w0 = part * CL.wpp, w1 = min(CL.nwin, w0 + CL.wpp);
 
   for (int step = 0; step < A.nsteps; step++) {
   // the previous step's state (written by every part with plain stores) changes hands
   X.site = 1;
-  if (step > 0) { if (!xch_fence_barrier<THREADS>(X)) return; }
+  if (step > 0) {   // (with the inlined detection part 0 then reads the whole state through plain loads: acquire)
+    if constexpr (DETECT) { if (!xch_fence_barrier<THREADS>(X)) return; }
+    else { if (!xch_barrier<THREADS>(X)) return; }
+  }
   const size_t so = (size_t) step * A.slot_state;
   // the tape state and f / r are read across parts: write-through stores, L1-bypassing loads (xnb, vinb, rfb, rrb, xob, vob)
-  const BufVec xnb = buf_vec(A.x_in + off + so, N), vinb = buf_vec(A.v_in + off + so, N);
-  const BufVec rfb = buf_vec(A.rec_f + off + so, N), rrb = buf_vec(A.rec_r + off + so, N);
+  const BufVec xnb = buf_vec(A.x_in + off + so, N, X.same_xcd), vinb = buf_vec(A.v_in + off + so, N, X.same_xcd);
+  const BufVec rfb = buf_vec(A.rec_f + off + so, N, X.same_xcd), rrb = buf_vec(A.rec_r + off + so, N, X.same_xcd);
   float *rec_n = A.rec_n + off + so;
   int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
   SelfRec srec = A.self;
@@ -62,16 +65,16 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // detection + layering of this step: part 0, then the lists change hands
     X.site = 2;
-    if (part == 0) self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, A.fv, (int *) lds);
-    if (!xch_fence_barrier<THREADS>(X)) return;
+    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, A.fv, (int *) lds); __syncthreads(); }
   }
   // number of self contacts of this step: part 0 knows it (its own detection, or the stand-alone detection kernel's record) and
   // hands it to the others inside an exchange, so that no part ever has to read it from memory another part wrote
   int nself = 0;
   {
-    double ns[3] = {0, 0, 0};
-    if (part == 0 && S.contact_enabled && S.self_enabled) ns[0] = (double) srec.meta[(size_t) b * kMetaStride];
-    if (!xch_sums<THREADS>(X, ns)) return;
+    double ns[3];
+    float mine = 0.f;
+    if (part == 0 && tid == 0 && S.contact_enabled && S.self_enabled) mine = (float) srec.meta[(size_t) b * kMetaStride];
+    if (!xch_allsum<THREADS>(X, mine, 0.f, 0.f, ns)) return;     // (the others wait here for part 0's detection)
     nself = (int) (ns[0] + 0.5);
   }
   const float *mu = A.mu + (size_t) b * S.ngroups;
@@ -101,8 +104,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   xch_drain();                                    // v is read by the neighbours' windows: its stores must have left the CU
   double sums[3];
   X.site = 3;
-  sums[0] = block_sum<THREADS>((double) part_s, red); sums[1] = block_sum<THREADS>((double) ncontact, red); sums[2] = 0;
-  if (!xch_sums<THREADS>(X, sums)) return;
+  if (!xch_allsum<THREADS>(X, part_s, (float) ncontact, 0.f, sums)) return;
   double min_xdiff = (double) h * sqrt(sums[0]) / (double) N;
   const int total_contacts = (int) (sums[1] + 0.5);
   bool improved = false, converged = false, stalled = false, best_is_current = false;
@@ -140,11 +142,11 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     __syncthreads();
     X.site = 4;
     if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) on part 0 over the rollout's f / r, then the right-hand side again
-      if (!xch_fence_barrier<THREADS>(X)) return;
+      if (!xch_barrier<THREADS>(X)) return;
       if (part == 0) {
         if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
       }
-      if (!xch_fence_barrier<THREADS>(X)) return;
+      if (!xch_barrier<THREADS>(X)) return;
       psum = 0.f;
       for (int i = r0 + tid; i < r1; i += THREADS) {
         f3 rhs = (ld3c(rfb, i) + ld3c(rrb, i) - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i];
@@ -173,10 +175,9 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     }
     double rz;
     {
-      const double ps = block_sum<THREADS>((double) psum, red);
-      if (tid == 0) xch_publish_sums(X, (float) ps, 0.f, 0.f);
+      xch_publish_sums(X, psum, 0.f, 0.f);
       f3 hv[HPT];
-      if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
+      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
 #pragma unroll
       for (int q = 0; q < HPT; q++) {
         const int j = tid + q * THREADS;
@@ -226,8 +227,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         const int wz = wv + zs, tz = tid + zs;
         spmv(wz, part2);
         X.site = 6;
-        sums[0] = block_sum_f<THREADS>(part2, red); sums[1] = 0; sums[2] = 0;
-        if (!xch_sums<THREADS>(X, sums)) return;
+        if (!xch_allsum<THREADS>(X, part2, 0.f, 0.f, sums)) return;
         const float alpha = (float) (rz / sums[0]);
         part2 = 0.f;
         X.site = 7;
@@ -246,10 +246,9 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           }
           if (l < R) xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
         }
-        const double ps = block_sum_f<THREADS>(part2, red);
-        if (tid == 0) xch_publish_sums(X, (float) ps, 0.f, 0.f);
+        xch_publish_sums(X, part2, 0.f, 0.f);
         f3 hv[HPT];
-        if (!xch_consume<THREADS, HPT, true>(X, sums, hv)) return;
+        if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
         const double rz_new = sums[0];
         it++; cg_total++;
         if (!(rz_new > stop)) break;
@@ -294,8 +293,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     }
     X.site = 8;
     xch_drain();                                  // the new v must have left the CU before the norm (= its hand-over flag) is published
-    sums[0] = block_sum<THREADS>((double) psum, red); sums[1] = 0; sums[2] = 0;
-    if (!xch_sums<THREADS>(X, sums)) return;
+    if (!xch_allsum<THREADS>(X, psum, 0.f, 0.f, sums)) return;
     xdiff = (double) h * sqrt(sums[0]) / (double) N;
     iters = iter + 1;
     converged = xdiff < (double) A.fwd_tol;
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     if (++since_progress >= A.stall_window) { stalled = true; break; }
   }
   // ---- write the new state of the own rows (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
-  const BufVec xob = buf_vec(A.x_out + off + so, N), vob = buf_vec(A.v_out + off + so, N);
+  const BufVec xob = buf_vec(A.x_out + off + so, N, X.same_xcd), vob = buf_vec(A.v_out + off + so, N, X.same_xcd);
   for (int i = r0 + tid; i < r1; i += THREADS) {
     f3 x = ld3c(xnb, i);
     if (converged) { f3 v = ld3c(vnb, i); st3c(vob, i, v); st3c(xob, i, x + v * h); }

@@ -199,3 +199,16 @@ int orc_detect(void *s, const double *x_n, const double *v, int *nprim, int *nse
 }
 
 }  // extern "C"
+
+// Diagnostic for the parity analysis: round fields of a stored record to fp32, to measure what the precision of
+// the tape alone does to the gradient. which: bit 0 = x (x_new), bit 1 = f, r and the contact d vectors.
+extern "C" void orc_round_record(void *s, int id, int which) {
+  Sim *S = (Sim *) s; Record &rec = S->records[id];
+  auto r32 = [](std::vector<double> &a) { for (double &q : a) q = (double) (float) q; };
+  if (which & 1) r32(rec.x);
+  if (which & 2) {
+    r32(rec.f); r32(rec.r);
+    for (PrimContact &c : rec.prim) { c.d = V3((float) c.d.x, (float) c.d.y, (float) c.d.z); c.r = V3((float) c.r.x, (float) c.r.y, (float) c.r.z); }
+    for (auto &L : rec.layers) for (SelfContact &c : L) c.d = V3((float) c.d.x, (float) c.d.y, (float) c.d.z);
+  }
+}

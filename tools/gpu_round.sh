@@ -30,6 +30,14 @@ CFG
     rest) TAILN=15 run rest python -m pytest tests -m gpu -q --deselect tests/test_gpu_bench_parity.py --deselect tests/test_gpu_cluster.py ;;
     bench) TAILN=3 run bench python bench.py --steps 20 --warmup 5 ;;
     bench32) TAILN=3 run bench32 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 ;;
+    b32f0) TAILN=2 run b32f0 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --fold-rows 0 ;;
+    b32f0k1) TAILN=2 run b32f0k1 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --fold-rows 0 --cluster 1 ;;
+    b32k4) TAILN=2 run b32k4 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 4 ;;
+    b32k2) TAILN=2 run b32k2 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 2 ;;
+    b64) TAILN=2 run b64 python bench.py --steps 20 --warmup 5 --total-batch 64 --cpu-steps 0 ;;
+    b128) TAILN=2 run b128 python bench.py --steps 20 --warmup 5 --total-batch 128 --cpu-steps 0 ;;
+    g128) TAILN=2 run g128 python bench.py --steps 8 --warmup 4 --grid 128 --fold-rows 0 --cpu-steps 0 ;;
+    g128k1) TAILN=2 run g128k1 python bench.py --steps 8 --warmup 4 --grid 128 --fold-rows 0 --cpu-steps 0 --cluster 1 ;;
     bench32k1) TAILN=3 run bench32k1 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 1 ;;
     *) echo "unknown item $item" ;;
   esac
