@@ -111,6 +111,34 @@ def cpu_baseline(args, V, F, center, field, x0, v0, mu, steps, gscale):
                        + ("direct adjoint solve" if args.adjoint_mode == 1 else "reference adjoint iteration"))
 
 
+def tshirt_evaluation0():
+    """Secondary, like-for-like line: evaluation 0 of the reference's shipped L-BFGS run output/tshirt-exampleopt (wind_tshirt demo,
+    1426 vertices, ONE rollout of 250 steps with self-collision, MATCH_TRAJECTORY loss, backward sweep) through this repository's
+    diffcloth_py.OptimizeHelper — the only workload the reference publishes timings for (its own CPU run: forwardLog.txt:3-5 41.0 s
+    forward, backwardLog.txt:3-9 2.67 s backward). Parameters of that evaluation from tests/golden/tshirt_golden.npz."""
+    sys.path.insert(0, os.path.join(ROOT, "diffcloth_amd", "lib"))
+    try:
+        import diffcloth_py as d
+        import scenes
+        g = np.load(os.path.join(scenes.GOLDEN, "tshirt_golden.npz"))
+        V, F = scenes.load_mesh("tshirt")
+        sim = d.makeSimFromMesh("wind_tshirt", V.reshape(-1), F.reshape(-1).tolist())
+        h = d.makeOptimizeHelperWithSim("wind_tshirt", sim)
+        x = np.array([*g["log_wind"][0], g["log_k"][0]])
+        h.runSimulationAndGetLoss(x)                      # warm-up (allocations, first launches)
+        t0 = time.perf_counter(); loss = h.runSimulationAndGetLoss(x); t_f = time.perf_counter() - t0
+        t0 = time.perf_counter(); recs = h.runSimulationAndGetLossGradient(x); t_fb = time.perf_counter() - t0
+        return {"workload": "wind_tshirt evaluation 0 of output/tshirt-exampleopt: 1 rollout, 250 steps fwd + 250 bwd, N=1426, self-collision on, "
+                            "through diffcloth_py.OptimizeHelper (one C-ABI call per step)",
+                "forward_s": t_f, "forward_plus_backward_s": t_fb, "backward_s": max(t_fb - t_f, 0.0), "steps_per_s_fwd_bwd": 250.0 / t_fb,
+                "loss": float(loss), "loss_logged_by_reference": float(g["losses"][0]), "pd_iterations": int(sim.getStateInfo().cumulateIter),
+                "adjoint_iterations": int(recs[0].backwardTotalIters),
+                "reference_cpu": {"forward_s": 41.0, "backward_s": 2.67, "steps_per_s_fwd_bwd": 250.0 / 43.67,
+                                  "source": "/root/reference/output/tshirt-exampleopt/forwardLog.txt:3-5, backwardLog.txt:3-9 (authors' machine)"}}
+    except Exception as ex:      # secondary information must never take the headline down
+        return {"error": f"{type(ex).__name__}: {ex}"}
+
+
 def config_key(args, B, K, W, N):
     return (f"N{N}_B{B}_K{K}_W{W}_fold{args.fold_rows}x{args.flap_force:g}_sc{args.selfcollision}_ft{args.fwd_tol:g}_cg{args.cg_tol:g}"
             f"_am{args.adjoint_mode}_ar{args.adjoint_rel_tol:g}")
@@ -153,6 +181,7 @@ def main():
     ap.add_argument("--cluster", type=int, default=-1, help="workgroups per rollout: -1 = engine's choice, 1 = one workgroup per rollout")
     ap.add_argument("--cpu-steps", type=int, default=-1,
                     help="steps of the CPU baseline sample (rollout 0 from its state after the warm-up steps); -1 = the timed steps, 0 disables")
+    ap.add_argument("--tshirt", type=int, default=1, help="also time evaluation 0 of the reference's T-shirt L-BFGS run (secondary line; 0 = skip)")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0: min(host cores, 32), the fastest setting measured on the MI355X host)")
     args = ap.parse_args()
@@ -327,6 +356,8 @@ def main():
         if world == 1 and ncpu > 0:
             xw, vw = e.get_state(W)
             out["cpu_baseline"] = cpu_baseline(args, V, F, center, field, xw[0], vw[0], MU[0, 0], ncpu, gscale)
+        if world == 1 and args.tshirt:
+            out["secondary"] = tshirt_evaluation0()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -6,6 +6,10 @@ The GPU box has no /root/reference, so everything the tests need from it is froz
   tshirt_golden.npz  the reference's only golden data: output/tshirt-exampleopt/iter0 — first frames of the
                      1426-vertex T-shirt rollout of L-BFGS evaluation 0, with the parameters of that run
                      (iter0/param.txt), the losses / parameters / iteration counts of forwardLog.txt and the gradients of backwardLog.txt
+  reference_callers/ the reference's own PyTorch caller layer, src/python_code/pySim/{__init__,functional,pySim}.py, frozen byte
+                     for byte: tests/test_gpu_reference_callers.py imports and runs it UNMODIFIED against this repository's
+                     diffcloth_py module (BASELINE.json north_star: "drops into the repo's ... hatController optimisation loops
+                     unchanged"). These three files are the reference's, not this repository's work; they are test input.
 """
 import os
 import re
@@ -31,7 +35,17 @@ def load_obj(path):
     return np.asarray(V, dtype=np.float64), np.asarray(F, dtype=np.int32)
 
 
+def freeze_reference_callers():
+    import shutil
+    dst = os.path.join(OUT, "reference_callers", "pySim")
+    os.makedirs(dst, exist_ok=True)
+    for f in ("__init__.py", "functional.py", "pySim.py"):
+        shutil.copyfile(os.path.join(REF, "src/python_code/pySim", f), os.path.join(dst, f))
+    print("froze", dst)
+
+
 def main():
+    freeze_reference_callers()
     meshes = {
         "hat": "src/assets/meshes/remeshed/agenthat2-579-rotated.obj",
         "tshirt": "src/assets/meshes/remeshed/T-shirt/tshirt1000-tri.obj",

@@ -24,6 +24,10 @@ CFG
     pym) TAILN=30 run pym python -m pytest tests/test_gpu_pymodule.py -q -x ;;
     pymk1) export DC_CLUSTER=1; TAILN=12 run pymk1 python -m pytest tests/test_gpu_pymodule.py -q -x -k "dress_twirl" -s; unset DC_CLUSTER ;;
     pymdress) TAILN=12 run pymdress python -m pytest tests/test_gpu_pymodule.py -q -x -k "dress_twirl" -s ;;
+    big) TAILN=8 run big python -m pytest tests/test_gpu_fullsize.py -q -s -k beyond ;;
+    bigk1) export DC_CLUSTER=1; TAILN=8 run bigk1 python -m pytest tests/test_gpu_fullsize.py -q -s -k beyond; unset DC_CLUSTER ;;
+    bigk4) export DC_CLUSTER=4; TAILN=8 run bigk4 python -m pytest tests/test_gpu_fullsize.py -q -s -k beyond; unset DC_CLUSTER ;;
+    refcall) TAILN=12 run refcall python -m pytest tests/test_gpu_reference_callers.py tests/test_gpu_rccl.py -q -s ;;
     fallb) TAILN=30 run fallb python -m pytest tests/test_gpu_fallbacks.py -q ;;
     parity) TAILN=40 run parity python -m pytest tests/test_gpu_bench_parity.py -q -s ;;
     all) TAILN=15 run all python -m pytest tests -m gpu -q -x ;;
