@@ -31,7 +31,7 @@ class dc_params(C.Structure):
                 ("selfcollision_enabled", C.c_int), ("gradient_clipping", C.c_int),
                 ("gradient_clipping_threshold", C.c_double), ("pd_iter_cap", C.c_int), ("adjoint_iter_cap", C.c_int),
                 ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int),
-                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double), ("max_self_contacts", C.c_int)]
+                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double), ("adjoint_block_precond", C.c_int), ("max_self_contacts", C.c_int)]
 
 
 class dc_step_stats(C.Structure):

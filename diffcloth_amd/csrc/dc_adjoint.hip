@@ -19,6 +19,7 @@
 #include "dc_devlib.h"
 #include "dc_winlib.h"
 #include "dc_denselib.h"
+#include "dc_adjprecond.h"
 
 namespace dc {
 
@@ -223,7 +224,8 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
 
 }  // namespace
 
-template <int THREADS, bool WIN, bool DENSE>
+// BLK: direct solve preconditioned with K's own 3 x 3 diagonal blocks (dc_adjprecond.h) instead of diag(P)^-1
+template <int THREADS, bool WIN, bool DENSE, bool BLK>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
   const DevSystem &S = *Sp;
   extern __shared__ float dyn_lds[];      // element windows (S.win_lds_bytes)
@@ -337,6 +339,12 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     constexpr int VB = 4;
     PH(0)
     float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = W.sd_sx + off;    // (detection scratch, idle in the backward pass)
+    float *ph = W.pre_p + off, *sh = W.pre_s + off, *minv = W.minv + (size_t) b * 9 * N;   // M^-1 p, M^-1 s, the block inverses
+    if constexpr (BLK) {   // K's own 3 x 3 diagonal blocks at this step's x_new, inverted (dc_adjprecond.h)
+      for (int i = tid; i < N; i += THREADS)
+        store_block_inverse(elastic_diag_block(S, C.xnew, i), S.mass[i], [&](f3 e) { return contact_JT(S, C, i, e); }, minv, i, N);
+    }
+    auto pre = [&](int i, f3 z) { return block_pre(minv, i, N, z); };
     float d1, d2;
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
     const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
@@ -352,6 +360,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     for (int i = tid; i < N; i += THREADS) {
       f3 q = ld3(gin, i, N) - ld3(v, i, N);
       st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
+      if constexpr (BLK) st3(ph, i, N, pre(i, q));
       part += dot(q, q);
     }
     double rho = block_sum<THREADS>((double) part, red);   // rhat.r = r.r
@@ -362,9 +371,10 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     if (status == 0 && cycle > 0 && cycle == kCycles - 1) status = 2;      // still above the tolerance after two restarts: the fp32 floor of this system
     if (status != 0) break;
     for (int k = kdone; k < kcap && status == 0; k++, kdone++) {
-      // v = K D^-1 p ;  alpha = rho / (rhat . v)
+      // v = K M^-1 p ;  alpha = rho / (rhat . v)
       PH(2)
-      adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
+      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, ph, false, v, rhat, d1, d2);
+      else adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
       double rv = block_sum<THREADS>((double) d1, red);
       PH(1)
       if (!(fabs(rv) > 1e-300)) { status = 2; break; }
@@ -380,39 +390,41 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
         for (int j = 0; j < VB; j++) {
           const int i = i0 + j * THREADS;
           f3 s = rq[j] - vq[j] * alpha;
-          if (i < N) { st3(r, i, N, s); part += dot(s, s); }
+          if (i < N) { st3(r, i, N, s); if constexpr (BLK) st3(sh, i, N, pre(i, s)); part += dot(s, s); }
         }
       }
       double ss = block_sum<THREADS>((double) part, red);
       iters++;
       if (ss <= stop) {
-        for (int i = tid; i < N; i += THREADS) st3(u, i, N, ld3(u, i, N) + ld3(p, i, N) * (alpha * S.dinv[i]));
+        for (int i = tid; i < N; i += THREADS) st3(u, i, N, ld3(u, i, N) + (BLK ? ld3(ph, i, N) * alpha : ld3(p, i, N) * (alpha * S.dinv[i])));
         rr = ss; status = 1; break;
       }
-      // t = K D^-1 s ;  omega = (t . s) / (t . t)
+      // t = K M^-1 s ;  omega = (t . s) / (t . t)
       PH(2)
-      adjoint_operator<THREADS, WIN>(S, C, r, true, t, r, d1, d2);
+      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, sh, false, t, r, d1, d2);
+      else adjoint_operator<THREADS, WIN>(S, C, r, true, t, r, d1, d2);
       double ts = (double) d1, tt = (double) d2;
       block_sum2<THREADS>(ts, tt, red);
       PH(1)
       if (!(tt > 1e-300)) { status = 2; break; }
       const float omega = (float) (ts / tt);
-      // u += alpha D^-1 p + omega D^-1 s ;  r = s - omega t ;  rho_new = rhat . r
+      // u += alpha M^-1 p + omega M^-1 s ;  r = s - omega t ;  rho_new = rhat . r
       float pa = 0.f, pb = 0.f;
       for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
-        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB];
-        float dq[VB];
+        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB], zq[VB];
 #pragma unroll
         for (int j = 0; j < VB; j++) {
           const int ic = min(i0 + j * THREADS, N - 1);
-          dq[j] = S.dinv[ic]; sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); pq[j] = ld3(p, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
+          sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
+          if constexpr (BLK) { zq[j] = ld3(sh, ic, N); pq[j] = ld3(ph, ic, N); }
+          else { const float di = S.dinv[ic]; zq[j] = sq[j] * di; pq[j] = ld3(p, ic, N) * di; }
         }
 #pragma unroll
         for (int j = 0; j < VB; j++) {
           const int i = i0 + j * THREADS;
           f3 rn = sq[j] - tq[j] * omega;
           if (i < N) {
-            st3(u, i, N, uq[j] + (pq[j] * alpha + sq[j] * omega) * dq[j]);
+            st3(u, i, N, uq[j] + pq[j] * alpha + zq[j] * omega);
             st3(r, i, N, rn);
             pa += dot(rn, hq[j]);
             pb += dot(rn, rn);
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
 #pragma unroll
         for (int j = 0; j < VB; j++) {
           const int i = i0 + j * THREADS;
-          if (i < N) st3(p, i, N, rq[j] + (pq[j] - vq[j] * omega) * beta);
+          if (i < N) { const f3 pn = rq[j] + (pq[j] - vq[j] * omega) * beta; st3(p, i, N, pn); if constexpr (BLK) st3(ph, i, N, pre(i, pn)); }
         }
       }
       __syncthreads();
@@ -557,9 +569,9 @@ static int pick_threads_bwd(int N) {
   return 1024;
 }
 
-template <int THREADS, bool DENSE>
-static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
-  if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
+template <int THREADS, bool DENSE, bool BLK>
+static void launch_adj_b(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+  if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false, false, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
   size_t lds = (size_t) S.win_lds_bytes;
   if (DENSE) lds = std::max(lds, sizeof(float) * (size_t) (3 * S.dense_ld + dense_lds_floats(S.dense_ld, THREADS / 64)));
   static size_t configured[kMaxDevices] = {};        // the attribute is per device: one entry per device this process has used
@@ -567,10 +579,16 @@ static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, i
   (void) hipGetDevice(&dev);
   size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
   if (lds > done || dev >= kMaxDevices) {
-    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, DENSE, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     done = lds;
   }
-  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE, BLK>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+}
+template <int THREADS, bool DENSE>
+static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+  // the block preconditioner belongs to the direct solve (mode 1); the reference's iteration (mode 0) uses P^-1 as the reference does
+  if (A.block_pre && A.mode == 1 && !DENSE) launch_adj_b<THREADS, DENSE, true>(S, W, A, B, st);
+  else launch_adj_b<THREADS, DENSE, false>(S, W, A, B, st);
 }
 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {

@@ -13,6 +13,7 @@
 #include "dc_devlib.h"
 #include "dc_winlib.h"
 #include "dc_cluster.h"
+#include "dc_adjprecond.h"
 #include <algorithm>
 
 namespace dc {
@@ -102,7 +103,7 @@ __device__ __forceinline__ bool adjoint_operator_cl(const DevSystem &S, const De
 
 }  // namespace
 
-template <int THREADS>
+template <int THREADS, bool BLK>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
                                                              BwdArgs A, int b0, int hc_off, int tail_off) {
   const DevSystem &S = *Sp;
@@ -144,6 +145,14 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   float *gx = A.gx + off, *gv = A.gv + off;
   float *gin = W.g + off, *u = W.vnow + off;
   float *r = W.cg_r + off, *p = W.cg_p + off, *v = W.cg_ap + off, *t = W.cg_x + off, *rhat = W.sd_sx + off;   // (detection scratch, idle here)
+  float *ph = W.pre_p + off, *sh = W.pre_s + off, *minv = W.minv + (size_t) b * 9 * N;   // M^-1 p, M^-1 s, the block inverses
+  if constexpr (BLK) {   // K's own 3 x 3 diagonal blocks at this step's x_new, inverted (dc_adjprecond.h); own rows
+    for (int i = r0 + tid; i < r1; i += THREADS)
+      store_block_inverse(elastic_diag_block(S, C.xnew, i), S.mass[i], [&](f3 e) { return contact_JT_cl(S, C, i, e); }, minv, i, N);
+  }
+  // BLK: M^-1 = those block inverses, the vectors M^-1 p / M^-1 s are stored and are what the operator is applied to;
+  // otherwise M^-1 = diag(P)^-1, applied inside the operator
+  auto pre = [&](int i, f3 z) { return BLK ? block_pre(minv, i, N, z) : z; };
   const float h = S.h, h2 = S.h * S.h;
 
   // ---- gradient clipping (Simulation.cpp:1460-1466), u = 0, r = rhat = p = g ----
@@ -195,8 +204,9 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
         if (cycle > 0) q = q - ld3(v, i, N);
         st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
         part_s += dot(q, q);
+        if constexpr (BLK) { q = pre(i, q); st3(ph, i, N, q); }
       }
-      xch_publish_boundary(X, l, R, q.x, q.y, q.z);
+      xch_publish_boundary(X, l, R, q.x, q.y, q.z);      // the operator's input: M^-1 p (BLK), or p itself, scaled by diag(P)^-1 inside the operator
     }
     xch_publish_sums(X, part_s, 0.f, 0.f);
     if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
@@ -211,8 +221,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     if (status != 0) break;
     for (int k = kdone; k < kcap && status == 0; k++, kdone++) {
       float d1, d2;
-      // v = K D^-1 p ;  alpha = rho / (rhat . v)
-      if (!adjoint_operator_cl<THREADS>(S, CL, C, X, p, true, v, rhat, d1, d2)) return;
+      // v = K M^-1 p ;  alpha = rho / (rhat . v)
+      if (!adjoint_operator_cl<THREADS>(S, CL, C, X, BLK ? ph : p, !BLK, v, rhat, d1, d2)) return;
       if (!xch_allsum<THREADS>(X, d1, 0.f, 0.f, sums)) return;
       const double rv = sums[0];
       if (!(fabs(rv) > 1e-300)) { status = 2; break; }
@@ -229,8 +239,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
           const int l = l0 + j * THREADS, i = r0 + l;
           f3 s = rq[j] - vq[j] * alpha;
           if (i >= r1) s = mk(0, 0, 0);
-          if (i < r1) { st3(r, i, N, s); part_s += dot(s, s); }
-          if (l < R) xch_publish_boundary(X, l, R, s.x, s.y, s.z);
+          if (i < r1) { st3(r, i, N, s); part_s += dot(s, s); if constexpr (BLK) { s = pre(i, s); st3(sh, i, N, s); } }
+          if (l < R) xch_publish_boundary(X, l, R, s.x, s.y, s.z);      // boundary rows of M^-1 s
         }
       }
       {
@@ -242,11 +252,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       const double ss = sums[0];
       iters++;
       if (ss <= stop) {
-        for (int i = r0 + tid; i < r1; i += THREADS) st3(u, i, N, ld3(u, i, N) + ld3(p, i, N) * (alpha * S.dinv[i]));
+        for (int i = r0 + tid; i < r1; i += THREADS) st3(u, i, N, ld3(u, i, N) + (BLK ? ld3(ph, i, N) * alpha : ld3(p, i, N) * (alpha * S.dinv[i])));
         rr = ss; status = 1; break;
       }
-      // t = K D^-1 s ;  omega = (t . s) / (t . t)
-      if (!adjoint_operator_cl<THREADS>(S, CL, C, X, r, true, t, r, d1, d2)) return;
+      // t = K M^-1 s ;  omega = (t . s) / (t . t)
+      if (!adjoint_operator_cl<THREADS>(S, CL, C, X, BLK ? sh : r, !BLK, t, r, d1, d2)) return;
       if (!xch_allsum<THREADS>(X, d1, d2, 0.f, sums)) return;
       const double ts = sums[0], tt = sums[1];
       if (!(tt > 1e-300)) { status = 2; break; }
@@ -254,19 +264,20 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       // u += alpha D^-1 p + omega D^-1 s ;  r = s - omega t ;  rho_new = rhat . r
       float pa = 0.f, pb = 0.f;
       for (int l0 = tid; l0 < R; l0 += VB * THREADS) {
-        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB];
-        float dq[VB];
+        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB], zq[VB];
 #pragma unroll
         for (int j = 0; j < VB; j++) {
           const int ic = min(r0 + l0 + j * THREADS, r1 - 1);
-          dq[j] = S.dinv[ic]; sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); pq[j] = ld3(p, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
+          sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
+          if constexpr (BLK) { zq[j] = ld3(sh, ic, N); pq[j] = ld3(ph, ic, N); }
+          else { const float di = S.dinv[ic]; zq[j] = sq[j] * di; pq[j] = ld3(p, ic, N) * di; }
         }
 #pragma unroll
         for (int j = 0; j < VB; j++) {
           const int i = r0 + l0 + j * THREADS;
           f3 rn = sq[j] - tq[j] * omega;
           if (i < r1) {
-            st3(u, i, N, uq[j] + (pq[j] * alpha + sq[j] * omega) * dq[j]);
+            st3(u, i, N, uq[j] + pq[j] * alpha + zq[j] * omega);
             st3(r, i, N, rn);
             pa += dot(rn, hq[j]);
             pb += dot(rn, rn);
@@ -293,8 +304,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
           const int l = l0 + j * THREADS, i = r0 + l;
           f3 pn = rq[j] + (pq[j] - vq[j] * omega) * beta;
           if (i >= r1) pn = mk(0, 0, 0);
-          if (i < r1) st3(p, i, N, pn);
-          if (l < R) xch_publish_boundary(X, l, R, pn.x, pn.y, pn.z);
+          if (i < r1) { st3(p, i, N, pn); if constexpr (BLK) { pn = pre(i, pn); st3(ph, i, N, pn); } }
+          if (l < R) xch_publish_boundary(X, l, R, pn.x, pn.y, pn.z);      // boundary rows of M^-1 p
         }
       }
       xch_publish_sums(X, 0.f, 0.f, 0.f);
@@ -434,9 +445,15 @@ hipError_t launch_adjoint_step_cluster(const DevSystem &S, const DevCluster &CL,
   const int tail_off = hc_off + 6 * CL.HB;
   const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
   if (lds > 160 * 1024 - 256 || A.mode != 1) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_adjoint_step_cl<THREADS>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, hc_off, tail_off);
+  if (A.block_pre) {
+    hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, true>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, hc_off, tail_off);
+  } else {
+    hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, false>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, hc_off, tail_off);
+  }
   return hipGetLastError();
 }
 

@@ -109,6 +109,9 @@ struct DevWork {
   float *cg_r, *cg_p, *cg_ap, *cg_x;   // [B][3][N] each
   float *corner;   // [B][3][NC] per-constraint-corner contributions
   float4 *ap4;     // [B][N] per-vertex float4 scratch of the resident PCG (A p, one 16-byte access per vertex)
+  // adjoint, direct solve: preconditioned search direction / residual (M^-1 p, M^-1 s) and the 3 x 3 block inverses (dc_adjprecond.h)
+  float *pre_p, *pre_s;   // [B][3][N]
+  float *minv;            // [B][9][N]
   // self-collision detection / layering scratch (k_self_detect)
   int *sd_cell, *sd_order;      // [B][N]
   float *sd_sx;                 // [B][3][N] positions in cell-sorted order
@@ -164,6 +167,7 @@ struct BwdArgs {
   float bwd_tol, cg_tol, clip_thr, rel_tol;
   int mode;                     // 0: reference fixed-point iteration (+ direct fallback), 1: direct Krylov solve
   int it_cap, cg_max, is_start, clip, stall_window;
+  int block_pre;                // direct solve: 1 = block-Jacobi from K's own diagonal blocks (dc_adjprecond.h), 0 = Jacobi from diag(P)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;
   size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements)

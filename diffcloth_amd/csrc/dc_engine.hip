@@ -203,6 +203,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.mode = c->params.adjoint_mode;
   A.rel_tol = (float) (c->params.adjoint_rel_tol > 0 ? c->params.adjoint_rel_tol : 1e-6);
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
+  { const char *envp = getenv("DC_BLOCK_PRE"); A.block_pre = envp ? (envp[0] != '0') : (c->params.adjoint_block_precond != 0); }   // (development switch)
   A.nsteps = 1; A.slot = slot;
   A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   A.slot_param = (size_t) c->B * 8; A.slot_xf = (size_t) c->B * 3 * c->S.Af; A.slot_stats = (size_t) c->B;
@@ -376,7 +377,7 @@ void dc_default_params(dc_params *p) {
   p->gravity_enabled = 1; p->contact_enabled = 1; p->selfcollision_enabled = 0;
   p->gradient_clipping = 1; p->gradient_clipping_threshold = 16.0;                                      // Simulation.h:330-331
   p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 0;
-  p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6;
+  p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6; p->adjoint_block_precond = 1;
   p->max_self_contacts = 0;      /* sized from the mesh in dc_build */
 }
 
@@ -756,6 +757,9 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->W.cg_x, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.corner, (size_t) B * 3 * NC))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.ap4, (size_t) B * N))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.pre_p, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.pre_s, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.minv, (size_t) B * 9 * N))) return rc;
   {
     const int cap = c->S.self_cap;
     c->self_cap = cap;

@@ -172,6 +172,14 @@ PYBIND11_MODULE(diffcloth_py, m) {
       .def_readonly("randSeed", &BackwardTaskInformation::randSeed)
       .def_readonly("srandSeed", &BackwardTaskInformation::srandSeed);
 
+  // python_interface.cpp:245-249
+  py::class_<CorresPondenceTargetInfo>(m, "CorresPondenceTargetInfo")
+      .def(py::init<>())
+      .def_readwrite("frameIdx", &CorresPondenceTargetInfo::frameIdx)
+      .def_property("targetPos", [](const CorresPondenceTargetInfo &c) { return toNp(c.targetPos); },
+                    [](CorresPondenceTargetInfo &c, const NpArr &a) { VecXd v = toVec(a); for (int d = 0; d < 3; d++) c.targetPos[d] = v.at(d); })
+      .def_readwrite("particleIndices", &CorresPondenceTargetInfo::particleIndices);
+
   py::class_<LossInfo>(m, "LossInfo")
       .def_property("targetLoc", [](const LossInfo &l) { return toNp(l.targetLoc); },
                     [](LossInfo &l, const NpArr &a) { VecXd v = toVec(a); for (int d = 0; d < 3; d++) l.targetLoc[d] = v.at(d); })
@@ -179,7 +187,8 @@ PYBIND11_MODULE(diffcloth_py, m) {
                     [](LossInfo &l, const NpArr &a) { VecXd v = toVec(a); for (int d = 0; d < 3; d++) l.targetTranslation[d] = v.at(d); })
       .def_property("targetFrameShape",
                     [](const LossInfo &l) { py::list out; for (auto &p : l.targetFrameShape) out.append(py::make_tuple(p.first, toNp(p.second))); return out; },
-                    [](LossInfo &l, const std::vector<std::pair<int, NpArr>> &v) { l.targetFrameShape.clear(); for (auto &p : v) l.targetFrameShape.push_back({p.first, toVec(p.second)}); });
+                    [](LossInfo &l, const std::vector<std::pair<int, NpArr>> &v) { l.targetFrameShape.clear(); for (auto &p : v) l.targetFrameShape.push_back({p.first, toVec(p.second)}); })
+      .def_readwrite("targetPosPairs", &LossInfo::targetPosPairs);      // python_interface.cpp:256 (ASSISTED_DRESSING_KEYPOINTS targets)
 
   py::class_<Primitive> primitive(m, "Primitive");
   py::enum_<PrimitiveType>(primitive, "PrimitiveType")

@@ -76,6 +76,10 @@ typedef struct dc_params {
    * block-Jacobi preconditioned BiCGSTAB on (P - dP^T) run to adjoint_rel_tol (relative residual; <=0: 1e-6). */
   int adjoint_mode;
   double adjoint_rel_tol;
+  /* direct adjoint solve: 1 (default) = block-Jacobi preconditioner from the 3x3 diagonal blocks of K = P - dP^T itself, rebuilt
+   * from x_new every backward step (in-plane stiff / normal soft, sticking contacts decoupled); 0 = the forward solve's Jacobi
+   * diag(P)^-1. Changes the iteration count only, not what the solve converges to.                                      */
+  int adjoint_block_precond;
   int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: sized from the mesh,
                                        max(2048, N) pairs (at most 16000); overflow is reported, never silent: dc_step_stats */
 } dc_params;

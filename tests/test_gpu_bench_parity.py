@@ -1,6 +1,6 @@
 """Parity gate AT THE CONFIGURATION bench.py MEASURES: the C4 workload (100 x 100 grid, N = 10 000, 256 rollouts, flap folded
 back so that every step carries ~500 loaded self contacts), bench.py's own solver settings (forward_tol 1e-8, cg_rel_tol 1e-4,
-adjoint_mode 1 with adjoint_rel_tol 2e-7, gradient clipping on, self-collision on) and its own code path (dc_rollout_forward /
+adjoint_mode 1 with adjoint_rel_tol 1e-6, gradient clipping on, self-collision on) and its own code path (dc_rollout_forward /
 dc_seed_gradient / dc_rollout_backward). Eight sampled rollouts over three consecutive time steps are compared, teacher-forced
 (each step from the GPU's own previous state / carried gradient), against the fp64 oracle run with the direct adjoint solve:
 positions <= 4.5e-5 (1e-5 L); gradients against the oracle at the same settings: median over the samples <= 1.5e-4
@@ -40,7 +40,7 @@ def rel(a, b):
 def bench_args(**over):
     """bench.py's defaults, without touching sys.argv."""
     d = dict(grid=100, fold_rows=5, fold_gap=0.02, flap_force=2.0, h=1.0 / 180, fwd_tol=1e-8, bwd_tol=5e-4, cg_tol=1e-4, cg_max=500,
-             adjoint_mode=1, adjoint_rel_tol=2e-7, selfcollision=1, warmup=5, cpu_threads=0)
+             adjoint_mode=1, adjoint_rel_tol=1e-6, block_precond=0, selfcollision=1, warmup=5, cpu_threads=0)
     d.update(over)
     return types.SimpleNamespace(**d)
 

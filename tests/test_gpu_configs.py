@@ -46,7 +46,11 @@ def settle(o, x, v, xf, steps, tol=1e-6):
     return f32(x), f32(v)
 
 
-def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None):
+def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, truth=None):
+    """truth: the same oracle at a forward tolerance of 1e-13 (the step's fixed point). Where the PD iteration contracts slowly the
+    stopping rule |x_new - x_now| / N < tol leaves BOTH implementations well short of that fixed point, a few iterations apart
+    from each other; then the meaningful statement is not |gpu - oracle| but each side's distance from the fixed point, and the
+    gate becomes: the GPU is no further from it than 1.5 x the fp64 oracle run at the same tolerance (or within grad_tol)."""
     B = len(X0)
     e.alloc_batch(B, 1)
     if mus is not None:
@@ -68,6 +72,20 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None):
         assert st["prim_contacts"][b] == ref["nprim"] and st["self_contacts"][b] == ref["nself"]
         rb = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
         worst["dx"] = max(worst["dx"], np.abs(x1[b] - ref["x"]).max())
+        if truth is not None:
+            if mus is not None:
+                for g in range(mus.shape[1]):
+                    truth.set_mu(g, float(mus[b, g]))
+            rt_ = truth.step(X0[b], V0[b], None if XF is None else XF[b])
+            assert rt_["converged"]
+            tb = truth.step_backward(rt_["id"], gx[b], gv[b], is_start=False, direct=True)
+            for key in ("dL_dx", "dL_dv") + (("dL_dxfixed",) if XF is not None else ()):
+                eg, eo = rel(gb[key][b], tb[key]), rel(rb[key], tb[key])
+                print(f"\n[config] rollout {b} {key}: distance from the step converged to 1e-13 (PD iterations {rt_['iters']}): GPU {eg:.2e}, fp64 oracle at the "
+                      f"same tolerance {eo:.2e} (PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}); GPU vs oracle {rel(gb[key][b], rb[key]):.2e}; "
+                      f"|x - x*| GPU {np.abs(x1[b] - rt_['x']).max():.1e} oracle {np.abs(ref['x'] - rt_['x']).max():.1e}")
+                assert eg <= max(grad_tol, 1.5 * eo), (b, key, eg, eo)
+            continue
         worst["gx"] = max(worst["gx"], rel(gb["dL_dx"][b], rb["dL_dx"]))
         worst["gv"] = max(worst["gv"], rel(gb["dL_dv"][b], rb["dL_dv"]))
         if XF is not None:
@@ -90,8 +108,8 @@ def test_c3_hat_batch_64():
     center = f32(scenes.hat_head_center(rmin, rmax, cfg["sphere_radius"]))
     att = cfg["attachments"]
     # forward threshold 1e-8 as hatController.py:83; this stiff scene (k_bend 120, k_att 1e4) contracts at ~0.995 per PD
-    # iteration, so the two sides stop a few iterations apart: |dx| ~ 1e-5 and, through the moved linearisation point,
-    # 1e-3-level gradient differences (the 1e-4 bound at identical linearisation points: sock case below, test_gpu_parity.py)
+    # iteration, so the stopping rule leaves both sides short of the step's fixed point and a few iterations apart from each
+    # other; what is gated is each side's distance from that fixed point (see check_rollouts)
     o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-8,
                    bwd_tol=1e-9, attachments=att, selfcollision=False, gradient_clipping=False)
     o.add_sphere(center, cfg["sphere_radius"], cfg["sphere_mu"])
@@ -111,7 +129,12 @@ def test_c3_hat_batch_64():
     V0 = np.stack([f32(v + 0.01 * rng.standard_normal(x.size)) for _ in range(B)])
     XF = np.stack([f32(xf + np.tile([0.0, -0.05, -0.3], 2) + 0.02 * rng.standard_normal(6)) for _ in range(B)])
     mus = f32(rng.uniform(0.05, 0.6, (B, 1)))
-    check_rollouts(o, e, X0, V0, XF, sample=(0, 17, 63), pos_tol=6e-5, grad_tol=3e-4, mus=mus)
+    # measure instead of assert — both sides against the step's fixed point (oracle at 1e-13)
+    ot = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-13,
+                    bwd_tol=1e-9, attachments=att, selfcollision=False, gradient_clipping=False, pd_iter_cap=40000)
+    ot.add_sphere(center, cfg["sphere_radius"], cfg["sphere_mu"])
+    ot.build()
+    check_rollouts(o, e, X0, V0, XF, sample=(0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus, truth=ot)
 
 
 def test_c5_sock_batch_512():

@@ -14,7 +14,7 @@ def test_module_surface():
     for fn in ["makeSim", "makeOptimizeHelper", "makeOptimizeHelperWithSim", "enableOpenMP", "render"]:
         assert callable(getattr(d, fn)), fn
     for cls in ["WindConfig", "SceneConfiguration", "PrimitiveCollisionInformation", "SelfCollisionInformation",
-                "ForwardInformation", "BackwardInformation", "BackwardTaskInformation", "LossInfo", "Primitive",
+                "ForwardInformation", "BackwardInformation", "BackwardTaskInformation", "LossInfo", "CorresPondenceTargetInfo", "Primitive",
                 "Simulation", "OptimizeHelper"]:
         assert hasattr(d, cls), cls
     sim_attrs = ["taskLossInfo", "primitives", "sceneConfig", "forwardRecords", "useCustomRLFixedPoint", "perStepGradient",
@@ -32,6 +32,11 @@ def test_module_surface():
         assert hasattr(d.BackwardInformation, a), a
     for a in ["taskInfo", "lossInfo", "lossType", "sim", "forward_steps"]:
         assert hasattr(d.OptimizeHelper, a), a
+    for a in ["targetLoc", "targetTranslation", "targetFrameShape", "targetPosPairs"]:      # python_interface.cpp:252-256
+        assert hasattr(d.LossInfo, a), a
+    c = d.CorresPondenceTargetInfo()                                                        # python_interface.cpp:245-249
+    c.frameIdx = 7; c.targetPos = [1.0, 2.0, 3.0]; c.particleIndices = [4, 5]
+    assert c.frameIdx == 7 and list(c.targetPos) == [1.0, 2.0, 3.0] and list(c.particleIndices) == [4, 5]
     assert d.WindConfig.WIND_SIN != d.WindConfig.NO_WIND
     assert d.Primitive.PrimitiveType.SPHERE is not None
 

@@ -28,6 +28,10 @@ CFG
     bigk1) export DC_CLUSTER=1; TAILN=8 run bigk1 python -m pytest tests/test_gpu_fullsize.py -q -s -k beyond; unset DC_CLUSTER ;;
     bigk4) export DC_CLUSTER=4; TAILN=8 run bigk4 python -m pytest tests/test_gpu_fullsize.py -q -s -k beyond; unset DC_CLUSTER ;;
     refcall) TAILN=12 run refcall python -m pytest tests/test_gpu_reference_callers.py tests/test_gpu_rccl.py -q -s ;;
+    hat) TAILN=14 run hat python -m pytest tests/test_gpu_configs.py -q -s -k hat ;;
+    benchj) export DC_BLOCK_PRE=0; TAILN=3 run benchj python bench.py --steps 20 --warmup 5 --cpu-steps 0 --tshirt 0; unset DC_BLOCK_PRE ;;
+    benchq) TAILN=3 run benchq python bench.py --steps 20 --warmup 5 --cpu-steps 0 --tshirt 0 ;;
+    cfgs) TAILN=20 run cfgs python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_random_scenes.py -q ;;
     fallb) TAILN=30 run fallb python -m pytest tests/test_gpu_fallbacks.py -q ;;
     parity) TAILN=40 run parity python -m pytest tests/test_gpu_bench_parity.py -q -s ;;
     all) TAILN=15 run all python -m pytest tests -m gpu -q -x ;;
