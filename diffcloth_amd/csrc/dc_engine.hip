@@ -246,13 +246,14 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
     const int Rc = own_w * w;
     if ((long long) (K - 1) * Rc >= N) break;           // a part would be empty
     if (Rc < HB) break;                                  // halo rows must come from the direct neighbours only
-    if (Rc < 512 && !forced) break;                      // fewer rows than threads: splitting further only adds exchanges
+    if (Rc < 1024 && !forced) break;                     // small parts: the exchanges cost more than the rows they save (measured: the
+                                                         // 1426-vertex T-shirt is fastest on ONE workgroup, tools/bench_tshirt_k.py)
     int v = 0;
     for (int a : allowed) if (a * 512 >= Rc) { v = a; break; }
     if (v == 0) continue;                                // more rows per part than the kernel holds in registers: more windows do not help
     if (!HW.build_own(H, own_w)) continue;
     const int win_floats = (int) (HW.lds_bytes / 4);
-    const int fwd = std::max(std::max(3 * (Rc + 2 * HB), win_floats), kSelfDetectLdsInts);
+    const int fwd = std::max(std::max((v <= 6 ? 6 : 3) * (Rc + 2 * HB), win_floats), kSelfDetectLdsInts);      // (<= 6 rows per thread: pipelined CG, two gather arrays)
     const int bwd = (win_floats + 3) / 4 * 4 + 6 * HB;
     if (fwd + 4 > lds_cap || bwd + 4 > lds_cap) continue;
     // the element reach of every window must stay inside the boundary rows its part receives

@@ -17,10 +17,12 @@
 #include "dc_pklib.h"
 #include "dc_cluster.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace dc {
 
-template <int THREADS, int VPT, bool DETECT>
+// PIPE: the inner solve is the pipelined CG of Ghysels & Vanroose (one exchange per iteration instead of two), see the loop
+template <int THREADS, int VPT, bool DETECT, bool PIPE>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
                                                         FwdArgs A, int b0, int tail_off, int fric_floats) {
   const DevSystem &S = *Sp;
@@ -38,6 +40,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   if (!xch_hello<THREADS>(X)) return;
   float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
   float *gz = lds + 2 * GL;
+  float2 *gxy1 = (float2 *) (lds + 3 * GL);   // PIPE: second gather array (the iterations alternate between the two)
+  float *gz1 = lds + 5 * GL;
   const int N = S.N;
   const int r0 = part * R, r1 = min(N, r0 + R);
   const int nch = R >> 6, cbase = r0 >> 6;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       rz = sums[0];
     }
     // ap = Ahat p on the own rows (p incl. halo in the gather array), part2 += <p, ap>
-    auto spmv = [&](int wz, float &part2) {
+    auto spmv = [&](int wz, const float2 *vxy, const float *vz, float &part2) {
       int4 nxt[PB];
       load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
 #pragma unroll
@@ -202,14 +206,14 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         for (int j = 0; j < PB; j++) cur[j] = nxt[j];
         if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
         const int li = HB + lcc * 64 + lane;
-        const float2 pxy = gxy[li];
-        const float pz = gz[li];
+        const float2 pxy = vxy[li];
+        const float pz = vz[li];
         float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
         const int base = li - 512;
-        consume_p(cur, gxy, gz, base, ax, ay, az);
+        consume_p(cur, vxy, vz, base, ax, ay, az);
         for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
           load_batch(cur, row, s0);
-          consume_p(cur, gxy, gz, base, ax, ay, az);
+          consume_p(cur, vxy, vz, base, ax, ay, az);
         }
         ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
         part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;
@@ -217,7 +221,83 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       }
     };
     __syncthreads();
-    // ---- global step: plain CG on the scaled system = Jacobi PCG on P dv = rhs ----
+    // ---- global step: CG on the scaled system = Jacobi PCG on P dv = rhs ----
+    if constexpr (PIPE) {
+      // Pipelined CG (Ghysels & Vanroose 2014, unpreconditioned form — the system is already scaled): besides x, r, p it carries
+      // w = A r, s = A p, z = A s by recurrence, so that both inner products of an iteration, (r, r) and (w, r), are available
+      // BEFORE its one matrix product q = A w. They travel in the same exchange as the boundary rows of w that product needs:
+      // ONE exchange per iteration instead of two, one more product per solve, three more axpys per iteration. Same iterates
+      // as CG in exact arithmetic; in fp32 the recurrences cost about a digit of attainable accuracy, far below cg_rel_tol.
+      if (rz > 1e-300) {
+        const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+        float ww[VPT][3], pp[VPT][3], ss[VPT][3], zz[VPT][3];
+        {
+          int zs;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+          float unused = 0.f;
+          spmv(wv + zs, gxy, gz, unused);            // w = A r (r and its halo are in the first gather array)
+        }
+#pragma unroll
+        for (int k = 0; k < VPT; k++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) { ww[k][c] = ap[k][c]; pp[k][c] = 0.f; ss[k][c] = 0.f; zz[k][c] = 0.f; }
+        float alpha_old = 1.f;
+        double gamma_old = 1.0;
+        for (int it = 0;;) {
+          int zs;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+          const int wz = wv + zs, tz = tid + zs;
+          float2 *cxy = (it & 1) ? gxy : gxy1;        // this iteration's gather array for w (the other one may still be read)
+          float *cz = (it & 1) ? gz : gz1;
+          float pg = 0.f, pd = 0.f;
+          X.site = 6;
+          xch_begin(X);
+#pragma unroll
+          for (int k = 0; k < VPT; k++) {
+            const int l = tz + k * THREADS;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { pg = fmaf(rr[k][c], rr[k][c], pg); pd = fmaf(ww[k][c], rr[k][c], pd); }
+            if (l < R) {
+              cxy[HB + l] = make_float2(ww[k][0], ww[k][1]); cz[HB + l] = ww[k][2];
+              xch_publish_boundary(X, l, R, ww[k][0], ww[k][1], ww[k][2]);
+            }
+          }
+          xch_publish_sums(X, pg, pd, 0.f);
+          f3 hv[HPT];
+          if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+          const double gamma = sums[0], delta = sums[1];
+          if (!(gamma > stop) || it >= A.cg_max) break;
+          float beta = 0.f, alpha;
+          if (it == 0) alpha = (float) (gamma / delta);
+          else {
+            beta = (float) (gamma / gamma_old);
+            alpha = (float) (gamma / (delta - (double) beta * gamma / (double) alpha_old));
+          }
+          if (!(alpha > 0.f) || !isfinite(alpha)) break;        // breakdown: keep the iterate reached so far
+#pragma unroll
+          for (int q = 0; q < HPT; q++) {
+            const int j = tid + q * THREADS;
+            if (j < 2 * HB) { const int li = j < HB ? j : R + j; cxy[li] = make_float2(hv[q].x, hv[q].y); cz[li] = hv[q].z; }
+          }
+          __syncthreads();
+          float unused = 0.f;
+          spmv(wz, cxy, cz, unused);                  // q = A w
+#pragma unroll
+          for (int k = 0; k < VPT; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              zz[k][c] = fmaf(beta, zz[k][c], ap[k][c]);
+              ss[k][c] = fmaf(beta, ss[k][c], ww[k][c]);
+              pp[k][c] = fmaf(beta, pp[k][c], rr[k][c]);
+              xx[k][c] = fmaf(alpha, pp[k][c], xx[k][c]);
+              rr[k][c] = fmaf(-alpha, ss[k][c], rr[k][c]);
+              ww[k][c] = fmaf(-alpha, zz[k][c], ww[k][c]);
+            }
+          gamma_old = gamma; alpha_old = alpha;
+          it++; cg_total++;
+        }
+      }
+    } else
     if (rz > 1e-300) {
       const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
       for (int it = 0; it < A.cg_max;) {
@@ -225,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         int zs;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         const int wz = wv + zs, tz = tid + zs;
-        spmv(wz, part2);
+        spmv(wz, gxy, gz, part2);
         X.site = 6;
         if (!xch_allsum<THREADS>(X, part2, 0.f, 0.f, sums)) return;
         const float alpha = (float) (rz / sums[0]);
@@ -335,25 +415,31 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   }   // step
 }
 
-template <int VPT, bool DETECT>
+template <int VPT, bool DETECT, bool PIPE>
 static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
   constexpr int THREADS = 512;
   const int GL = CL.R + 2 * CL.HB;
-  int floats = std::max(3 * GL, CL.win_lds_bytes / 4);
+  int floats = std::max((PIPE ? 6 : 3) * GL, CL.win_lds_bytes / 4);
   const int fric_floats = floats;      // LDS offered to the layered friction pass: the same with and without the inlined detection
   if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
   const int tail_off = (floats + 3) / 4 * 4;
   const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
   if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, tail_off, fric_floats);
+  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT, PIPE>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, tail_off, fric_floats);
   return hipGetLastError();
 }
 
 // nb rollouts starting at b0, K workgroups each; the caller has zeroed the exchange area and made sure K nb <= CUs.
 hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
-#define DC_CL_CASE(V) case V: return A.inline_detect ? launch_cl_inst<V, true>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false>(S, CL, W, A, b0, nb, st);
+  // Pipelined CG (one exchange per iteration, needs <= 6 rows per thread for its seven row vectors) is OFF unless DC_PIPECG=1
+  // (development switch). Measured r02v, C4 at 32 rollouts x 8 workgroups: forward 8.77 -> 7.99 ms per step (+8 % rollout-steps/s),
+  // same PD / CG iteration counts — but its recurrences for A r, A p, A s drift in fp32: at N = 16 384 (36 iterations per solve)
+  // the converged positions moved by 7e-5 against the fp64 oracle (bound 4.5e-5; the two-exchange CG: 1.2e-7). Parity first.
+  static const bool pipe_ok = getenv("DC_PIPECG") && getenv("DC_PIPECG")[0] == '1';
+#define DC_CL_CASE(V) case V: if (pipe_ok && V <= 6) return A.inline_detect ? launch_cl_inst<V, true, (V <= 6)>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, (V <= 6)>(S, CL, W, A, b0, nb, st); \
+                              return A.inline_detect ? launch_cl_inst<V, true, false>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, false>(S, CL, W, A, b0, nb, st);
   switch (CL.pk_vpt) {
     DC_CL_CASE(1) DC_CL_CASE(2) DC_CL_CASE(3) DC_CL_CASE(4) DC_CL_CASE(6) DC_CL_CASE(8) DC_CL_CASE(12)
     default: return hipErrorInvalidValue;

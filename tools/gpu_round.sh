@@ -32,18 +32,19 @@ CFG
     benchj) export DC_BLOCK_PRE=0; TAILN=3 run benchj python bench.py --steps 20 --warmup 5 --cpu-steps 0 --tshirt 0; unset DC_BLOCK_PRE ;;
     benchq) TAILN=3 run benchq python bench.py --steps 20 --warmup 5 --cpu-steps 0 --tshirt 0 ;;
     cfgs) TAILN=20 run cfgs python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_random_scenes.py -q ;;
+    b32nopipe) export DC_PIPECG=0; TAILN=2 run b32nopipe python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --tshirt 0; unset DC_PIPECG ;;
     fallb) TAILN=30 run fallb python -m pytest tests/test_gpu_fallbacks.py -q ;;
     parity) TAILN=40 run parity python -m pytest tests/test_gpu_bench_parity.py -q -s ;;
     all) TAILN=15 run all python -m pytest tests -m gpu -q -x ;;
     rest) TAILN=15 run rest python -m pytest tests -m gpu -q --deselect tests/test_gpu_bench_parity.py --deselect tests/test_gpu_cluster.py ;;
     bench) TAILN=3 run bench python bench.py --steps 20 --warmup 5 ;;
-    bench32) TAILN=3 run bench32 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 ;;
+    bench32) TAILN=3 run bench32 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --tshirt 0 ;;
     b32f0) TAILN=2 run b32f0 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --fold-rows 0 ;;
     b32f0k1) TAILN=2 run b32f0k1 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --fold-rows 0 --cluster 1 ;;
     b32k4) TAILN=2 run b32k4 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 4 ;;
     b32k2) TAILN=2 run b32k2 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 2 ;;
-    b64) TAILN=2 run b64 python bench.py --steps 20 --warmup 5 --total-batch 64 --cpu-steps 0 ;;
-    b128) TAILN=2 run b128 python bench.py --steps 20 --warmup 5 --total-batch 128 --cpu-steps 0 ;;
+    b64) TAILN=2 run b64 python bench.py --steps 20 --warmup 5 --total-batch 64 --cpu-steps 0 --tshirt 0 ;;
+    b128) TAILN=2 run b128 python bench.py --steps 20 --warmup 5 --total-batch 128 --cpu-steps 0 --tshirt 0 ;;
     g128) TAILN=2 run g128 python bench.py --steps 8 --warmup 4 --grid 128 --fold-rows 0 --cpu-steps 0 ;;
     g128k1) TAILN=2 run g128k1 python bench.py --steps 8 --warmup 4 --grid 128 --fold-rows 0 --cpu-steps 0 --cluster 1 ;;
     bench32k1) TAILN=3 run bench32k1 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 1 ;;
