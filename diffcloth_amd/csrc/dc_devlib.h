@@ -339,6 +339,7 @@ __device__ __forceinline__ void self_JT_layers(const DevSystem &S, const SelfRec
 // workgroup barrier), and the results are scattered back. `lds` offers `lds_floats` floats; returns false (nothing done)
 // when the working set does not fit, and the caller takes the global-memory version.
 __device__ __forceinline__ int self_lds_need(int M, int C, int nl) { return 7 * M + 8 * C + nl + 2; }
+constexpr int kWideLayers = 8;      // up to this many layers the LDS passes use the whole workgroup with a barrier per layer
 
 template <int THREADS, class FV, class RV>
 __device__ __forceinline__ bool self_friction_layers_lds_v(const DevSystem &S, const SelfRec &R, int b, const FV &f, const RV &r,
@@ -365,26 +366,37 @@ __device__ __forceinline__ bool self_friction_layers_lds_v(const DevSystem &S, c
   for (int k = tid; k < C; k += THREADS) ln[k] = nrm[k];
   for (int l = tid; l <= nl; l += THREADS) loff[l] = meta[2 + l];
   __syncthreads();
-  if (tid < 64) {
+  auto contact = [&](int k) {
+    const float4 n4 = ln[k];
+    const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
+    const f3 n = mk(n4.x, n4.y, n4.z);
+    const float iA = lim[sa], iB = lim[sb];
+    f3 rA = mk(lr[sa], lr[M + sa], lr[2 * M + sa]), rB = mk(lr[sb], lr[M + sb], lr[2 * M + sb]);
+    f3 d = (mk(lf[sa], lf[M + sa], lf[2 * M + sa]) + rA) * iA - (mk(lf[sb], lf[M + sb], lf[2 * M + sb]) + rB) * iB;
+    ld[k] = make_float4(d.x, d.y, d.z, 0.f);
+    f3 ri = dry_friction(n, d, kClothMu) * (1.0f / (iA + iB));           // k = mA mB / (mA + mB)
+    rA = rA + ri; rB = rB - ri;
+    lr[sa] = rA.x; lr[M + sa] = rA.y; lr[2 * M + sa] = rA.z;
+    lr[sb] = rB.x; lr[M + sb] = rB.y; lr[2 * M + sb] = rB.z;
+  };
+  if (nl <= kWideLayers) {
+    // few, wide layers (a fold: hundreds of vertex-disjoint pairs in layer 0): every thread takes contacts, a barrier per layer
     for (int l = 0; l < nl; l++) {
       const int k1 = loff[l + 1];
-      for (int k = loff[l] + tid; k < k1; k += 64) {
-        const float4 n4 = ln[k];
-        const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
-        const f3 n = mk(n4.x, n4.y, n4.z);
-        const float iA = lim[sa], iB = lim[sb];
-        f3 rA = mk(lr[sa], lr[M + sa], lr[2 * M + sa]), rB = mk(lr[sb], lr[M + sb], lr[2 * M + sb]);
-        f3 d = (mk(lf[sa], lf[M + sa], lf[2 * M + sa]) + rA) * iA - (mk(lf[sb], lf[M + sb], lf[2 * M + sb]) + rB) * iB;
-        ld[k] = make_float4(d.x, d.y, d.z, 0.f);
-        f3 ri = dry_friction(n, d, kClothMu) * (1.0f / (iA + iB));           // k = mA mB / (mA + mB)
-        rA = rA + ri; rB = rB - ri;
-        lr[sa] = rA.x; lr[M + sa] = rA.y; lr[2 * M + sa] = rA.z;
-        lr[sb] = rB.x; lr[M + sb] = rB.y; lr[2 * M + sb] = rB.z;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");             // compiler: keep the layers' LDS accesses in order
+      for (int k = loff[l] + tid; k < k1; k += THREADS) contact(k);
+      __syncthreads();
     }
+  } else {
+    // many, thin layers (chains): ONE wave walks them, its LDS operations execute in program order — no barrier per layer
+    if (tid < 64) {
+      for (int l = 0; l < nl; l++) {
+        const int k1 = loff[l + 1];
+        for (int k = loff[l] + tid; k < k1; k += 64) contact(k);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");             // compiler: keep the layers' LDS accesses in order
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; r.st(v, lr[s]); r.st(N + v, lr[M + s]); r.st(2 * N + v, lr[2 * M + s]); }
   for (int k = tid; k < C; k += THREADS) dvec[k] = ld[k];
   __syncthreads();
@@ -417,23 +429,32 @@ __device__ __forceinline__ bool self_JT_layers_lds_v(const DevSystem &S, const S
   for (int k = tid; k < C; k += THREADS) { ln[k] = nrm[k]; ld[k] = dvec[k]; }
   for (int l = tid; l <= nl; l += THREADS) loff[l] = meta[2 + l];
   __syncthreads();
-  if (tid < 64) {
+  auto contact = [&](int k) {
+    const float4 n4 = ln[k], d4 = ld[k];
+    const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
+    const float iA = lim[sa], iB = lim[sb];
+    f3 zA = mk(lz[sa], lz[M + sa], lz[2 * M + sa]), zB = mk(lz[sb], lz[M + sb], lz[2 * M + sb]);
+    f3 g = dri_dfi_T(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * (1.0f / (iA + iB));
+    zA = zA + g * iA; zB = zB - g * iB;
+    lz[sa] = zA.x; lz[M + sa] = zA.y; lz[2 * M + sa] = zA.z;
+    lz[sb] = zB.x; lz[M + sb] = zB.y; lz[2 * M + sb] = zB.z;
+  };
+  if (nl <= kWideLayers) {
     for (int l = nl - 1; l >= 0; l--) {
       const int k1 = loff[l + 1];
-      for (int k = loff[l] + tid; k < k1; k += 64) {
-        const float4 n4 = ln[k], d4 = ld[k];
-        const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
-        const float iA = lim[sa], iB = lim[sb];
-        f3 zA = mk(lz[sa], lz[M + sa], lz[2 * M + sa]), zB = mk(lz[sb], lz[M + sb], lz[2 * M + sb]);
-        f3 g = dri_dfi_T(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * (1.0f / (iA + iB));
-        zA = zA + g * iA; zB = zB - g * iB;
-        lz[sa] = zA.x; lz[M + sa] = zA.y; lz[2 * M + sa] = zA.z;
-        lz[sb] = zB.x; lz[M + sb] = zB.y; lz[2 * M + sb] = zB.z;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      for (int k = loff[l] + tid; k < k1; k += THREADS) contact(k);
+      __syncthreads();
     }
+  } else {
+    if (tid < 64) {
+      for (int l = nl - 1; l >= 0; l--) {
+        const int k1 = loff[l + 1];
+        for (int k = loff[l] + tid; k < k1; k += 64) contact(k);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; z.st(v, lz[s]); z.st(N + v, lz[M + s]); z.st(2 * N + v, lz[2 * M + s]); }
   __syncthreads();
   return true;

@@ -21,6 +21,16 @@
 
 namespace dc {
 
+#ifdef DC_PROFILE_PHASES
+#define CPH_DECL long long cph_t = clock64(); long long cph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CPH(k) { long long n_ = clock64(); cph[k] += n_ - cph_t; cph_t = n_; }
+#define CPH_PRINT if (b == b0 && tid == 0) printf("[phases cl part %d] pd %d cg %d | per PD iter: windows %lld self %lld rhs-exch %lld update+exch %lld | per CG iter: spmv %lld exch-pAp %lld upd+publish %lld exch-rr+halo %lld p-update %lld cycles\n", part, iters, cg_total, cph[0] / iters, cph[1] / iters, cph[2] / iters, cph[7] / iters, cph[3] / max(cg_total, 1), cph[4] / max(cg_total, 1), cph[5] / max(cg_total, 1), cph[6] / max(cg_total, 1), 0ll);
+#else
+#define CPH_DECL
+#define CPH(k)
+#define CPH_PRINT
+#endif
+
 // PIPE: the inner solve is the pipelined CG of Ghysels & Vanroose (one exchange per iteration instead of two), see the loop
 template <int THREADS, int VPT, bool DETECT, bool PIPE>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
 
+  CPH_DECL
   for (int iter = 0; iter < A.pd_cap; iter++) {
     int zp;                                       // opaque zero against LICM of the unrolled row indices (dc_forward_pk.hip)
     asm volatile("s_mov_b32 %0, 0" : "=s"(zp));
@@ -144,6 +155,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       psum += dot(rhs, rhs);
     });
     __syncthreads();
+    CPH(0)
     X.site = 4;
     if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) on part 0 over the rollout's f / r, then the right-hand side again
       if (!xch_barrier<THREADS>(X)) return;
@@ -159,6 +171,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       }
       __syncthreads();
     }
+    CPH(1)
     // ---- residual into registers, search direction p0 = r0 into the gather array, boundary rows to the neighbours ----
     float rr[VPT][3], ap[VPT][3], xx[VPT][3];
     X.site = 5;
@@ -189,10 +202,20 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       }
       rz = sums[0];
     }
+    // With few rows per thread the first packet batch of every row (16 registers per row) stays in registers for the whole solve:
+    // the matrix is the same in all ~25 iterations, and a part that is only a few rows deep cannot hide the L2 latency of
+    // re-reading it behind its own arithmetic (measured r02w: 4.9 k cycles per product of 3 rows, 1.6 x the per-row cost of the
+    // 20-row kernel).
+    constexpr bool MATREG = VPT <= 4;
+    int4 mat[MATREG ? VPT : 1][PB];
+    if constexpr (MATREG) {
+#pragma unroll
+      for (int k = 0; k < VPT; k++) load_batch(mat[k], CL.pk + CL.pk_ptr[cbase + min(wv + k * WAVES, nch - 1)] + lane, 0);
+    }
     // ap = Ahat p on the own rows (p incl. halo in the gather array), part2 += <p, ap>
     auto spmv = [&](int wz, const float2 *vxy, const float *vz, float &part2) {
       int4 nxt[PB];
-      load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
+      if constexpr (!MATREG) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
 #pragma unroll
       for (int k = 0; k < VPT; k++) {
         const int lc = wz + k * WAVES;          // wave-uniform local chunk
@@ -202,9 +225,14 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         const int np = CL.pk_n[chunk];
         const int4 *row = CL.pk + CL.pk_ptr[chunk] + lane;
         int4 cur[PB];
+        if constexpr (MATREG) {
 #pragma unroll
-        for (int j = 0; j < PB; j++) cur[j] = nxt[j];
-        if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
+          for (int j = 0; j < PB; j++) cur[j] = mat[k][j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < PB; j++) cur[j] = nxt[j];
+          if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
+        }
         const int li = HB + lcc * 64 + lane;
         const float2 pxy = vxy[li];
         const float pz = vz[li];
@@ -221,6 +249,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       }
     };
     __syncthreads();
+    CPH(2)
     // ---- global step: CG on the scaled system = Jacobi PCG on P dv = rhs ----
     if constexpr (PIPE) {
       // Pipelined CG (Ghysels & Vanroose 2014, unpreconditioned form — the system is already scaled): besides x, r, p it carries
@@ -306,8 +335,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         const int wz = wv + zs, tz = tid + zs;
         spmv(wz, gxy, gz, part2);
+        CPH(3)
         X.site = 6;
         if (!xch_allsum<THREADS>(X, part2, 0.f, 0.f, sums)) return;
+        CPH(4)
         const float alpha = (float) (rz / sums[0]);
         part2 = 0.f;
         X.site = 7;
@@ -327,8 +358,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           if (l < R) xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
         }
         xch_publish_sums(X, part2, 0.f, 0.f);
+        CPH(5)
         f3 hv[HPT];
         if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+        CPH(6)
         const double rz_new = sums[0];
         it++; cg_total++;
         if (!(rz_new > stop)) break;
@@ -375,6 +408,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     xch_drain();                                  // the new v must have left the CU before the norm (= its hand-over flag) is published
     if (!xch_allsum<THREADS>(X, psum, 0.f, 0.f, sums)) return;
     xdiff = (double) h * sqrt(sums[0]) / (double) N;
+    CPH(7)
     iters = iter + 1;
     converged = xdiff < (double) A.fwd_tol;
     if (xdiff < min_xdiff) {
@@ -412,6 +446,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     s.self_overflow = (S.contact_enabled && S.self_enabled) ? srec.meta[(size_t) b * kMetaStride + kMetaStride - 2] : 0;
     A.stats[b + (size_t) step * A.slot_stats] = s;
   }
+  CPH_PRINT
   }   // step
 }
 
