@@ -105,7 +105,7 @@ __device__ __forceinline__ bool adjoint_operator_cl(const DevSystem &S, const De
 
 template <int THREADS, bool BLK>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
-                                                             BwdArgs A, int b0, int hc_off, int tail_off) {
+                                                             BwdArgs A, int b0, int nb_real, int hc_off, int tail_off) {
   const DevSystem &S = *Sp;
   const DevCluster &CL = *Cp;
   constexpr int HPT = (1024 + THREADS - 1) / THREADS;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   const int N = S.N, K = CL.K, R = CL.R, HB = CL.HB;
   int lb, part;
   cluster_map(K, lb, part);
+  if (lb >= nb_real) return;       // padding workgroups: the launch is rounded up to a multiple of 8 rollouts (see the launcher)
   const int b = b0 + lb;
   Xch X = xch_init(CL, lb, part, dyn_lds + tail_off);
   if (!xch_hello<THREADS>(X)) return;
@@ -448,11 +449,11 @@ hipError_t launch_adjoint_step_cluster(const DevSystem &S, const DevCluster &CL,
   if (A.block_pre) {
     hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, true>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, hc_off, tail_off);
+    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, true>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, hc_off, tail_off);
   } else {
     hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, false>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, hc_off, tail_off);
+    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, false>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, hc_off, tail_off);
   }
   return hipGetLastError();
 }

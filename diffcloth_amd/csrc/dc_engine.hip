@@ -246,8 +246,9 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
     const int Rc = own_w * w;
     if ((long long) (K - 1) * Rc >= N) break;           // a part would be empty
     if (Rc < HB) break;                                  // halo rows must come from the direct neighbours only
-    if (Rc < 1024 && !forced) break;                     // small parts: the exchanges cost more than the rows they save (measured: the
-                                                         // 1426-vertex T-shirt is fastest on ONE workgroup, tools/bench_tshirt_k.py)
+    if (Rc < 256 && !forced) break;                      // parts of fewer rows than half a workgroup: nothing left to save (the 1426-vertex
+                                                         // T-shirt, one rollout: 21.9 / 19.0 / 18.4 / 18.2 ms per fwd+bwd step at K = 1 / 4 / 6 / 8
+                                                         // once its parts share an XCD, tools/bench_tshirt_k.py)
     int v = 0;
     for (int a : allowed) if (a * 512 >= Rc) { v = a; break; }
     if (v == 0) continue;                                // more rows per part than the kernel holds in registers: more windows do not help
@@ -296,7 +297,10 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   if ((rc = upload_cl<int>(c, &D.pk_n, HP.pk_n))) return rc;
   if ((rc = upload_cl<float>(c, &D.sq_dinv, HP.sq_dinv))) return rc;
   cl.K = K;
-  cl.nb = std::max(1, std::min(c->B, c->cus / K));
+  {   // rollouts per launch: all of them when they fit, else equal chunks (never a last launch with a handful of rollouts)
+    const int nbmax = std::max(1, c->cus / K), nchunks = (c->B + nbmax - 1) / nbmax;
+    cl.nb = std::max(1, (c->B + nchunks - 1) / nchunks);
+  }
   D.nb = cl.nb;
   cl.xch_bytes = (size_t) cl.nb * K * 2 * D.xch_stride * sizeof(v4i);
   if ((rc = dev_alloc(c, cl.allocs, &D.xch, cl.xch_bytes / sizeof(v4i)))) return rc;
@@ -318,14 +322,27 @@ int choose_cluster(dc_ctx *c) {
   const int forced = env ? atoi(env) : -1;
   if (forced == 0 || forced == 1) return DC_OK;
   if (c->S.dense_inv) { if (forced < 2) return DC_OK; }     // small meshes: the explicit-inverse kernels are the faster ones
+  // Fewer rollouts than CUs: as many parts as fit (B K <= CUs), up to 8 — a rollout's speed-up grows with K (measured on C4: 1.3 /
+  // 1.9 / 3.0 x at K = 2 / 4 / 8). A mesh too large for one workgroup needs kmin parts; when that oversubscribes the device the
+  // batch runs in several launches and K is the one that wastes the least: score = fraction of the CUs busy x per-CU efficiency.
+  static const double eff[9] = {0, 1.0, 0.65, 0.55, 0.48, 0.44, 0.42, 0.40, 0.38};
+  const int kmin = (!c->S.pk_ok || !c->S.win_ok) ? std::max(2, std::min(8, (c->host.N + 6143) / 6144)) : 1;
   int K = 1;
-  while (K * 2 * c->B <= c->cus && K * 2 <= 8) K *= 2;
-  if (!c->S.pk_ok || !c->S.win_ok) K = std::max(K, std::min(8, (c->host.N + 6143) / 6144));
   if (forced >= 2) K = std::min(forced, 8);
+  else if ((long long) c->B * std::max(kmin, 2) <= c->cus) { K = std::max(kmin, 2); while ((K + 1) * c->B <= c->cus && K + 1 <= 8) K++; }
+  else if (kmin > 1) {
+    double best = -1;
+    for (int k = kmin; k <= 8; k++) {
+      const int nbmax = std::max(1, c->cus / k), nchunks = (c->B + nbmax - 1) / nbmax, nb = (c->B + nchunks - 1) / nchunks;
+      const double score = (double) nb * k / c->cus * eff[k];
+      if (score > best + 1e-9) { best = score; K = k; }
+    }
+  }
   for (; K >= 2; K--) {
     int rc = build_cluster(c, K, forced >= 2);
     if (rc) return rc;
     if (c->cl.ok) break;
+    if (forced < 2 && K <= kmin) break;
   }
   return DC_OK;
 }

@@ -34,7 +34,7 @@ namespace dc {
 // PIPE: the inner solve is the pipelined CG of Ghysels & Vanroose (one exchange per iteration instead of two), see the loop
 template <int THREADS, int VPT, bool DETECT, bool PIPE>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
-                                                        FwdArgs A, int b0, int tail_off, int fric_floats) {
+                                                        FwdArgs A, int b0, int nb_real, int tail_off, int fric_floats) {
   const DevSystem &S = *Sp;
   const DevCluster &CL = *Cp;
   constexpr int WAVES = THREADS / 64;
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   const int K = CL.K, R = CL.R, HB = CL.HB, GL = R + 2 * HB;
   int lb, part;
   cluster_map(K, lb, part);
+  if (lb >= nb_real) return;       // padding workgroups: the launch is rounded up to a multiple of 8 rollouts (see the launcher)
   const int b = b0 + lb;
   Xch X = xch_init(CL, lb, part, lds + tail_off);
   if (!xch_hello<THREADS>(X)) return;
@@ -462,11 +463,14 @@ static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const
   if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT, PIPE>), dim3(nb * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, tail_off, fric_floats);
+  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT, PIPE>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, tail_off, fric_floats);
   return hipGetLastError();
 }
 
-// nb rollouts starting at b0, K workgroups each; the caller has zeroed the exchange area and made sure K nb <= CUs.
+// nb rollouts starting at b0, K workgroups each; the caller has zeroed the exchange area and made sure K nb <= CUs. The grid is
+// rounded up to a multiple of 8 rollouts: with the observed round-robin placement (block b on XCD b % 8) the K parts of a rollout
+// then land on ONE XCD whatever nb is (cluster_map), which lets their exchanges stay in that XCD's L2; the padding workgroups
+// exit at once. Correctness does not depend on the placement (xch_hello checks it at run time).
 hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
   // Pipelined CG (one exchange per iteration, needs <= 6 rows per thread for its seven row vectors) is OFF unless DC_PIPECG=1
   // (development switch). Measured r02v, C4 at 32 rollouts x 8 workgroups: forward 8.77 -> 7.99 ms per step (+8 % rollout-steps/s),
