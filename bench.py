@@ -144,17 +144,28 @@ def config_key(args, B, K, W, N):
             f"_am{args.adjoint_mode}_ar{args.adjoint_rel_tol:g}_bp{args.block_precond}")
 
 
-def load_profile():
-    """Latest profiles/r*_roofline.json (tools/profile_round.sh -> tools/roofline_from_pmc.py): per kernel the calibrated HBM-side
-    bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), the LDS-array / VALU busy fractions (SQ counter
-    passes) and the algorithmic bytes of the profiled run."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        p = json.load(f)
-    p["file"] = os.path.relpath(files[-1], ROOT)
-    return p
+def load_profiles():
+    """profiles/r*_roofline.json (tools/profile_round.sh -> tools/roofline_from_pmc.py), newest first: per kernel the calibrated
+    HBM-side bytes of the timed sweep (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), the LDS-array / VALU busy
+    fractions (SQ counter passes) and the algorithmic bytes of the profiled run."""
+    out = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline.json")), reverse=True):
+        with open(f) as fh:
+            p = json.load(fh)
+        p["file"] = os.path.relpath(f, ROOT)
+        out.append(p)
+    return out
+
+
+def profile_for(profiles, key, kernel):
+    """the profile of this very configuration if there is one, else the newest one that contains the kernel"""
+    for p in profiles:
+        if p.get("config_key") == key and kernel in p.get("kernels", {}):
+            return p, True
+    for p in profiles:
+        if kernel in p.get("kernels", {}):
+            return p, False
+    return None, False
 
 
 def main():
@@ -298,7 +309,7 @@ def main():
         bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b) * N
     cl = e.cluster() if hasattr(e, "cluster") else 1
     key = config_key(args, B, K, W, N)
-    prof = load_profile() if world == 1 else None
+    profiles = load_profiles() if world == 1 else []
 
     def kernel_entry(name, nbytes, ms, launches):
         # one launch = the K timed steps of (a chunk of) the B rollouts (dc_rollout_* runs a rollout's steps inside one launch).
@@ -312,9 +323,10 @@ def main():
                "ms_per_step": ms / K, "algorithmic_bytes": nbytes, "algorithmic_rate_gbs": nbytes / sec / 1e9,
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "achieved": None, "frac": None, "traffic_source": None,
                "lds_frac": None, "valu_frac": None, "wait_frac": None}
-        pk = (prof or {}).get("kernels", {}).get(name)
-        if pk:
-            if prof.get("config_key") == key:
+        prof, exact = profile_for(profiles, key, name)
+        if prof:
+            pk = prof["kernels"][name]
+            if exact:
                 traffic, src = pk["hbm_bytes"], f"{prof['file']} (this configuration)"
             else:
                 traffic = nbytes * pk["hbm_bytes"] / max(pk["algorithmic_bytes"], 1.0)

@@ -12,14 +12,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py $ARGS > $OUT/bench_plain.log 2>&1
 grep '"metric"' $OUT/bench_plain.log | tail -1 > $OUT/bench_line.json
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 --tshirt 0 > $OUT/bench_under_rocprof.log 2>&1
 grep '"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 --tshirt 0 > $OUT/pmc_$C.log 2>&1
   [ -x $R/tools/bin/pmc_calib ] && rocprofv3 --kernel-trace --pmc $C -d $OUT/calib_$C -o x --output-format csv -- $R/tools/bin/pmc_calib > $OUT/calib_$C.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq_b -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 > $OUT/pmc_sq_b.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_sq_c -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 > $OUT/pmc_sq_c.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq_b -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 --tshirt 0 > $OUT/pmc_sq_b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_sq_c -o x --output-format csv -- python $R/bench.py $ARGS --cpu-steps 0 --tshirt 0 > $OUT/pmc_sq_c.log 2>&1
 python $R/tools/roofline_from_pmc.py $OUT $TAG > $OUT/roofline_summary.txt 2>&1
 cat $OUT/roofline_summary.txt
 cp $OUT/stats/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null || find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
