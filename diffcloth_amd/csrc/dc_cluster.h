@@ -9,8 +9,10 @@
 // sc1 loads until the tag equals the exchange's sequence number (MI355X_MICROARCH.md "inter-workgroup visibility", form R2: the
 // data is the flag — no fence, no separate flag, placement independent). Every exchange waits for the partial-sum granule of
 // EVERY part, so a part can never be more than one exchange ahead of another: two buffers (sequence parity) suffice.
-// Per-step hand-overs of whole arrays (tape state, self-contact lists) use plain stores bracketed by agent-scope
-// release / acquire fences around an exchange (xch_fence_barrier).
+// Whole arrays that cross parts (tape state, records, the adjoint's y) go through the same sc1 path (BufVec): plain stores with
+// agent-scope release / acquire fences around an exchange were measured NOT to be sufficient on this part (a part read a stale
+// self-contact count), so a count travels inside an exchange and xch_fence_barrier only remains in front of the inlined
+// self-collision detection, whose plain loads read positions another part wrote a whole time step earlier.
 // Every spin is bounded (kSpinLimit of the 100 MHz wall clock): a part that gives up raises DevCluster::err and all parts of
 // the rollout leave the kernel; the host reports DC_ERR_HIP. All parts of a launch are resident by construction (the launcher
 // never starts more workgroups than the device has CUs).
