@@ -191,7 +191,9 @@ int dc_get_param_gradients(dc_ctx *ctx, int slot, double *out /*B*8*/);
 int dc_get_force_gradient(dc_ctx *ctx, double *dL_df /*B*3N*/);
 
 /* ---- device-resident rollouts (no host copies inside; used by bench.py and batched callers) --------- */
-/* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Asynchronous. When the packet
+/* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Returns when the sweep has finished on the
+ * device (its kernel time and the split kernels' error word are read back; a self-contact overflow of a step is reported by
+ * dc_get_stats for that slot: DC_ERR_CAPACITY). When the packet
  * kernel is in use all steps of a rollout run inside ONE launch (each rollout advances on its own, self-collision
  * detection inlined per step); results are bitwise those of nsteps dc_step_forward calls.                          */
 int dc_rollout_forward(dc_ctx *ctx, int slot, int nsteps);
@@ -201,7 +203,7 @@ int dc_seed_gradient(dc_ctx *ctx, int slot, const double *target /*3N or NULL*/,
 /* nsteps backward steps from record `slot` down to slot-nsteps+1, carrying (dL_dx, dL_dv) on the device
  * exactly as Simulation::runBackwardTask does (Simulation.cpp:3938-3952), all steps in one launch. dL_dmu accumulates
  * over the steps, the per-step parameter gradients stay readable per slot (dc_get_param_gradients); dL_dx_fixed of the
- * individual steps is only available through dc_step_backward. Asynchronous.                                        */
+ * individual steps is only available through dc_step_backward. Returns when the sweep has finished on the device.    */
 int dc_rollout_backward(dc_ctx *ctx, int slot, int nsteps);
 int dc_get_gradient(dc_ctx *ctx, double *dL_dx, double *dL_dv, double *dL_dmu /*B*num_groups or NULL*/);
 int dc_get_stats(dc_ctx *ctx, int slot, dc_step_stats *fwd /*B or NULL*/, dc_bwd_stats *bwd /*B or NULL*/);
