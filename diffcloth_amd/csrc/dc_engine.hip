@@ -174,6 +174,8 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.pd_cap = pd_cap(c);
   A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
+  static const bool seed_on = !(getenv("DC_CG_SEED") && getenv("DC_CG_SEED")[0] == '0');     // development switch
+  A.cg_seed = seed_on ? 1 : 0;
   A.nsteps = 1; A.inline_detect = 0; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
   A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   return A;

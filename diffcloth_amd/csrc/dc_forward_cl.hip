@@ -59,6 +59,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   const size_t off = (size_t) b * 3 * N;
   float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off, *scr = W.cg_r + off;
   const BufVec vnb = buf_vec(vnow, N, X.same_xcd);
+  const BufVec dpb = buf_vec(W.cg_x + off, N, X.same_xcd);    // scaled correction of the previous PD iteration (seed of the next solve)
   const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
   const int w0 = part * CL.wpp, w1 = min(CL.nwin, w0 + CL.wpp);
 
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       for (int k = 0; k < VPT; k++) load_batch(mat[k], CL.pk + CL.pk_ptr[cbase + min(wv + k * WAVES, nch - 1)] + lane, 0);
     }
     // ap = Ahat p on the own rows (p incl. halo in the gather array), part2 += <p, ap>
-    auto spmv = [&](int wz, const float2 *vxy, const float *vz, float &part2) {
+    auto spmv = [&](int wz, const float2 *vxy, const float *vz, float &part2, bool with_pr, float &part3) {
       int4 nxt[PB];
       if constexpr (!MATREG) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
 #pragma unroll
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         }
         ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
         part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;
+        if (with_pr) part3 += (pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2]) * onf;     // seeded pass only (uniform branch)
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           int zs;
           asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
           float unused = 0.f;
-          spmv(wv + zs, gxy, gz, unused);            // w = A r (r and its halo are in the first gather array)
+          spmv(wv + zs, gxy, gz, unused, false, unused);            // w = A r (r and its halo are in the first gather array)
         }
 #pragma unroll
         for (int k = 0; k < VPT; k++)
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           }
           __syncthreads();
           float unused = 0.f;
-          spmv(wz, cxy, cz, unused);                  // q = A w
+          spmv(wz, cxy, cz, unused, false, unused);                  // q = A w
 #pragma unroll
           for (int k = 0; k < VPT; k++)
 #pragma unroll
@@ -330,17 +332,32 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     } else
     if (rz > 1e-300) {
       const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+      // Recycled first direction (A.cg_seed, see dc_forward_pk.hip): the previous PD iteration's correction d, read back with its
+      // boundary rows from the array every part stored its rows to before the exchange of the update; x = <d, r> / <d, A d> d,
+      // then CG restarted from the new residual. Saves exchanges as well as products.
+      bool seed = A.cg_seed && iter > 0;
+      if (seed) {
+        for (int j = tid; j < R + 2 * HB; j += THREADS) {
+          const int i = r0 - HB + j;                      // gather index j <-> global row i
+          const bool on = i >= 0 && i < N && (j < HB || j >= HB + R || i < r1);
+          f3 d = mk(0, 0, 0);
+          if (on) d = ld3c(dpb, i);
+          gxy[j] = make_float2(d.x, d.y); gz[j] = d.z;
+        }
+        __syncthreads();
+      }
       for (int it = 0; it < A.cg_max;) {
-        float part2 = 0.f;
+        float part2 = 0.f, part3 = 0.f;
         int zs;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         const int wz = wv + zs, tz = tid + zs;
-        spmv(wz, gxy, gz, part2);
+        spmv(wz, gxy, gz, part2, seed, part3);
         CPH(3)
         X.site = 6;
-        if (!xch_allsum<THREADS>(X, part2, 0.f, 0.f, sums)) return;
+        if (!xch_allsum<THREADS>(X, part2, part3, 0.f, sums)) return;
         CPH(4)
-        const float alpha = (float) (rz / sums[0]);
+        const double pr = seed ? sums[1] : rz;
+        const float alpha = sums[0] > 1e-300 ? (float) (pr / sums[0]) : 0.f;
         part2 = 0.f;
         X.site = 7;
         xch_begin(X);
@@ -366,7 +383,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         const double rz_new = sums[0];
         it++; cg_total++;
         if (!(rz_new > stop)) break;
-        const float beta = (float) (rz_new / rz);
+        const float beta = seed ? 0.f : (float) (rz_new / rz);
+        seed = false;
         rz = rz_new;
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       const f3 vq = ld3c(vnb, ic);
       ap[k][0] = xx[k][0] * sq; ap[k][1] = xx[k][1] * sq; ap[k][2] = xx[k][2] * sq;
       if (on) {
+        if (A.cg_seed) st3c(dpb, i, mk(xx[k][0], xx[k][1], xx[k][2]));
         st3c(vnb, i, mk(vq.x + ap[k][0], vq.y + ap[k][1], vq.z + ap[k][2]));
         psum = fmaf(ap[k][0], ap[k][0], psum); psum = fmaf(ap[k][1], ap[k][1], psum); psum = fmaf(ap[k][2], ap[k][2], psum);
       }

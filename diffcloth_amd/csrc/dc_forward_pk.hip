@@ -57,6 +57,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   const int N = S.N, T = S.T, E = S.E, NC = S.NC;
   const size_t off = (size_t) b * 3 * N;
   float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off;
+  float *dprev = W.cg_x + off;                // scaled correction of the previous PD iteration (first search direction of the next solve)
   float *corner = W.corner + (size_t) b * 3 * NC;
   const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
   // A.nsteps consecutive time steps of this rollout in one launch (dc_rollout_forward without self-collision): rollouts
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     }
     PH(1)
     // ap = Ahat * (the vector in lp), part2 += <lp, ap>; rows of a thread tid + k * THREADS
-    auto spmv = [&](int wz, float &part2) {
+    auto spmv = [&](int wz, float &part2, bool with_pr, float &part3) {
       int4 nxt[PB];
       load_batch(nxt, S.pk + S.pk_ptr[wz] + lane, 0);
 #pragma unroll
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         }
         ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
         part2 += pxy.x * ax + pxy.y * ay + pz * az;
+        if (with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];      // seeded pass only (uniform branch)
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           }
           __syncthreads();
           float part2 = 0.f;
-          spmv(wz, part2);
+          float nopr = 0.f;
+          spmv(wz, part2, false, nopr);
           part2 = 0.f;
 #pragma unroll
           for (int k = 0; k < VPT; k++)
@@ -291,17 +294,32 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     } else
     if (rz > 1e-300) {
       const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+      // Recycled first direction (A.cg_seed): successive PD iterations of a step produce strongly correlated corrections, so the
+      // previous solution d is a far better first search direction than the residual: x = gamma d with gamma = <d, r> / <d, A d>
+      // (the energy-norm minimiser along d), then ordinary CG restarted from the new residual (beta = 0). One extra product,
+      // and the relative stopping rule (against the right-hand side) is met several iterations earlier.
+      bool seed = A.cg_seed && iter > 0;
+      if (seed) {
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int i = tq + k * THREADS, ic = min(i, N - 1);
+          const float okf = i < N ? 1.f : 0.f;
+          ((float2 *) lp)[i] = make_float2(dprev[ic] * okf, dprev[N + ic] * okf); lp[2 * NP + i] = dprev[2 * N + ic] * okf;
+        }
+      }
       for (int it = 0; it < A.cg_max;) {
         __syncthreads();
-        float part2 = 0.f;
+        float part2 = 0.f, part3 = 0.f;
         int zs;                               // opaque zero: keeps the per-row addresses out of LICM's reach (they
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));   // would be hoisted into ~60 live registers otherwise)
         const int wz = wv + zs, tz = tid + zs;
-        spmv(wz, part2);
+        spmv(wz, part2, seed, part3);
         PH(2)
         const double pAp = block_sum_f<THREADS>(part2, red);
+        double pr = rz;
+        if (seed) pr = block_sum_f<THREADS>(part3, red);
         PH(3)
-        const float alpha = (float) (rz / pAp);
+        const float alpha = pAp > 1e-300 ? (float) (pr / pAp) : 0.f;
         part2 = 0.f;
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
@@ -319,7 +337,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         const double rz_new = block_sum_f<THREADS>(part2, red);
         it++; cg_total++;
         if (!(rz_new > stop)) break;
-        const float beta = (float) (rz_new / rz);
+        const float beta = seed ? 0.f : (float) (rz_new / rz);
+        seed = false;
         rz = rz_new;
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
@@ -356,7 +375,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           for (int c = 0; c < 3; c++) {
             const float xs = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tq];
             ap[k][c] = xs * sq[j];             // delta v (A p is dead here)
-            if (i < N) { vnow[c * N + i] = vq[j][c] + ap[k][c]; part = fmaf(ap[k][c], ap[k][c], part); }
+            if (i < N) { vnow[c * N + i] = vq[j][c] + ap[k][c]; part = fmaf(ap[k][c], ap[k][c], part); if (A.cg_seed) dprev[c * N + i] = xs; }
           }
         }
       }

@@ -48,6 +48,9 @@ CFG
     g128) TAILN=2 run g128 python bench.py --steps 8 --warmup 4 --grid 128 --fold-rows 0 --cpu-steps 0 ;;
     g128k1) TAILN=2 run g128k1 python bench.py --steps 8 --warmup 4 --grid 128 --fold-rows 0 --cpu-steps 0 --cluster 1 ;;
     bench32k1) TAILN=3 run bench32k1 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --cluster 1 ;;
+    benchq0) export DC_CG_SEED=0; TAILN=3 run benchq0 python bench.py --steps 20 --warmup 5 --cpu-steps 0 --tshirt 0; unset DC_CG_SEED ;;
+    bench32s0) export DC_CG_SEED=0; TAILN=3 run bench32s0 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --tshirt 0; unset DC_CG_SEED ;;
+    paritycore) TAILN=12 run paritycore python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_configs.py -q -x ;;
     *) echo "unknown item $item" ;;
   esac
 done
