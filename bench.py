@@ -326,6 +326,10 @@ def main():
         prof, exact = profile_for(profiles, key, name)
         if prof:
             pk = prof["kernels"][name]
+            # a profile of this configuration taken with other kernels (its launch time is off by > 10 %) only lends its traffic per
+            # algorithmic byte, like a profile of another configuration
+            if exact and abs(pk["launch_ms_total"] - ms) > 0.1 * ms:
+                exact = False
             if exact:
                 traffic, src = pk["hbm_bytes"], f"{prof['file']} (this configuration)"
             else:

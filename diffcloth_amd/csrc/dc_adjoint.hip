@@ -354,11 +354,16 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     // digits (7.31e-5 -> 7.31e-5) — the fp32 floor of this solve is eps * cond(K) in the operator's coefficients, not residual
     // drift — so one cycle is the default.
     for (int cycle = 0, kdone = 0; cycle < kCycles; cycle++) {
-    adjoint_operator<THREADS, WIN>(S, C, u, false, v, nullptr, d1, d2);
-    __syncthreads();            // (as above; inside the loop the block reductions that follow every application do this)
+    // r = rhat = p = g - K u; the direct mode starts from u = 0: K u = 0 without applying the operator (one of ~75 applications)
+    const bool u_is_zero = (A.mode == 1 && cycle == 0);
+    if (!u_is_zero) {
+      adjoint_operator<THREADS, WIN>(S, C, u, false, v, nullptr, d1, d2);
+      __syncthreads();            // (as above; inside the loop the block reductions that follow every application do this)
+    }
     part = 0.f;
     for (int i = tid; i < N; i += THREADS) {
-      f3 q = ld3(gin, i, N) - ld3(v, i, N);
+      f3 q = ld3(gin, i, N);
+      if (!u_is_zero) q = q - ld3(v, i, N);
       st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
       if constexpr (BLK) st3(ph, i, N, pre(i, q));
       part += dot(q, q);
