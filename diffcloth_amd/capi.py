@@ -50,7 +50,8 @@ EXPORTED_SYMBOLS = [
     "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force", "dc_set_vertex_forces", "dc_get_force_gradient",
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
-    "dc_timer_stop", "dc_kernel_times", "dc_get_cluster",
+    "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
+    "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed",
 ]
 
 _lib = None
@@ -270,6 +271,42 @@ class Engine:
 
     def rollout_backward(self, slot, nsteps):
         self._chk(self.lib.dc_rollout_backward(self.h, C.c_int(slot), C.c_int(nsteps)))
+
+    # ---- device-resident schedules (dc_set_*_schedule) ----
+    def set_gradient(self, dL_dx, dL_dv):
+        n3 = 3 * self.N
+        self._chk(self.lib.dc_set_gradient(self.h, _d(self._vec(dL_dx, n3)), _d(self._vec(dL_dv, n3))))
+
+    def set_fixed_point_schedule(self, slot0, xf):
+        """xf: [nsteps][B][3 Af] targets of the steps slot0+k -> slot0+k+1"""
+        xf = np.ascontiguousarray(np.asarray(xf, dtype=np.float64).reshape(-1, self.B, 3 * self.Af))
+        self._chk(self.lib.dc_set_fixed_point_schedule(self.h, C.c_int(slot0), C.c_int(xf.shape[0]), _d(xf)))
+
+    def set_force_schedule(self, slot0, nsteps, fu=None, fv_scale=None):
+        fu = None if fu is None else np.ascontiguousarray(np.asarray(fu, dtype=np.float64).reshape(nsteps, self.B, 3))
+        fs = None if fv_scale is None else np.ascontiguousarray(np.asarray(fv_scale, dtype=np.float64).reshape(nsteps, self.B))
+        self._chk(self.lib.dc_set_force_schedule(self.h, C.c_int(slot0), C.c_int(nsteps), _d(fu), _d(fs)))
+
+    def set_seed_schedule(self, slot0, dL_dx, dL_dv=None):
+        """dL_dx: [nslots][B][3 N] loss gradient w.r.t. the state at slot slot0+k"""
+        gx = np.ascontiguousarray(np.asarray(dL_dx, dtype=np.float64).reshape(-1, self.B, 3 * self.N))
+        gv = None if dL_dv is None else np.ascontiguousarray(np.asarray(dL_dv, dtype=np.float64).reshape(gx.shape))
+        self._chk(self.lib.dc_set_seed_schedule(self.h, C.c_int(slot0), C.c_int(gx.shape[0]), _d(gx), _d(gv)))
+
+    def clear_schedules(self):
+        self._chk(self.lib.dc_clear_schedules(self.h))
+
+    def get_states(self, slot0, nslots):
+        x = np.zeros((nslots, self.B, 3 * self.N)); v = np.zeros((nslots, self.B, 3 * self.N))
+        self._chk(self.lib.dc_get_states(self.h, C.c_int(slot0), C.c_int(nslots), _d(x), _d(v)))
+        return x, v
+
+    def get_dxfixed(self, slot0, nslots):
+        out = np.zeros((nslots, self.B, max(3 * self.Af, 1)))
+        if self.Af > 0:
+            out = np.zeros((nslots, self.B, 3 * self.Af))
+            self._chk(self.lib.dc_get_dxfixed(self.h, C.c_int(slot0), C.c_int(nslots), _d(out)))
+        return out[:, :, :3 * self.Af]
 
     def get_gradient(self):
         dx = np.zeros((self.B, 3 * self.N)); dv = np.zeros((self.B, 3 * self.N)); dmu = np.zeros((self.B, self.ngroups))

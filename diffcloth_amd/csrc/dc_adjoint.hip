@@ -244,6 +244,9 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     A.self.pair -= A.slot_self; A.self.nrm -= A.slot_self; A.self.dvec -= A.slot_self; A.self.meta -= A.slot_meta; A.self.verts -= 2 * A.slot_self;
     if (A.d_param) A.d_param -= A.slot_param;
     A.x_fixed -= A.slot_xf; A.stats -= A.slot_stats;
+    if (A.d_xfixed) A.d_xfixed -= A.slot_xf;
+    if (A.ix) A.ix -= A.slot_ix;
+    if (A.iv) A.iv -= A.slot_ix;
     A.is_start = (A.slot - step == 1) ? 1 : 0;            // isStart: Simulation.cpp:3947
   }
   AdjCtx C;

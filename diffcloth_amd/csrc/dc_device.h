@@ -140,6 +140,7 @@ struct FwdArgs {
   const float *mu;              // [B][ngroups]
   const float *fu;              // [B][3] uniform extra force or nullptr
   const float *fv;              // [B][3][N] per-vertex extra force (wind with fall-off, constant force field) or nullptr
+  const float *fv_scale;        // [B] factor on fv for this step (per-step wind factor of a force schedule) or nullptr = 1
   dc_step_stats *stats;         // [B]
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
@@ -149,6 +150,8 @@ struct FwdArgs {
   int nsteps, inline_detect;    // inline_detect: run the self-collision detection of every step inside the kernel
   size_t slot_state, slot_prim, slot_stats;     // slot strides of the [B][3][N] arrays, the [B][N] array, the stats
   size_t slot_self, slot_meta;                  // ... of the self-contact lists and their meta blocks
+  // device-resident schedules (dc_set_*_schedule): per-step strides of x_fixed, fu and fv_scale; 0 = the same values in every step
+  size_t slot_xfix, slot_fu, slot_fvs;
 };
 
 struct BwdArgs {
@@ -171,7 +174,8 @@ struct BwdArgs {
   int block_pre;                // direct solve: 1 = block-Jacobi from K's own diagonal blocks (dc_adjprecond.h), 0 = Jacobi from diag(P)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;
-  size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements)
+  size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements); d_xfixed steps by slot_xf too
+  size_t slot_ix;               // seed schedule: ix / iv of step s are ix - s * slot_ix (0: none / the same buffer)
 };
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);

@@ -66,7 +66,14 @@ struct dc_ctx {
   bool fu_set = false;
   float *fv = nullptr;              // [B][3][N] per-vertex extra force
   bool fv_set = false;
-  float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DXF = nullptr, *DMU = nullptr, *target = nullptr;
+  float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DMU = nullptr, *target = nullptr;
+  float *DXF = nullptr;             // [(tape+1)][B][3][Af] dL_dxfixed of the step that produced the slot
+  // device-resident schedules of the fused rollouts (dc_set_*_schedule); flags per tape slot
+  float *FU_S = nullptr;            // [(tape+1)][B][3] uniform force of the step that produces the slot
+  float *FVS_S = nullptr;           // [(tape+1)][B] factor on fv of that step
+  float *SEEDX = nullptr, *SEEDV = nullptr;   // [(tape+1)][B][3][N] loss gradient w.r.t. the state at the slot (allocated on first use)
+  std::vector<char> sched_xf, sched_fu, sched_fvs, sched_seed;
+  std::vector<void *> sched_pool;
   dc_step_stats *fstats = nullptr;  // [(tape+1)][B]
   dc_bwd_stats *bstats = nullptr;   // [(tape+1)][B], indexed by the slot whose record was differentiated
   double *stage[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -163,6 +170,11 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.rec_f = c->F + se * (slot + 1); A.rec_r = c->R + se * (slot + 1); A.rec_n = c->NRM + se * (slot + 1);
   A.rec_prim = c->PRIM + sp * (slot + 1);
   A.x_fixed = c->xf_cur; A.mu = c->mu; A.fu = c->fu_set ? c->fu : nullptr; A.fv = c->fv_set ? c->fv : nullptr;
+  A.fv_scale = nullptr; A.slot_xfix = 0; A.slot_fu = 0; A.slot_fvs = 0;
+  // scheduled values of this step (dc_set_*_schedule) take precedence over the current ones
+  if (c->S.Af > 0 && c->sched_xf[slot + 1]) A.x_fixed = c->XF + (size_t) c->B * 3 * c->S.Af * (slot + 1);
+  if (c->sched_fu[slot + 1]) A.fu = c->FU_S + (size_t) c->B * 3 * (slot + 1);
+  if (c->sched_fvs[slot + 1] && A.fv) A.fv_scale = c->FVS_S + (size_t) c->B * (slot + 1);
   A.stats = c->fstats + (size_t) c->B * (slot + 1);
   {
     const size_t sc = (size_t) c->B * c->self_cap * (slot + 1), sm = (size_t) c->B * kMetaStride * (slot + 1);
@@ -191,8 +203,11 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
     A.self.verts = c->SC_verts + 2 * sc;
   }
   A.gx = c->GX; A.gv = c->GV;
-  A.ix = with_init ? c->IX : nullptr; A.iv = with_init ? c->IV : nullptr;
-  A.d_xfixed = c->DXF; A.d_mu = c->DMU;
+  A.ix = with_init ? c->IX : nullptr; A.iv = with_init ? c->IV : nullptr; A.slot_ix = 0;
+  if (!with_init && c->SEEDX && c->sched_seed[slot - 1]) {      // seed schedule: the loss gradient w.r.t. the state this step started from
+    A.ix = c->SEEDX + se * (slot - 1); A.iv = c->SEEDV + se * (slot - 1); A.slot_ix = se;
+  }
+  A.d_xfixed = c->DXF + (size_t) c->B * 3 * c->S.Af * slot; A.d_mu = c->DMU;
   A.d_param = c->DPAR + (size_t) c->B * 8 * slot;
   A.x_fixed = c->XF + (size_t) c->B * 3 * c->S.Af * slot;
   A.x_prev = c->X + se * (slot - 1); A.v_prev = c->V + se * (slot - 1); A.stats = c->bstats + (size_t) c->B * slot;
@@ -805,7 +820,11 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->GV, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->IX, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->IV, se))) return rc;
-  if ((rc = dev_alloc(c, pool, &c->DXF, (size_t) B * 3 * Af))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->DXF, (size_t) B * 3 * Af * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->FU_S, (size_t) B * 3 * slots))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->FVS_S, (size_t) B * slots))) return rc;
+  c->SEEDX = c->SEEDV = nullptr;
+  c->sched_xf.assign(slots + 1, 0); c->sched_fu.assign(slots + 1, 0); c->sched_fvs.assign(slots + 1, 0); c->sched_seed.assign(slots + 1, 0);
   if ((rc = dev_alloc(c, pool, &c->DMU, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->target, (size_t) 3 * N))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fstats, (size_t) B * slots))) return rc;
@@ -906,8 +925,9 @@ int dc_step_forward(dc_ctx *c, int slot, const double *fixed_pts, dc_step_stats 
   const int Af = c->S.Af;
   if (fixed_pts && Af > 0) {
     if ((rc = h2d_planar(c, fixed_pts, c->xf_cur, Af, 2, false))) return rc;
+    c->sched_xf[slot + 1] = 0;               // explicit targets win over a schedule entry of this step
   }
-  if (Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * Af * (slot + 1), c->xf_cur, sizeof(float) * c->B * 3 * Af, hipMemcpyDeviceToDevice, c->stream));
+  if (Af > 0 && !c->sched_xf[slot + 1]) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * Af * (slot + 1), c->xf_cur, sizeof(float) * c->B * 3 * Af, hipMemcpyDeviceToDevice, c->stream));
   if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
   if ((rc = cluster_begin(c))) return rc;
   if ((rc = enqueue_pd_step(c, fwd_args(c, slot)))) return rc;
@@ -998,12 +1018,16 @@ int dc_step_backward(dc_ctx *c, int slot, const double *dL_dxnew, const double *
     if ((rc = h2d_planar(c, dL_dvinit, c->IV, N, 3, true))) return rc;
   }
   HIPCHK(c, hipMemsetAsync(c->DMU, 0, sizeof(float) * c->B * G, c->stream));
-  if (Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF, 0, sizeof(float) * c->B * 3 * Af, c->stream));
+  if (Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF + (size_t) c->B * 3 * Af * slot, 0, sizeof(float) * c->B * 3 * Af, c->stream));
   if ((rc = cluster_begin(c))) return rc;
-  if ((rc = enqueue_adjoint_step(c, bwd_args(c, slot, is_start != 0, with_init)))) return rc;
+  {
+    BwdArgs BA = bwd_args(c, slot, is_start != 0, with_init);
+    if (!with_init) { BA.ix = nullptr; BA.iv = nullptr; BA.slot_ix = 0; }     // the per-step call takes its seeds from its arguments only
+    if ((rc = enqueue_adjoint_step(c, BA))) return rc;
+  }
   if ((rc = d2h_planar(c, c->GX, dL_dx, N, 0, true))) return rc;
   if ((rc = d2h_planar(c, c->GV, dL_dv, N, 1, true))) return rc;
-  if (dL_dxfixed && Af > 0 && (rc = d2h_planar(c, c->DXF, dL_dxfixed, Af, 2, false))) return rc;
+  if (dL_dxfixed && Af > 0 && (rc = d2h_planar(c, c->DXF + (size_t) c->B * 3 * Af * slot, dL_dxfixed, Af, 2, false))) return rc;
   std::vector<float> dmu((size_t) c->B * G);
   HIPCHK(c, hipMemcpyAsync(dmu.data(), c->DMU, dmu.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   if (stats) HIPCHK(c, hipMemcpyAsync(stats, c->bstats + (size_t) c->B * slot, sizeof(dc_bwd_stats) * c->B, hipMemcpyDeviceToHost, c->stream));
@@ -1025,18 +1049,28 @@ int dc_rollout_forward(dc_ctx *c, int slot, int nsteps) {
   if (fused) {
     // all steps of a rollout run inside ONE launch (self-collision detection inlined per step), so a rollout never waits
     // for the slowest rollout of the batch between steps
-    for (int k = 0; k < nsteps && c->S.Af > 0; k++)
+    // a schedule (dc_set_*_schedule) has to cover all steps of a fused sweep or none of them
+    int nxf = 0, nfu = 0, nfvs = 0;
+    for (int k = 1; k <= nsteps; k++) { nxf += c->sched_xf[slot + k]; nfu += c->sched_fu[slot + k]; nfvs += c->sched_fvs[slot + k]; }
+    if ((nxf % nsteps) || (nfu % nsteps) || (nfvs % nsteps))
+      return fail(c, DC_ERR_INVALID, "dc_rollout_forward: a fixed-point / force schedule covers only part of the steps " + std::to_string(slot) + " .. " + std::to_string(slot + nsteps));
+    for (int k = 0; k < nsteps && c->S.Af > 0 && nxf == 0; k++)
       HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
-    FwdArgs A = fwd_args(c, slot);
+    FwdArgs A = fwd_args(c, slot);           // (points x_fixed / fu / fv_scale at the first step's schedule entries)
+    if (nxf) A.slot_xfix = (size_t) c->B * 3 * c->S.Af;
+    if (nfu) A.slot_fu = (size_t) c->B * 3;
+    if (nfvs && A.fv_scale) A.slot_fvs = (size_t) c->B;
     A.nsteps = nsteps; A.inline_detect = self_on ? 1 : 0;
     if ((rc = enqueue_pd_step(c, A))) return rc;
   } else {
     for (int k = 0; k < nsteps; k++) {
-      if (c->S.Af > 0) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
+      if (c->S.Af > 0 && !c->sched_xf[slot + k + 1]) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * c->S.Af * (slot + k + 1), c->xf_cur, sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
       if (self_on) launch_self_detect(c->S, c->W, fwd_args(c, slot + k), c->B, c->stream);
       if ((rc = enqueue_pd_step(c, fwd_args(c, slot + k)))) return rc;
     }
   }
+  if (c->S.Af > 0 && c->sched_xf[slot + nsteps])      // later unscheduled steps continue from the last scheduled targets
+    HIPCHK(c, hipMemcpyAsync(c->xf_cur, c->XF + (size_t) c->B * 3 * c->S.Af * (slot + nsteps), sizeof(float) * c->B * 3 * c->S.Af, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
   HIPCHK(c, hipGetLastError());
   // kernel-time accounting is resolved lazily in dc_kernel_times / dc_sync
@@ -1072,6 +1106,12 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   HIPCHK(c, hipEventRecord(c->ev_a, c->stream));
   static const bool fuse_ok = !(getenv("DC_FUSE_STEPS") && getenv("DC_FUSE_STEPS")[0] == '0');     // development switch
   if ((rc = cluster_begin(c))) return rc;
+  if (c->SEEDX) {
+    int ns = 0;
+    for (int k = 0; k < nsteps; k++) ns += c->sched_seed[slot - k - 1];
+    if (ns % nsteps) return fail(c, DC_ERR_INVALID, "dc_rollout_backward: the seed schedule covers only part of the slots " + std::to_string(slot - nsteps) + " .. " + std::to_string(slot - 1));
+  }
+  if (c->S.Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF + (size_t) c->B * 3 * c->S.Af * (slot - nsteps + 1), 0, sizeof(float) * c->B * 3 * c->S.Af * nsteps, c->stream));
   if (fuse_ok && nsteps > 1) {
     BwdArgs A = bwd_args(c, slot, slot == 1, false);
     A.nsteps = nsteps;                       // the whole sweep of a rollout in one launch
@@ -1103,6 +1143,114 @@ int dc_get_gradient(dc_ctx *c, double *dL_dx, double *dL_dv, double *dL_dmu) {
     std::vector<float> dmu((size_t) c->B * G);
     HIPCHK(c, hipMemcpy(dmu.data(), c->DMU, dmu.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < dmu.size(); k++) dL_dmu[k] = dmu[k];
+  }
+  return DC_OK;
+}
+
+// ---- device-resident schedules of the fused rollouts (stepFixPoints / fillForces / the per-frame loss seeds
+// of runBackwardTask, Simulation.cpp:55-116, 964-1018, 3938-3952, as streams on the device) ----
+int dc_set_fixed_point_schedule(dc_ctx *c, int slot0, int nsteps, const double *xf) {
+  int rc = check_batch(c, slot0, slot0 + nsteps);
+  if (rc) return rc;
+  if (nsteps < 1 || !xf) return fail(c, DC_ERR_INVALID, "dc_set_fixed_point_schedule: null schedule");
+  const int Af = c->S.Af;
+  if (Af <= 0) return DC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t per = (size_t) c->B * 3 * Af;
+  for (int k = 0; k < nsteps; k++) {
+    if ((rc = h2d_planar(c, xf + per * k, c->XF + per * (slot0 + k + 1), Af, k & 3, false))) return rc;
+    c->sched_xf[slot0 + k + 1] = 1;
+    if ((k & 3) == 3) HIPCHK(c, hipStreamSynchronize(c->stream));      // the four staging buffers are reused
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DC_OK;
+}
+
+int dc_set_force_schedule(dc_ctx *c, int slot0, int nsteps, const double *fu, const double *fv_scale) {
+  int rc = check_batch(c, slot0, slot0 + nsteps);
+  if (rc) return rc;
+  if (nsteps < 1) return fail(c, DC_ERR_INVALID, "dc_set_force_schedule: nsteps < 1");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (fu) {
+    std::vector<float> v((size_t) nsteps * c->B * 3);
+    for (size_t k = 0; k < v.size(); k++) v[k] = (float) fu[k];
+    HIPCHK(c, hipMemcpy(c->FU_S + (size_t) c->B * 3 * (slot0 + 1), v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (fv_scale) {
+    std::vector<float> v((size_t) nsteps * c->B);
+    for (size_t k = 0; k < v.size(); k++) v[k] = (float) fv_scale[k];
+    HIPCHK(c, hipMemcpy(c->FVS_S + (size_t) c->B * (slot0 + 1), v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  for (int k = 1; k <= nsteps; k++) { c->sched_fu[slot0 + k] = fu ? 1 : 0; c->sched_fvs[slot0 + k] = fv_scale ? 1 : 0; }
+  return DC_OK;
+}
+
+int dc_set_seed_schedule(dc_ctx *c, int slot0, int nslots, const double *dL_dx, const double *dL_dv) {
+  int rc = check_batch(c, slot0, slot0 + nslots - 1);
+  if (rc) return rc;
+  if (nslots < 1 || !dL_dx) return fail(c, DC_ERR_INVALID, "dc_set_seed_schedule: null schedule");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c), slots = (size_t) c->tape + 1;
+  if (!c->SEEDX) {
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->SEEDX, se * slots))) return rc;
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->SEEDV, se * slots))) return rc;
+  }
+  const int N = c->host.N;
+  for (int k = 0; k < nslots; k++) {
+    if ((rc = h2d_planar(c, dL_dx + (size_t) 3 * N * c->B * k, c->SEEDX + se * (slot0 + k), N, 0, true))) return rc;
+    if (dL_dv) { if ((rc = h2d_planar(c, dL_dv + (size_t) 3 * N * c->B * k, c->SEEDV + se * (slot0 + k), N, 1, true))) return rc; }
+    else HIPCHK(c, hipMemsetAsync(c->SEEDV + se * (slot0 + k), 0, se * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sched_seed[slot0 + k] = 1;
+  }
+  return DC_OK;
+}
+
+int dc_clear_schedules(dc_ctx *c) {
+  if (!c || c->B <= 0) return fail(c, DC_ERR_STATE, "dc_clear_schedules: no batch");
+  std::fill(c->sched_xf.begin(), c->sched_xf.end(), 0); std::fill(c->sched_fu.begin(), c->sched_fu.end(), 0);
+  std::fill(c->sched_fvs.begin(), c->sched_fvs.end(), 0); std::fill(c->sched_seed.begin(), c->sched_seed.end(), 0);
+  return DC_OK;
+}
+
+int dc_set_gradient(dc_ctx *c, const double *dL_dx, const double *dL_dv) {
+  int rc = check_batch(c, 0, 0);
+  if (rc) return rc;
+  if (!dL_dx || !dL_dv) return fail(c, DC_ERR_INVALID, "dc_set_gradient: null gradient");
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = h2d_planar(c, dL_dx, c->GX, c->host.N, 0, true))) return rc;
+  if ((rc = h2d_planar(c, dL_dv, c->GV, c->host.N, 1, true))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->DMU, 0, sizeof(float) * c->B * c->S.ngroups, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return DC_OK;
+}
+
+int dc_get_states(dc_ctx *c, int slot0, int nslots, double *x, double *v) {
+  int rc = check_batch(c, slot0, slot0 + nslots - 1);
+  if (rc) return rc;
+  if (nslots < 1) return fail(c, DC_ERR_INVALID, "dc_get_states: nslots < 1");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c);
+  for (int k = 0; k < nslots; k++) {
+    if (x && (rc = d2h_planar(c, c->X + se * (slot0 + k), x + se * k, c->host.N, 0, true))) return rc;
+    if (v && (rc = d2h_planar(c, c->V + se * (slot0 + k), v + se * k, c->host.N, 1, true))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return DC_OK;
+}
+
+int dc_get_dxfixed(dc_ctx *c, int slot0, int nslots, double *dL_dxfixed) {
+  int rc = check_batch(c, slot0, slot0 + nslots - 1);
+  if (rc) return rc;
+  if (slot0 < 1 || nslots < 1 || !dL_dxfixed) return fail(c, DC_ERR_INVALID, "dc_get_dxfixed: slot 0 has no record");
+  const int Af = c->S.Af;
+  if (Af <= 0) return DC_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t per = (size_t) c->B * 3 * Af;
+  for (int k = 0; k < nslots; k++) {
+    if ((rc = d2h_planar(c, c->DXF + per * (slot0 + k), dL_dxfixed + per * k, Af, 2, false))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return DC_OK;
 }

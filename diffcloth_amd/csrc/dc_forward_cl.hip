@@ -60,7 +60,6 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off, *scr = W.cg_r + off;
   const BufVec vnb = buf_vec(vnow, N, X.same_xcd);
   const BufVec dpb = buf_vec(W.cg_x + off, N, X.same_xcd);    // scaled correction of the previous PD iteration (seed of the next solve)
-  const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
   const int w0 = part * CL.wpp, w1 = min(CL.nwin, w0 + CL.wpp);
 
   for (int step = 0; step < A.nsteps; step++) {
@@ -71,6 +70,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     else { if (!xch_barrier<THREADS>(X)) return; }
   }
   const size_t so = (size_t) step * A.slot_state;
+  // this step's fixed-point targets and external forces (constant over the launch, or one set per step: dc_set_*_schedule)
+  const float *xfix = A.x_fixed + (size_t) step * A.slot_xfix + (size_t) b * 3 * S.Af;
+  const float *fu_s = A.fu ? A.fu + (size_t) step * A.slot_fu : nullptr;
+  const float *fvs_s = A.fv_scale ? A.fv_scale + (size_t) step * A.slot_fvs : nullptr;
   // the tape state and f / r are read across parts: write-through stores, L1-bypassing loads (xnb, vinb, rfb, rrb, xob, vob)
   const BufVec xnb = buf_vec(A.x_in + off + so, N, X.same_xcd), vinb = buf_vec(A.v_in + off + so, N, X.same_xcd);
   const BufVec rfb = buf_vec(A.rec_f + off + so, N, X.same_xcd), rrb = buf_vec(A.rec_r + off + so, N, X.same_xcd);
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // detection + layering of this step: part 0, then the lists change hands
     X.site = 2;
-    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, A.fv, (int *) lds); __syncthreads(); }
+    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lds); __syncthreads(); }
   }
   // number of self contacts of this step: part 0 knows it (its own detection, or the stand-alone detection kernel's record) and
   // hands it to the others inside an exchange, so that no part ever has to read it from memory another part wrote
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   const float *mu = A.mu + (size_t) b * S.ngroups;
   const float h = S.h;
   const f3 grav = mk(S.gx, S.gy, S.gz);
-  const f3 fu = A.fu ? mk(A.fu[3 * b], A.fu[3 * b + 1], A.fu[3 * b + 2]) : mk(0, 0, 0);
+  const f3 fu = fu_s ? mk(fu_s[3 * b], fu_s[3 * b + 1], fu_s[3 * b + 2]) : mk(0, 0, 0);
+  const float fvs = fvs_s ? fvs_s[b] : 1.f;
 
   // ---- step set-up on the own rows: s_n, initial guess, contact detection (Simulation.cpp:1097-1160, :1254-1256) ----
   float part_s = 0.f;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     const float m = S.mass[i];
     f3 v = ld3c(vinb, i);
     f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
-    if (A.fv) fext = fext + ld3(A.fv + off, i, N);
+    if (A.fv) fext = fext + ld3(A.fv + off, i, N) * fvs;
     f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
     st3c(vnb, i, v0);
     st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h

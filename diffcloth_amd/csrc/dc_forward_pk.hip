@@ -59,7 +59,6 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off;
   float *dprev = W.cg_x + off;                // scaled correction of the previous PD iteration (first search direction of the next solve)
   float *corner = W.corner + (size_t) b * 3 * NC;
-  const float *xfix = A.x_fixed + (size_t) b * 3 * S.Af;
   // A.nsteps consecutive time steps of this rollout in one launch (dc_rollout_forward without self-collision): rollouts
   // are independent, so nothing forces them to wait for the slowest one after every step. Step s reads tape slot k + s
   // and writes slot k + s + 1 (slot strides: A.slot_state floats, A.slot_prim ints, A.slot_stats entries).
@@ -69,17 +68,22 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   const float *xn = A.x_in + off + so, *vn = A.v_in + off + so;
   float *rec_f = A.rec_f + off + so, *rec_r = A.rec_r + off + so, *rec_n = A.rec_n + off + so;
   int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
+  // this step's fixed-point targets and external forces (constant over the launch, or one set per step: dc_set_*_schedule)
+  const float *xfix = A.x_fixed + (size_t) step * A.slot_xfix + (size_t) b * 3 * S.Af;
+  const float *fu_s = A.fu ? A.fu + (size_t) step * A.slot_fu : nullptr;
+  const float *fvs_s = A.fv_scale ? A.fv_scale + (size_t) step * A.slot_fvs : nullptr;
   SelfRec srec = A.self;                      // self contacts of this step's record
   srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
   srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // fused sweeps: detection + layering of this step run here (dc_selflib.h)
-    self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, A.fu, A.fv, (int *) lp);
+    self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lp);
     __syncthreads();
   }
   const float *mu = A.mu + (size_t) b * S.ngroups;
   const float h = S.h;
   const f3 grav = mk(S.gx, S.gy, S.gz);
-  const f3 fu = A.fu ? mk(A.fu[3 * b], A.fu[3 * b + 1], A.fu[3 * b + 2]) : mk(0, 0, 0);
+  const f3 fu = fu_s ? mk(fu_s[3 * b], fu_s[3 * b + 1], fu_s[3 * b + 2]) : mk(0, 0, 0);
+  const float fvs = fvs_s ? fvs_s[b] : 1.f;
 
   // ---- step set-up: s_n, initial guess, contact detection (Simulation.cpp:1097-1160, :1254-1256) ----
   float part = 0.f;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     const float m = S.mass[i];
     f3 v = ld3(vn, i, N);
     f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
-    if (A.fv) fext = fext + ld3(A.fv + off, i, N);
+    if (A.fv) fext = fext + ld3(A.fv + off, i, N) * fvs;
     f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
     st3(vnow, i, N, v0);
     st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h

@@ -133,7 +133,7 @@ __device__ int contact_layering_rest(const SelfTmp &t, int nact, int remaining) 
 // rec_prim / self / fu are the step's record pointers of the whole batch (indexed by b inside). Call with all threads.
 template <int THREADS>
 __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const DevWork &W, int b, const float *x_in, const float *v_in,
-                                                    int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, const float *fv_all, int *lds) {
+                                                    int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, const float *fv_all, const float *fvs_all, int *lds) {
   float *redf = (float *) lds;              // [16]
   int *hist = lds + 16;                     // [kSelfCells + 1]
   int *cursor = hist + kSelfCells + 1;      // [kSelfCells]
@@ -155,10 +155,11 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
   const f3 grav = mk(S.gx, S.gy, S.gz);
   const f3 fu = fu_all ? mk(fu_all[3 * b], fu_all[3 * b + 1], fu_all[3 * b + 2]) : mk(0, 0, 0);
   const float *fv = fv_all ? fv_all + (size_t) b * 3 * N : nullptr;
+  const float fvs = fvs_all ? fvs_all[b] : 1.f;
   auto v_guess = [&](int i) {                                        // (s_n - x_n) / h
     const float m = S.mass[i];
     f3 fext = grav * m + fu;
-    if (fv) fext = fext + ld3(fv, i, N);
+    if (fv) fext = fext + ld3(fv, i, N) * fvs;
     return ld3(vn, i, N) + fext * (h / m);
   };
 

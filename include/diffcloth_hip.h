@@ -206,6 +206,31 @@ int dc_seed_gradient(dc_ctx *ctx, int slot, const double *target /*3N or NULL*/,
  * individual steps is only available through dc_step_backward. Returns when the sweep has finished on the device.    */
 int dc_rollout_backward(dc_ctx *ctx, int slot, int nsteps);
 int dc_get_gradient(dc_ctx *ctx, double *dL_dx, double *dL_dv, double *dL_dmu /*B*num_groups or NULL*/);
+/* Carried gradient of the backward sweep set from the host (the loss gradient w.r.t. the last state, Simulation.cpp:3925-3936);
+ * also clears the accumulated dL_dmu. */
+int dc_set_gradient(dc_ctx *ctx, const double *dL_dx /*B*3N*/, const double *dL_dv /*B*3N*/);
+
+/* ---- device-resident schedules: what the host loop of Simulation::runBackwardTask (Simulation.cpp:3853-3961) feeds into every
+ * step — stepFixPoints targets (:964-1018), fillForces terms (:55-116), the per-frame loss gradients dL_dxinit / dL_dvinit
+ * (:3938-3952) — uploaded once per rollout, so that a whole loss + gradient evaluation is dc_rollout_forward + dc_rollout_backward.
+ * A schedule entry belongs to a tape slot and stays until it is overwritten, dc_clear_schedules or dc_alloc_batch; the per-step
+ * calls honour force / fixed-point entries of their slot as well (explicit fixed_pts of dc_step_forward win). A fused sweep needs
+ * each kind of schedule on all of its steps or on none (DC_ERR_INVALID otherwise). */
+/* targets of the steps slot0+k -> slot0+k+1, k = 0..nsteps-1: xf[k*B*3Af ...] laid out like dc_step_forward's fixed_pts */
+int dc_set_fixed_point_schedule(dc_ctx *ctx, int slot0, int nsteps, const double *xf /*nsteps*B*3Af*/);
+/* external forces of those steps: fu = uniform force per rollout (wind * windNorm * windFactor(t)), fv_scale = factor on the
+ * per-vertex force of dc_set_vertex_forces (windFactor(t) for a wind with fall-off; pass the factor-free field there). Either may
+ * be NULL (= the current dc_set_uniform_force value / factor 1). */
+int dc_set_force_schedule(dc_ctx *ctx, int slot0, int nsteps, const double *fu /*nsteps*B*3 or NULL*/, const double *fv_scale /*nsteps*B or NULL*/);
+/* loss gradient w.r.t. the state AT slot slot0+k (k = 0..nslots-1): added by dc_rollout_backward when its sweep arrives at that
+ * state, i.e. it is the dL_dxinit / dL_dvinit argument of the step through record slot0+k+1. dL_dv may be NULL (zeros).
+ * Costs two more tape-sized arrays, allocated on first use. dc_step_backward ignores it (its seeds are its arguments). */
+int dc_set_seed_schedule(dc_ctx *ctx, int slot0, int nslots, const double *dL_dx /*nslots*B*3N*/, const double *dL_dv /*or NULL*/);
+int dc_clear_schedules(dc_ctx *ctx);
+/* states of nslots consecutive slots in one call: x[k*B*3N ...], v likewise (either may be NULL) */
+int dc_get_states(dc_ctx *ctx, int slot0, int nslots, double *x, double *v);
+/* dL_dxfixed of the steps through records slot0 .. slot0+nslots-1 of the last backward sweep / step (B*3Af each) */
+int dc_get_dxfixed(dc_ctx *ctx, int slot0, int nslots, double *dL_dxfixed /*nslots*B*3Af*/);
 int dc_get_stats(dc_ctx *ctx, int slot, dc_step_stats *fwd /*B or NULL*/, dc_bwd_stats *bwd /*B or NULL*/);
 int dc_sync(dc_ctx *ctx);
 /* Split execution: with fewer rollouts than compute units (BASELINE C4 sharded over 8 GPUs: 32 per GPU; hatController.py: 20 rollouts)

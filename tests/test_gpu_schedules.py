@@ -1,0 +1,138 @@
+"""Device-resident schedules (dc_set_fixed_point_schedule / dc_set_force_schedule / dc_set_seed_schedule): what the host loop of
+Simulation::runBackwardTask feeds into every step (stepFixPoints targets, fillForces terms, per-frame loss gradients; reference
+Simulation.cpp:55-116, 964-1018, 3938-3952) uploaded once, so that a loss + gradient evaluation is two launches. The fused,
+scheduled sweeps must reproduce the per-step calls that receive the same values as arguments: bitwise in the forward direction
+(same kernels, same fp32 inputs), to solver tolerance in the backward direction.
+"""
+import numpy as np
+import pytest
+
+import meshes
+from diffcloth_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-30)
+
+
+def scene(nx, att, selfcollision=0):
+    V, F = meshes.grid_cloth(nx, nx, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    c = f32(meshes.sphere_scene_center(V, 2.0))
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_attachments(att)
+    e.set_params(time_step=1 / 180, density=0.3, k_stretch=150.0, k_bend=0.05, forward_tol=1e-7, backward_tol=1e-7, cg_rel_tol=1e-5,
+                 cg_max_iter=2000, gradient_clipping=0, selfcollision_enabled=selfcollision, adjoint_mode=1, adjoint_rel_tol=1e-7)
+    e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=c, radius=2.0, mu=0.4)])
+    e.build()
+    return V, F, e
+
+
+def streams(V, att, B, S, rng):
+    """per-step fixed-point targets (moving clips), uniform forces and factors on the per-vertex force (exact in fp32)"""
+    N = V.shape[0]
+    top = V[list(att)]
+    XF = np.stack([np.stack([f32((top + np.array([0.01 * (s + 1) * (b + 1), 0.02 * (s + 1), 0.0])).reshape(-1)) for b in range(B)]) for s in range(S)])
+    FU = f32(0.02 * rng.standard_normal((S, B, 3)))
+    FV = f32(0.001 * rng.standard_normal((B, 3 * N)))
+    FVS = np.array([[0.5, 1.0, 0.25, 2.0][(s + b) % 4] for s in range(S) for b in range(B)]).reshape(S, B)     # powers of two: exact under FMA contraction
+    return XF, FU, FV, FVS
+
+
+@pytest.mark.parametrize("nx,cluster", [(17, 0), (48, 4)])
+def test_scheduled_rollout_equals_per_step_calls(nx, cluster, monkeypatch):
+    """forward: fixed points + uniform force + scaled per-vertex force per step; backward: per-frame loss seeds, dL_dxfixed per slot"""
+    if cluster:
+        monkeypatch.setenv("DC_CLUSTER", str(cluster))
+    rng = np.random.default_rng(5)
+    att = (0, nx - 1)
+    B, S = 2, 5
+    V, F, e = scene(nx, att)
+    N = V.shape[0]
+    e.alloc_batch(B, S)
+    assert e.cluster() == (cluster if cluster else 1)
+    XF, FU, FV, FVS = streams(V, att, B, S, rng)
+    X0 = np.stack([f32(V.reshape(-1)), f32(V.reshape(-1) + np.tile([0.05, 0.0, 0.02], N))])
+    V0 = np.zeros_like(X0)
+
+    # ---- (a) per-step calls: every value handed over as an argument of its step
+    e.set_state(0, X0, V0)
+    for s in range(S):
+        e.set_uniform_force(FU[s])
+        e.set_vertex_forces(FV * FVS[s][:, None])
+        e.step_forward(s, fixed_pts=XF[s])
+    xa, va = e.get_states(0, S + 1)
+    seeds = f32(1e-3 * rng.standard_normal((S + 1, B, 3 * N)))          # loss gradient w.r.t. the state of every slot
+    gx, gv = seeds[S].copy(), np.zeros((B, 3 * N))
+    dxf_a, par_a = {}, {}
+    dmu_a = np.zeros((B, 1))
+    for s in range(S, 0, -1):
+        out = e.step_backward(s, gx, gv, dL_dxinit=seeds[s - 1], dL_dvinit=np.zeros((B, 3 * N)), is_start=(s == 1))
+        gx, gv = out["dL_dx"], out["dL_dv"]
+        dxf_a[s] = out["dL_dxfixed"].copy(); par_a[s] = e.get_param_gradients(s); dmu_a += out["dL_dmu"]
+
+    # ---- (b) schedules + two launches
+    e.set_uniform_force(None)
+    e.set_vertex_forces(FV)                                             # the factor-free field; the schedule carries the factors
+    e.set_state(0, X0, V0)
+    e.set_fixed_point_schedule(0, XF)
+    e.set_force_schedule(0, S, fu=FU, fv_scale=FVS)
+    e.rollout_forward(0, S)
+    xb, vb = e.get_states(0, S + 1)
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(va, vb)
+    e.set_seed_schedule(0, seeds[:S])
+    e.set_gradient(seeds[S], np.zeros((B, 3 * N)))
+    e.rollout_backward(S, S)
+    dx, dv, dmu = e.get_gradient()
+    dxf_b = e.get_dxfixed(1, S)
+    print(f"\n[schedules nx={nx} K={e.cluster()}] fused vs per-step: dL_dx {rel(dx, gx):.2e} dL_dv {rel(dv, gv):.2e} dmu {rel(dmu, dmu_a):.2e} "
+          f"dxfixed {max(rel(dxf_b[s - 1], dxf_a[s]) for s in range(1, S + 1)):.2e}")
+    assert rel(dx, gx) <= 2e-6 and rel(dv, gv) <= 2e-6
+    np.testing.assert_allclose(dmu, dmu_a, rtol=1e-4, atol=1e-9)
+    for s in range(1, S + 1):
+        assert rel(dxf_b[s - 1], dxf_a[s]) <= 2e-6
+        pb = e.get_param_gradients(s)
+        for key in ("dL_dk", "dL_ddensity", "sum_dfext"):
+            np.testing.assert_allclose(pb[key], par_a[s][key], rtol=1e-4, atol=1e-10)
+
+    # ---- a schedule that covers only part of a fused sweep is an error, not a silent mix
+    e.clear_schedules()
+    e.set_force_schedule(0, 2, fu=FU[:2])
+    with pytest.raises(capi.DcError, match="covers only part"):
+        e.rollout_forward(0, S)
+    e.clear_schedules()
+    e.set_state(0, X0, V0)
+    e.rollout_forward(0, S)                                             # and without schedules the current values apply again
+    xc, _ = e.get_states(S, 1)
+    assert np.abs(xc[0] - xa[S]).max() > 1e-6
+
+
+def test_schedules_with_self_collision_and_explicit_fixed_points_override():
+    V, F, e = scene(24, (0, 23), selfcollision=1)
+    rng = np.random.default_rng(2)
+    B, S = 1, 3
+    e.alloc_batch(B, S)
+    XF, FU, FV, FVS = streams(V, (0, 23), B, S, rng)
+    X0 = f32(V.reshape(-1))[None, :]
+    e.set_state(0, X0, np.zeros_like(X0))
+    e.set_fixed_point_schedule(0, XF)
+    e.set_force_schedule(0, S, fu=FU)
+    e.rollout_forward(0, S)
+    xa, _ = e.get_states(0, S + 1)
+    # the per-step call of a scheduled slot uses the schedule, explicit fixed points win over it
+    e.set_state(0, X0, np.zeros_like(X0))
+    for s in range(S):
+        e.step_forward(s)
+    xb, _ = e.get_states(0, S + 1)
+    np.testing.assert_array_equal(xa, xb)
+    e.step_forward(S - 1, fixed_pts=XF[0])
+    xc, _ = e.get_states(S, 1)
+    assert np.abs(xc[0] - xa[S]).max() > 1e-6
