@@ -2,8 +2,9 @@
 // seeds (Simulation::calculateLossAndGradient, reference Simulation.cpp:3237-3488), parameter injection
 // (resetSystemWithParams, :3490-3584), the forward rollout + backward sweep (runBackwardTask, :3853-3961) and the
 // OptimizeHelper that maps a flat parameter vector to those (optimization/OptimizeHelper.cpp,
-// optimization/OptimizationTaskSetup.cpp). Host code only: every time step goes through Simulation::step() /
-// stepBackward(), i.e. through the dc_* C-ABI.
+// optimization/OptimizationTaskSetup.cpp). Host code only: every time step goes through the dc_* C-ABI — step by step
+// (Simulation::step() / stepBackward()) or, where the scene allows it, as one fused launch per direction with the per-step inputs
+// uploaded as schedules (Simulation::rolloutOnDevice / sweepBackwardOnDevice).
 #include "optimize.h"
 #include <algorithm>
 #include <cmath>
@@ -164,7 +165,7 @@ std::vector<BackwardInformation> Simulation::runBackwardTask(BackwardTaskInforma
   if (!skipForward) resetSystemWithParams(task, guess);
   forwardConvergenceThreshold = task.forwardAccuracyLevel;
   backwardConvergenceThreshold = task.backwardAccuracyLevel;
-  if (!skipForward)
+  if (!skipForward && !rolloutOnDevice(FORWARD_STEPS))        // all steps in one launch where the scene allows it (simulation.h)
     for (int i = 0; i < FORWARD_STEPS; i++) step();
   BackwardInformation first;
   if (forwardRecords.empty()) { first.loss = 0; return {first}; }
@@ -181,11 +182,21 @@ std::vector<BackwardInformation> Simulation::runBackwardTask(BackwardTaskInforma
   if (FORWARD_STEPS + 1 != frames)
     std::fprintf(stderr, "WARNING: invariant violated: FORWARD_STEPS:%d fowardRecords: %d\n", FORWARD_STEPS, frames);
   VecXd dL_dxinit, dL_dvinit;
-  for (int idx = frames - 1; idx >= 1; idx--) {
-    calculateLossAndGradient(lossType, lossInfo, dL_dxinit, dL_dvinit, idx - 1, false);
-    derivative = stepBackward(task, derivative, forwardRecords[idx], (idx - 1) == 0, dL_dxinit, dL_dvinit);
-    all.push_back(derivative);
+  // the whole sweep in one launch with the per-frame loss gradients as a device schedule, or step by step
+  std::vector<BackwardInformation> fused;
+  if (deviceResidentRollouts && !needsForceVector(task)) {
+    std::vector<std::pair<VecXd, VecXd>> seeds(frames);
+    for (int i = 0; i + 1 < frames; i++) calculateLossAndGradient(lossType, lossInfo, seeds[i].first, seeds[i].second, i, false);
+    seeds[frames - 1] = {dL_dlastx, dL_dlastv};
+    fused = sweepBackwardOnDevice(task, seeds, L);
   }
+  if (!fused.empty()) all = std::move(fused);
+  else
+    for (int idx = frames - 1; idx >= 1; idx--) {
+      calculateLossAndGradient(lossType, lossInfo, dL_dxinit, dL_dvinit, idx - 1, false);
+      derivative = stepBackward(task, derivative, forwardRecords[idx], (idx - 1) == 0, dL_dxinit, dL_dvinit);
+      all.push_back(derivative);
+    }
   std::reverse(all.begin(), all.end());
   all[0].correspondingForwardIdxInStats = stats.totalForwardSim - 1;
   stats.totalBackprop++;
@@ -331,7 +342,10 @@ VecXd OptimizeHelper::getRandomParam(int randSeed) {
     VecXd x(totalParamNumber);
     for (int i = 0; i < totalParamNumber; i++) {
       const double u = (double) std::rand() / RAND_MAX;
-      const double lo = std::max(paramLowerBound[i], -50.0), hi = std::min(paramUpperBound[i], 50.0);
+      // uniform in the parameter's bounds (OptimizeHelper.cpp:316-322); the boxes this host class does not model (spline end points,
+      // x0: bounded by the scene box in the reference, +-1e3 / +-1e30 here) are cut to +-50 — only where that leaves an interval
+      double lo = paramLowerBound[i], hi = paramUpperBound[i];
+      if (std::max(lo, -50.0) < std::min(hi, 50.0)) { lo = std::max(lo, -50.0); hi = std::min(hi, 50.0); }
       x[i] = lo + u * (hi - lo);
     }
     ParamInfo param = vecXdToParamInfo(x);

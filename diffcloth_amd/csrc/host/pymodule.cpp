@@ -214,6 +214,10 @@ PYBIND11_MODULE(diffcloth_py, m) {
                     [](const Simulation &s) { py::list out; for (auto &g : s.perStepGradient) out.append(toNp(g)); return out; },
                     [](Simulation &s, const std::vector<NpArr> &v) { s.perStepGradient.clear(); for (auto &a : v) s.perStepGradient.push_back(toVec(a)); })
       .def_readwrite("gradientClipping", &Simulation::gradientClipping)
+      // additive: runBackwardTask / OptimizeHelper evaluations as one fused launch per direction (simulation.h); records of such an
+      // evaluation carry x, v, fixed points and statistics, loadRecordDetails(i) fetches f, r and the contact lists of record i
+      .def_readwrite("deviceResidentRollouts", &Simulation::deviceResidentRollouts)
+      .def("loadRecordDetails", &Simulation::loadRecordDetails)
       .def_readwrite("controlPointSplines", &Simulation::controlPointSplines)    // sysMat[0].controlPointSplines of the reference
       .def("resetSystemWithSplines", [](Simulation &s, const std::vector<Spline> &c) { s.resetSystem(c); })
       .def_readwrite("gradientClippingThreshold", &Simulation::gradientClippingThreshold)

@@ -400,6 +400,7 @@ void Simulation::resetSystem() {
   r0.stepIdx = 0; r0.deviceSlot = 0; r0.t = 0;
   forwardRecords.push_back(r0);
   fixedPointCur = fixedPointRest;
+  check(ctx, dc_clear_schedules(ctx), "dc_clear_schedules");     // per-slot inputs of an earlier device-resident evaluation
   check(ctx, dc_set_state(ctx, 0, r0.x.data(), r0.v.data()), "dc_set_state");
 }
 
@@ -627,6 +628,13 @@ BackwardInformation Simulation::stepBackwardNN(BackwardTaskInformation &taskInfo
 }
 
 // Simulation::stepBackward (Simulation.cpp:1455-1780)
+bool Simulation::needsForceVector(const BackwardTaskInformation &taskInfo) const {
+  // dL_dfext_vec = h^2 (I + dr_df)^T u* per vertex (:1700-1760): its plain sum comes with the parameter gradients; the
+  // per-vertex vector is needed only when a fall-off weighting, the force field or the per-step factors use it
+  return taskInfo.dL_dconstantForceField || taskInfo.dL_dwindFactor ||
+         ((taskInfo.dL_dfext || taskInfo.dL_dfwind) && sceneConfig.windConfig == WIND_SIN_AND_FALLOFF);
+}
+
 BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,
                                              const ForwardInformation &fwd, bool isStart, const VecXd &dL_dxinit, const VecXd &dL_dvinit) {
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
@@ -634,19 +642,38 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
   if (fwd.deviceSlot < 1 || fwd.deviceSlot >= (int) forwardRecords.size() + 1) throw std::runtime_error("stepBackward: record has no device slot");
   const auto tStart = std::chrono::steady_clock::now();
   pushParams();
-  BackwardInformation ret;
-  ret.dL_dx.resize(n3); ret.dL_dv.resize(n3);
-  VecXd dxf(3 * std::max<size_t>(Af, 1), 0.0);
-  VecXd dmu(std::max<size_t>(primitives.size(), 1), 0.0);
+  VecXd dx(n3), dv(n3);
+  DeviceBackwardStep d;
+  d.dxf.assign(3 * std::max<size_t>(Af, 1), 0.0);
+  d.dmu.assign(std::max<size_t>(primitives.size(), 1), 0.0);
   const bool haveInit = dL_dxinit.size() == n3 && dL_dvinit.size() == n3;
   dc_bwd_stats st;
   check(ctx, dc_step_backward(ctx, fwd.deviceSlot, gradient_new.dL_dx.data(), gradient_new.dL_dv.data(),
                               haveInit ? dL_dxinit.data() : nullptr, haveInit ? dL_dvinit.data() : nullptr, isStart ? 1 : 0,
-                              ret.dL_dx.data(), ret.dL_dv.data(), dxf.data(), dmu.data(), &st), "dc_step_backward");
-  ret.converged = st.converged != 0;
-  ret.backwardIters = st.adjoint_iters;
-  ret.backwardTotalIters = st.adjoint_iters + gradient_new.backwardTotalIters;
-  ret.convergedAccum = gradient_new.convergedAccum + (st.converged == 1 ? 1 : 0);
+                              dx.data(), dv.data(), d.dxf.data(), d.dmu.data(), &st), "dc_step_backward");
+  d.converged = st.converged; d.iters = st.adjoint_iters;
+  // parameter gradients of this step (Simulation.cpp:1672-1764): the device returns this step's contributions
+  check(ctx, dc_get_param_gradients(ctx, fwd.deviceSlot, d.par), "dc_get_param_gradients");
+  if (needsForceVector(taskInfo)) {
+    d.fvec.resize(n3);
+    check(ctx, dc_get_force_gradient(ctx, d.fvec.data()), "dc_get_force_gradient");
+  }
+  BackwardInformation ret = accumulateBackward(taskInfo, gradient_new, fwd, d);
+  ret.dL_dx = std::move(dx); ret.dL_dv = std::move(dv);
+  ret.totalRuntime = gradient_new.totalRuntime + std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tStart).count();
+  return ret;
+}
+
+BackwardInformation Simulation::accumulateBackward(BackwardTaskInformation &taskInfo, const BackwardInformation &gradient_new,
+                                                   const ForwardInformation &fwd, const DeviceBackwardStep &d) {
+  const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
+  const VecXd &dxf = d.dxf, &dmu = d.dmu, &fvec = d.fvec;
+  const double *par = d.par;
+  BackwardInformation ret;
+  ret.converged = d.converged != 0;
+  ret.backwardIters = d.iters;
+  ret.backwardTotalIters = d.iters + gradient_new.backwardTotalIters;
+  ret.convergedAccum = gradient_new.convergedAccum + (d.converged == 1 ? 1 : 0);
   ret.loss = gradient_new.loss;
   ret.dL_dxfixed.assign(3 * Af, 0.0);
   ret.dL_dxfixed_accum.assign(3 * Af, 0.0);
@@ -669,27 +696,16 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
       const int np = sp.getParameterNumber();
       std::vector<double> J = sp.dxfixed_dcontrolPoints(fwd.simDurartionFraction);
       for (int q = 0; q < np; q++)
-        for (int d = 0; d < 3; d++) ret.dL_dsplines[0][k][q] += J[(size_t) d * np + q] * dxf[3 * (size_t) sp.pFixed + d];
+        for (int dd = 0; dd < 3; dd++) ret.dL_dsplines[0][k][q] += J[(size_t) dd * np + q] * dxf[3 * (size_t) sp.pFixed + dd];
     }
   }
-  // parameter gradients of this step (Simulation.cpp:1672-1764): the device returns this step's contributions
-  double par[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  check(ctx, dc_get_param_gradients(ctx, fwd.deviceSlot, par), "dc_get_param_gradients");
   ret.dL_ddensity = gradient_new.dL_ddensity;
   if (taskInfo.dL_density) ret.dL_ddensity += par[3];
   ret.dL_dk_pertype = gradient_new.dL_dk_pertype;      // Constraint::ConstraintType order: spring, attachment, triangle, bending
   const double perType[4] = {0.0, par[2], par[0], par[1]};
   for (int k = 0; k < 4; k++)
     if (taskInfo.dL_dk_pertype[k]) ret.dL_dk_pertype[k] = gradient_new.dL_dk_pertype[k] + perType[k];
-  // dL_dfext_vec = h^2 (I + dr_df)^T u* per vertex (:1700-1760): its plain sum comes with the parameter gradients; the
-  // per-vertex vector is fetched only when a fall-off weighting, the force field or the per-step factors need it
-  const bool needVec = taskInfo.dL_dconstantForceField || taskInfo.dL_dwindFactor ||
-                       ((taskInfo.dL_dfext || taskInfo.dL_dfwind) && sceneConfig.windConfig == WIND_SIN_AND_FALLOFF);
-  VecXd fvec;
-  if (needVec) {
-    fvec.resize(n3);
-    check(ctx, dc_get_force_gradient(ctx, fvec.data()), "dc_get_force_gradient");
-  }
+  const bool needVec = needsForceVector(taskInfo) && fvec.size() == n3;
   const bool haveFall = windFallOff.size() == n3;
   double total[3] = {par[4], par[5], par[6]};       // sum_i dL_dfext_vec_i, fall-off weighted for WIND_SIN_AND_FALLOFF
   if (needVec && sceneConfig.windConfig == WIND_SIN_AND_FALLOFF && haveFall) {
@@ -698,14 +714,14 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
   }
   ret.dL_dfext = gradient_new.dL_dfext;
   if (taskInfo.dL_dfext)                        // :1700-1712
-    for (int d = 0; d < 3; d++) ret.dL_dfext[d] += total[d] * fwd.windFactor;
+    for (int dd = 0; dd < 3; dd++) ret.dL_dfext[dd] += total[dd] * fwd.windFactor;
   ret.dL_dconstantForceField = gradient_new.dL_dconstantForceField;
-  if (taskInfo.dL_dconstantForceField) {        // :1714-1718
+  if (taskInfo.dL_dconstantForceField && needVec) {        // :1714-1718
     if (ret.dL_dconstantForceField.size() != n3) ret.dL_dconstantForceField.assign(n3, 0.0);
     for (size_t k = 0; k < n3; k++) ret.dL_dconstantForceField[k] += fvec[k];
   }
   ret.dL_dwindtimestep = gradient_new.dL_dwindtimestep;
-  if (taskInfo.dL_dwindFactor) {                // :1720-1729
+  if (taskInfo.dL_dwindFactor && needVec) {                // :1720-1729
     if (ret.dL_dwindtimestep.size() <= (size_t) fwd.stepIdx) ret.dL_dwindtimestep.resize((size_t) fwd.stepIdx + 1, 0.0);
     double acc = 0;
     for (size_t k = 0; k < n3; k++) acc += fvec[k] * wind[k % 3] * windNorm * (haveFall ? windFallOff[k] : 1.0);
@@ -715,8 +731,8 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
   if (taskInfo.dL_dfwind) {                     // :1731-1760 (sin wind model, with or without fall-off)
     const double c = std::cos(windFrequency * fwd.t + windPhase);
     double tf = 0;
-    for (int d = 0; d < 3; d++) tf += total[d] * wind[d] * windNorm;
-    for (int d = 0; d < 3; d++) ret.dL_dwind[d] += total[d] * fwd.windFactor;
+    for (int dd = 0; dd < 3; dd++) tf += total[dd] * wind[dd] * windNorm;
+    for (int dd = 0; dd < 3; dd++) ret.dL_dwind[dd] += total[dd] * fwd.windFactor;
     ret.dL_dwind[3] += tf * c * 0.5 * fwd.t;
     ret.dL_dwind[4] += tf * c * 0.5;
   }
@@ -726,8 +742,147 @@ BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, 
       double prev = k < gradient_new.dL_dmu.size() ? gradient_new.dL_dmu[k].second : 0.0;
       ret.dL_dmu.push_back({prim, prev + (prim >= 0 && prim < (int) dmu.size() ? dmu[prim] : 0.0)});
     }
-  ret.totalRuntime = gradient_new.totalRuntime + std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tStart).count();
   return ret;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-resident evaluation: the loops of runBackwardTask (Simulation.cpp:3853-3961) as two launches
+// ---------------------------------------------------------------------------------------------------------------
+bool Simulation::rolloutOnDevice(int nsteps) {
+  static const bool envOff = std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS") && std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS")[0] == '0';
+  if (!deviceResidentRollouts || envOff || nsteps < 1 || forwardRecords.empty()) return false;
+  if (sceneConfig.trajectory == PER_STEP_TRAJECTORY) return false;          // the targets of a step arrive with the step (RL action)
+  if ((int) forwardRecords.size() + nsteps > tapeSlots) throw std::runtime_error("Simulation::rolloutOnDevice: tape exhausted (stepNum + 8 records)");
+  const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
+  const bool fallOff = windEnabled && windHasFallOff() && windFallOff.size() == n3;
+  const bool field = enableConstantForcefield && external_force_field.size() == n3;
+  if (fallOff && field) return false;                                        // two per-vertex terms with different time factors
+  const auto tStart = std::chrono::steady_clock::now();
+  pushParams();
+  const int slot0 = forwardRecords.back().deviceSlot;
+  const size_t first = forwardRecords.size();
+  // ---- the per-step inputs of step(): wind factor, fillForces terms, stepFixPoints targets (in order: the twirl is incremental) ----
+  std::vector<double> fu((size_t) nsteps * 3, 0.0), fvs(nsteps, 1.0), xf((size_t) nsteps * 3 * std::max<size_t>(Af, 1), 0.0);
+  for (int k = 0; k < nsteps; k++) {
+    const ForwardInformation &prev = forwardRecords.back();
+    ForwardInformation rec;
+    rec.t = prev.t + sceneConfig.timeStep;
+    rec.stepIdx = (int) forwardRecords.size();
+    rec.deviceSlot = prev.deviceSlot + 1;
+    rec.windFactor = windFactorAt(rec.t, rec.stepIdx);
+    if (windEnabled && !fallOff) for (int d = 0; d < 3; d++) fu[3 * (size_t) k + d] = wind[d] * windNorm * rec.windFactor;
+    if (fallOff) fvs[k] = rec.windFactor;
+    rec.x_fixedpoints = fixedPointTargets(rec.t);
+    for (size_t q = 0; q < 3 * Af; q++) xf[(size_t) k * 3 * Af + q] = rec.x_fixedpoints[q];
+    rec.simDurartionFraction = rec.t / (sceneConfig.timeStep * sceneConfig.stepNum);
+    rec.splines = controlPointSplines;
+    forwardRecords.push_back(std::move(rec));
+  }
+  check(ctx, dc_clear_schedules(ctx), "dc_clear_schedules");
+  if (fallOff || field) {
+    VecXd fv(n3, 0.0);
+    for (size_t k = 0; k < n3; k++) fv[k] = fallOff ? wind[k % 3] * windNorm * windFallOff[k] : external_force_field[k];
+    check(ctx, dc_set_vertex_forces(ctx, fv.data()), "dc_set_vertex_forces");
+  } else check(ctx, dc_set_vertex_forces(ctx, nullptr), "dc_set_vertex_forces");
+  check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
+  check(ctx, dc_set_force_schedule(ctx, slot0, nsteps, (windEnabled && !fallOff) ? fu.data() : nullptr, fallOff ? fvs.data() : nullptr), "dc_set_force_schedule");
+  if (Af > 0) check(ctx, dc_set_fixed_point_schedule(ctx, slot0, nsteps, xf.data()), "dc_set_fixed_point_schedule");
+  check(ctx, dc_rollout_forward(ctx, slot0, nsteps), "dc_rollout_forward");
+  // ---- records: states in one download, solver statistics per slot ----
+  VecXd X((size_t) nsteps * n3), V((size_t) nsteps * n3);
+  check(ctx, dc_get_states(ctx, slot0 + 1, nsteps, X.data(), V.data()), "dc_get_states");
+  const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tStart).count();
+  for (int k = 0; k < nsteps; k++) {
+    ForwardInformation &rec = forwardRecords[first + k];
+    const ForwardInformation &prev = forwardRecords[first + k - 1];
+    rec.x.assign(X.begin() + (size_t) k * n3, X.begin() + (size_t) (k + 1) * n3);
+    rec.v.assign(V.begin() + (size_t) k * n3, V.begin() + (size_t) (k + 1) * n3);
+    rec.x_prev = prev.x; rec.v_prev = prev.v;
+    dc_step_stats st;
+    check(ctx, dc_get_stats(ctx, rec.deviceSlot, &st, nullptr), "dc_get_stats");
+    rec.converged = st.converged != 0;
+    rec.convergeIter = st.pd_iters;
+    rec.totalConverged = prev.totalConverged + (rec.converged ? 1 : 0);
+    rec.cumulateIter = prev.cumulateIter + st.pd_iters;
+    rec.totalRuntime = prev.totalRuntime + us / nsteps;
+  }
+  return true;
+}
+
+void Simulation::loadRecordDetails(int recordIdx) {
+  if (recordIdx < 1 || recordIdx >= (int) forwardRecords.size()) throw std::runtime_error("loadRecordDetails: no such record");
+  ForwardInformation &rec = forwardRecords[recordIdx];
+  const size_t n3 = 3 * (size_t) N;
+  rec.f.resize(n3); rec.r.resize(n3);
+  check(ctx, dc_get_record(ctx, rec.deviceSlot, rec.f.data(), rec.r.data()), "dc_get_record");
+  std::vector<int> grp(N);
+  VecXd nrm(n3);
+  check(ctx, dc_get_contacts(ctx, rec.deviceSlot, grp.data(), nrm.data()), "dc_get_contacts");
+  rec.primitiveCollisions.clear();
+  for (int i = 0; i < N; i++)
+    if (grp[i] >= 0) rec.primitiveCollisions.push_back({grp[i], i, {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]}});
+  dc_step_stats st;
+  check(ctx, dc_get_stats(ctx, rec.deviceSlot, &st, nullptr), "dc_get_stats");
+  rec.selfCollisionLayers.clear();
+  if (st.self_contacts > 0) {
+    const int cap = st.self_contacts;
+    std::vector<int> pairs(2 * (size_t) cap), layer(cap);
+    VecXd sn(3 * (size_t) cap);
+    int cnt = 0, nl = 0;
+    check(ctx, dc_get_self_contacts(ctx, rec.deviceSlot, 0, cap, &cnt, &nl, pairs.data(), layer.data(), sn.data()), "dc_get_self_contacts");
+    rec.selfCollisionLayers.assign(std::max(nl, 1), {});
+    for (int k = 0; k < std::min(cnt, cap); k++)
+      rec.selfCollisionLayers[layer[k]].push_back({pairs[2 * k], pairs[2 * k + 1], layer[k], {sn[3 * k], sn[3 * k + 1], sn[3 * k + 2]}});
+  }
+}
+
+std::vector<BackwardInformation> Simulation::sweepBackwardOnDevice(BackwardTaskInformation &taskInfo,
+                                                                   const std::vector<std::pair<VecXd, VecXd>> &seeds, double loss) {
+  static const bool envOff = std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS") && std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS")[0] == '0';
+  const int frames = (int) forwardRecords.size();
+  if (!deviceResidentRollouts || envOff || frames < 2 || (int) seeds.size() != frames) return {};
+  if (needsForceVector(taskInfo)) return {};        // the per-vertex force gradient of every step is a host-side product: per-step path
+  if (forwardRecords[0].deviceSlot != 0) return {};      // isStart of the sweep is tied to tape slot 1
+  for (int i = 1; i < frames; i++) if (forwardRecords[i].deviceSlot != forwardRecords[i - 1].deviceSlot + 1) return {};
+  const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
+  const auto tStart = std::chrono::steady_clock::now();
+  pushParams();
+  const int slot0 = forwardRecords[0].deviceSlot, last = forwardRecords.back().deviceSlot, nsteps = frames - 1;
+  VecXd SX((size_t) nsteps * n3), SV((size_t) nsteps * n3);
+  for (int i = 0; i < nsteps; i++) {
+    if (seeds[i].first.size() != n3 || seeds[i].second.size() != n3) return {};
+    std::copy(seeds[i].first.begin(), seeds[i].first.end(), SX.begin() + (size_t) i * n3);
+    std::copy(seeds[i].second.begin(), seeds[i].second.end(), SV.begin() + (size_t) i * n3);
+  }
+  check(ctx, dc_set_seed_schedule(ctx, slot0, nsteps, SX.data(), SV.data()), "dc_set_seed_schedule");
+  check(ctx, dc_set_gradient(ctx, seeds[frames - 1].first.data(), seeds[frames - 1].second.data()), "dc_set_gradient");
+  check(ctx, dc_rollout_backward(ctx, last, nsteps), "dc_rollout_backward");
+  VecXd dx(n3), dv(n3), dmuTotal(std::max<size_t>(primitives.size(), 1), 0.0);
+  check(ctx, dc_get_gradient(ctx, dx.data(), dv.data(), dmuTotal.data()), "dc_get_gradient");
+  VecXd DXF((size_t) nsteps * 3 * std::max<size_t>(Af, 1), 0.0);
+  if (Af > 0) check(ctx, dc_get_dxfixed(ctx, slot0 + 1, nsteps, DXF.data()), "dc_get_dxfixed");
+  const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tStart).count();
+  BackwardInformation derivative;
+  derivative.dL_dx = seeds[frames - 1].first; derivative.dL_dv = seeds[frames - 1].second; derivative.loss = loss;
+  std::vector<BackwardInformation> all = {derivative};
+  for (int idx = frames - 1; idx >= 1; idx--) {
+    const ForwardInformation &fwd = forwardRecords[idx];
+    DeviceBackwardStep d;
+    d.dxf.assign(3 * std::max<size_t>(Af, 1), 0.0);
+    for (size_t q = 0; q < 3 * Af; q++) d.dxf[q] = DXF[(size_t) (idx - 1) * 3 * Af + q];
+    d.dmu.assign(dmuTotal.size(), 0.0);
+    if (idx == 1) d.dmu = dmuTotal;               // the device accumulates dL_dmu over the sweep: the total enters at the last step
+    dc_bwd_stats st;
+    check(ctx, dc_get_stats(ctx, fwd.deviceSlot, nullptr, &st), "dc_get_stats");
+    d.converged = st.converged; d.iters = st.adjoint_iters;
+    check(ctx, dc_get_param_gradients(ctx, fwd.deviceSlot, d.par), "dc_get_param_gradients");
+    BackwardInformation next = accumulateBackward(taskInfo, derivative, fwd, d);
+    next.totalRuntime = derivative.totalRuntime + us / nsteps;
+    if (idx == 1) { next.dL_dx = dx; next.dL_dv = dv; }
+    derivative = next;
+    all.push_back(std::move(next));
+  }
+  return all;
 }
 
 }  // namespace dchost

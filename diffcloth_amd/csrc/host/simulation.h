@@ -230,6 +230,18 @@ class Simulation {
   void rebuildSystem();          // stiffness / density changed: new constraint weights, masses and system matrix on the device
   std::vector<std::pair<VecXd, VecXd>> groundTruthForwardRecords;
   void step();
+  // Device-resident evaluation (include/diffcloth_hip.h "device-resident schedules"): the per-step inputs of `nsteps` steps (wind
+  // factors, fixed-point targets) are uploaded once and the steps run in ONE launch; the records get x, v, fixed points and solver
+  // statistics (f, r and the contact lists stay on the device: loadRecordDetails). Returns false without doing anything when the
+  // scene needs a per-step host decision (PER_STEP trajectory, fall-off wind together with a force field) or
+  // `deviceResidentRollouts` is off — the caller then loops over step().
+  bool rolloutOnDevice(int nsteps);
+  void loadRecordDetails(int recordIdx);          // f, r, primitive and self contacts of forwardRecords[recordIdx] from the device
+  // backward sweep over all records in ONE launch with the per-frame loss gradients as a device schedule; `seeds[i]` = (dL_dx, dL_dv)
+  // of the loss w.r.t. the state of record i. Returns the BackwardInformation per record like the stepBackward loop of
+  // runBackwardTask (entry 0 complete; dL_dx / dL_dv of the intermediate entries are not downloaded). Empty = not applicable.
+  std::vector<BackwardInformation> sweepBackwardOnDevice(BackwardTaskInformation &taskInfo, const std::vector<std::pair<VecXd, VecXd>> &seeds, double loss);
+  bool deviceResidentRollouts = true;             // environment DIFFCLOTH_DEVICE_ROLLOUTS=0 switches the fast path off
   void stepNN(int idx, const VecXd &x, const VecXd &v, const VecXd &fixedPointPos);
   BackwardInformation stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,
                                    const ForwardInformation &forwardInfo_new, bool isStart, const VecXd &dL_dxinit,
@@ -276,6 +288,11 @@ class Simulation {
   void configureDevice();
   void pushParams();
   VecXd fixedPointTargets(double t);
+  struct DeviceBackwardStep { VecXd dxf, dmu, fvec; double par[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int converged = 0, iters = 0; };
+  // host side of stepBackward (Simulation.cpp:1608-1764): accumulate this step's device outputs onto the carried gradient record
+  BackwardInformation accumulateBackward(BackwardTaskInformation &taskInfo, const BackwardInformation &gradient_new, const ForwardInformation &fwd,
+                                         const DeviceBackwardStep &d);
+  bool needsForceVector(const BackwardTaskInformation &taskInfo) const;
   double windFactorAt(double t, int stepIdx) const;
   bool windHasFallOff() const { return sceneConfig.windConfig == WIND_SIN_AND_FALLOFF || sceneConfig.windConfig == WIND_FACTOR_PER_STEP; }
 

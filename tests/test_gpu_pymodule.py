@@ -270,3 +270,39 @@ def test_remaining_demo_helpers_run_a_short_rollout_with_gradients(demo, mesh, s
           f"(step {eps:.3g}, predicted loss change / fp32 noise = {abs(g[k]) * 2 * eps / noise:.1f}{'' if resolved else ': below the resolution of a finite difference, ratio not asserted'})")
     if resolved:
         assert g[k] * fd > 0 and 0.5 <= g[k] / fd <= 2.0
+
+
+@pytest.mark.parametrize("demo,mesh,steps", [("wind_tshirt", "tshirt", 12), ("wear_hat", "hat", 15), ("dress_twirl", "dress", 5)])
+def test_device_resident_evaluation_equals_the_per_step_loops(demo, mesh, steps):
+    """runBackwardTask as two launches (Simulation::rolloutOnDevice / sweepBackwardOnDevice: wind factors, spline / twirl targets and
+    the per-frame loss gradients uploaded as device schedules) against its step() / stepBackward() loops (Simulation.cpp:3853-3961):
+    same kernels and same fp32 inputs, so the states agree bit for bit and the gradients to the last digits."""
+    d = pytest.importorskip("diffcloth_py")
+    V, F = scenes.load_mesh(mesh)
+    sim = d.makeSimFromMesh(demo, V.reshape(-1), F.reshape(-1).tolist())
+    h = d.makeOptimizeHelperWithSim(demo, sim)
+    h.forward_steps = steps
+    if demo == "wind_tshirt":
+        x = np.array(h.getActualParam()); x[0] *= 1.3; x[5] *= 0.8       # off the ground truth, inside the bounds
+    else:
+        x = h.getRandomParam(3)
+    out = {}
+    for fast in (True, False):
+        sim.deviceResidentRollouts = fast
+        recs = h.runSimulationAndGetLossGradient(x)
+        last = sim.getStateInfo()
+        sim.loadRecordDetails(steps)
+        det = sim.getStateInfo()
+        out[fast] = dict(loss=recs[0].loss, g=np.array(h.gradientInfoToVecXd(recs[0])), iters=recs[0].backwardTotalIters, conv=recs[0].convergedAccum,
+                         x=np.array(last.x), v=np.array(last.v), pd=last.cumulateIter, nrec=len(recs), f=np.array(det.f), r=np.array(det.r),
+                         dx0=np.array(recs[0].dL_dx))
+    a, b = out[True], out[False]
+    err = np.abs(a["g"] - b["g"]).max() / max(np.abs(b["g"]).max(), 1e-30)
+    print(f"\n[{demo}] fused vs per-step: loss {a['loss']:.6e} / {b['loss']:.6e}, gradient max rel diff {err:.1e}, adjoint iterations {a['iters']} / {b['iters']}, "
+          f"PD iterations {a['pd']} / {b['pd']}")
+    assert a["nrec"] == b["nrec"] == steps + 1
+    np.testing.assert_array_equal(a["x"], b["x"]); np.testing.assert_array_equal(a["v"], b["v"])
+    np.testing.assert_array_equal(a["f"], b["f"]); np.testing.assert_array_equal(a["r"], b["r"])
+    assert a["loss"] == b["loss"] and a["pd"] == b["pd"] and a["iters"] == b["iters"] and a["conv"] == b["conv"]
+    assert err <= 1e-6
+    np.testing.assert_allclose(a["dx0"], b["dx0"], rtol=1e-6, atol=1e-12 * max(np.abs(b["dx0"]).max(), 1e-30))
