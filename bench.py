@@ -129,7 +129,7 @@ def tshirt_evaluation0():
         t0 = time.perf_counter(); loss = h.runSimulationAndGetLoss(x); t_f = time.perf_counter() - t0
         t0 = time.perf_counter(); recs = h.runSimulationAndGetLossGradient(x); t_fb = time.perf_counter() - t0
         return {"workload": "wind_tshirt evaluation 0 of output/tshirt-exampleopt: 1 rollout, 250 steps fwd + 250 bwd, N=1426, self-collision on, "
-                            "through diffcloth_py.OptimizeHelper (one C-ABI call per step)",
+                            "through diffcloth_py.OptimizeHelper (device-resident evaluation: wind factors and per-frame loss gradients as schedules, one launch per direction)",
                 "forward_s": t_f, "forward_plus_backward_s": t_fb, "backward_s": max(t_fb - t_f, 0.0), "steps_per_s_fwd_bwd": 250.0 / t_fb,
                 "loss": float(loss), "loss_logged_by_reference": float(g["losses"][0]), "pd_iterations": int(sim.getStateInfo().cumulateIter),
                 "adjoint_iterations": int(recs[0].backwardTotalIters),
