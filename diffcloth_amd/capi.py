@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
-    "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed",
+    "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout",
 ]
 
 _lib = None
@@ -332,6 +332,12 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))
+
+    def layout(self):
+        """which kernel set dc_build chose (dc_get_layout)"""
+        c = _i32(np.zeros(6))
+        self._chk(self.lib.dc_get_layout(self.h, _i(c)))
+        return dict(renumbered=bool(c[0]), bandwidth=int(c[1]), packet_kernel=bool(c[2]), element_windows=bool(c[3]), windows=int(c[4]), dense_inverse=bool(c[5]))
 
     def cluster(self):
         """workgroups per rollout the engine chose for this batch (dc_get_cluster); 1 = one workgroup per rollout"""

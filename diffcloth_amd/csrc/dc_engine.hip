@@ -535,7 +535,14 @@ int dc_build(dc_ctx *c) {
   c->bandwidth = 0;
   for (int r = 0; r < H.N; r++)
     for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++) c->bandwidth = std::max(c->bandwidth, std::abs(H.P_col[k] - r));
-  if (c->host_only) { c->built = true; return DC_OK; }
+  if (c->host_only) {       // which kernel set this system would get (dc_get_layout): the same host-side table builders, nothing uploaded
+    HostWindows HW; HostPackets HP;
+    c->S.win_ok = HW.build(H, (size_t) 150 * 1024) ? 1 : 0;
+    c->S.pk_ok = HP.build(H) ? 1 : 0;
+    c->S.nwin = HW.nwin; c->S.pk_vpt = HP.vpt;
+    c->built = true;
+    return DC_OK;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   free_cluster(c);
@@ -1281,6 +1288,14 @@ int dc_sync(dc_ctx *c) {
   if (c->host_only) return DC_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return cluster_check(c);
+}
+
+int dc_get_layout(const dc_ctx *c, int *out6) {
+  if (!c || !out6) return DC_ERR_INVALID;
+  if (!c->built) return DC_ERR_STATE;
+  out6[0] = c->user_of.empty() ? 0 : 1; out6[1] = c->bandwidth; out6[2] = c->S.pk_ok; out6[3] = c->S.win_ok; out6[4] = c->S.nwin;
+  out6[5] = c->S.dense_inv ? 1 : 0;
+  return DC_OK;
 }
 
 int dc_get_cluster(const dc_ctx *c, int *workgroups_per_rollout, int *rollouts_per_launch) {

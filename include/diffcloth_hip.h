@@ -239,6 +239,11 @@ int dc_sync(dc_ctx *ctx);
  * and the device (environment DC_CLUSTER=k forces k; 0 or 1 = one workgroup per rollout). Results agree with the one-workgroup
  * kernels to solver tolerance (different summation order), not bitwise. Reports K and how many rollouts one launch covers. */
 int dc_get_cluster(const dc_ctx *ctx, int *workgroups_per_rollout, int *rollouts_per_launch);
+/* Which kernel set dc_build chose for this system (works on a host-only context too): out6 = {vertices renumbered on the device
+ * (0 / 1), bandwidth of the system matrix in device numbering, packet-matrix forward kernel usable (needs bandwidth <= 511),
+ * LDS element windows usable, number of element windows, explicit-inverse solve (small meshes)}. A mesh that fails the packet /
+ * window conditions runs on the global-memory fallback kernels — correct, but several times slower. */
+int dc_get_layout(const dc_ctx *ctx, int *out6);
 /* HIP-event timing of everything enqueued between the two calls on the context's stream (ms). */
 int dc_timer_start(dc_ctx *ctx);
 int dc_timer_stop(dc_ctx *ctx, float *ms);

@@ -51,6 +51,7 @@ def main():
         "tshirt": "src/assets/meshes/remeshed/T-shirt/tshirt1000-tri.obj",
         "sock": "src/assets/meshes/remeshed/sock1055-2081.obj",
         "dress": "src/assets/meshes/remeshed/dress-handsup-drape.obj",
+        "dress7k": "src/assets/meshes/remeshed/dress-v7k-f14k.obj",      # 7 742 vertices: the garment-sized self-contact workload of tools/bench_dress7k.py
     }
     out = {}
     for name, rel in meshes.items():

@@ -180,10 +180,12 @@ def test_c5_sock_batch_512():
     assert st["prim_contacts"].min() > 0
 
 
-def test_c4_dress_self_contact_batch():
-    """dress mesh (3634 vertices) hanging from its top rim and folded so that sheets touch: self-collision detection,
-    layering, layered friction and its adjoint on a real garment (the batch of 256 is the bench's job; 8 here)."""
-    V, F = scenes.load_mesh("dress")
+@pytest.mark.parametrize("mesh,B,sample", [("dress", 8, (0, 7)), ("dress7k", 4, (3,))])
+def test_c4_dress_self_contact_batch(mesh, B, sample):
+    """dress mesh (3634 vertices: the dress_twirl demo's; 7742 vertices: dress-v7k-f14k.obj, the garment-sized workload of
+    tools/bench_dress7k.py) hanging from its top rim and folded so that sheets touch: self-collision detection, layering, layered
+    friction and its adjoint on a real garment (the batch of 256 is the bench's job; a few rollouts here)."""
+    V, F = scenes.load_mesh(mesh)
     cfg = dict(h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
     P, rmin, rmax = scenes.normalise_model(V, "FRONT", 8.0)
     P = f32(P)
@@ -199,9 +201,8 @@ def test_c4_dress_self_contact_batch():
     X[:, 2] *= 0.9
     vel = np.zeros_like(X)
     vel[:, 2] = -0.1 * np.sign(P[:, 2])
-    B = 8
     X0 = np.stack([f32((X + 0.0005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
     V0 = np.stack([f32((vel + 0.005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
     XF = np.stack([f32(X[top].reshape(-1)) for _ in range(B)])
-    st = check_rollouts(o, e, X0, V0, XF, sample=(0, 7), pos_tol=8e-5, grad_tol=2e-4)
+    st = check_rollouts(o, e, X0, V0, XF, sample=sample, pos_tol=8e-5, grad_tol=2e-4)
     assert st["self_contacts"].min() > 20

@@ -145,3 +145,39 @@ def test_mesh_beyond_the_packet_kernel_limit():
     assert np.all(np.isin(st["converged"], (1, 2))) and np.all(np.isin(gb["converged"], (1, 2)))
     assert st["prim_contacts"].min() > 0
     check_against_oracle(o, e, W, (1,), MU, gx, gv, st, gb, pos_tol=5e-5, grad_tol=1e-4)
+
+
+@pytest.mark.parametrize("nx,vpt", [(22, 1), (32, 2), (39, 3), (45, 4), (55, 6), (64, 8), (71, 10), (78, 12), (90, 16)])
+def test_every_rows_per_thread_instance_of_the_packet_kernel(nx, vpt, monkeypatch):
+    """k_pd_step_pk<512, VPT, XL> is instantiated for 1 ... 20 rows per thread (N <= 512 VPT); small batches of large meshes are
+    split over several workgroups by default, so the one-workgroup instances between the demo meshes' sizes and N = 10 000 are
+    pinned here (DC_CLUSTER=1): one step forward + backward of a draped, contacting cloth against the fp64 oracle."""
+    monkeypatch.setenv("DC_CLUSTER", "1")
+    monkeypatch.setenv("DC_DENSE_MAX_N", "0")            # the packet solve itself, not the explicit inverse of the smallest meshes
+    V, F, e, o = scene(nx, False, 1e-8)
+    prev = {1: 0, 2: 1, 3: 2, 4: 3, 6: 4, 8: 6, 10: 8, 12: 10, 16: 12}[vpt]
+    assert 512 * prev < e.N <= 512 * vpt
+    lay = e.layout()
+    assert lay["packet_kernel"] and lay["element_windows"]
+    X, MU = start_states(V, 2, [])
+    X[:, 1::3] -= 0.12                                    # lower the sheet onto the sphere: contacts in the very first step
+    X = f32(X)
+    e.alloc_batch(2, 1)
+    assert e.cluster() == 1
+    e.set_mu(MU)
+    e.set_state(0, X, np.zeros_like(X))
+    st = e.step_forward(0)
+    x1, v1 = e.get_state(1)
+    rng = np.random.default_rng(nx)
+    gx = f32(rng.standard_normal(X.shape)); gv = f32(0.01 * rng.standard_normal(X.shape))
+    gb = e.step_backward(1, gx, gv, is_start=True)
+    o.set_mu(0, float(MU[1, 0]))
+    ref = o.step(X[1], np.zeros_like(X[1]))
+    rb = o.step_backward(ref["id"], gx[1], gv[1], is_start=True, direct=True)
+    dx = np.abs(x1[1] - ref["x"]).max()
+    print(f"\n[pk VPT={vpt}] N={e.N}: contacts {st['prim_contacts'][1]} / {ref['nprim']}, PD iterations {st['pd_iters'][1]} / {ref['iters']}, PCG per PD iteration "
+          f"{st['cg_iters'][1] / max(st['pd_iters'][1], 1):.1f}, max|dx| {dx:.2e}, gradient rel err dx {rel(gb['dL_dx'][1], rb['dL_dx']):.2e} dv {rel(gb['dL_dv'][1], rb['dL_dv']):.2e}")
+    assert st["converged"][1] == 1 and ref["converged"] and st["prim_contacts"][1] == ref["nprim"] and ref["nprim"] > 0
+    assert abs(int(st["pd_iters"][1]) - ref["iters"]) <= 1
+    assert dx <= 4.5e-5
+    assert rel(gb["dL_dx"][1], rb["dL_dx"]) <= 1e-4 and rel(gb["dL_dv"][1], rb["dL_dv"]) <= 1e-4
