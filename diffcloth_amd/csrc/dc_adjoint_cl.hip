@@ -321,6 +321,9 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     __syncthreads();
     }   // cycle
   }
+  // "stalled at the fp32 floor" (2) is only claimed near the tolerance: a breakdown or stall with the residual still more than 100 x
+  // above it (an adjoint system beyond an fp32 Krylov solve, e.g. a strongly compressed fine garment) is reported as NOT converged
+  if (status == 2 && rr > 1e4 * (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm) status = 0;
   udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual (of the last recomputed or recurrence residual)
   __syncthreads();
   // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650) ----

@@ -85,7 +85,18 @@ __device__ __forceinline__ void store_block_inverse(const Sym3 &B, float m, JT j
   const float det = dot(cx, r0);
   float inv = 1.0f / det;
   f3 q0 = r0 * inv, q1 = r1 * inv, q2 = r2 * inv;
-  if (!(fabsf(det) > 1e-30f) || !isfinite(inv)) { const float d = 1.0f / m; q0 = mk(d, 0, 0); q1 = mk(0, d, 0); q2 = mk(0, 0, d); }
+  // K_ii = m I + (elastic block) has no eigenvalue below m while the elastic block is positive semi-definite; under compression
+  // I - dp/dx has negative directions and the block can come close to singular or turn indefinite — its inverse would then blow a
+  // residual component up instead of damping it (BiCGSTAB breaks down, seen on a squashed 7 742-vertex garment). A block whose inverse
+  // has an entry above 2 / m (an eigenvalue below m / 2), a non-positive determinant or a non-finite inverse is replaced by the scalar
+  // 1 / (m + tr(B) / 3), the diag(P)-like value of that vertex.
+  const float lim = 2.0f / m;
+  const float big = fmaxf(fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q1.x))),
+                          fmaxf(fmaxf(fabsf(q1.y), fabsf(q1.z)), fmaxf(fmaxf(fabsf(q2.x), fabsf(q2.y)), fabsf(q2.z))));
+  if (!(det > 1e-30f) || !isfinite(inv) || !(big <= lim)) {
+    const float d = 1.0f / (m + fmaxf(0.f, (B.xx + B.yy + B.zz) * (1.0f / 3.0f)));
+    q0 = mk(d, 0, 0); q1 = mk(0, d, 0); q2 = mk(0, 0, d);
+  }
   minv[i] = q0.x; minv[N + i] = q0.y; minv[2 * N + i] = q0.z;
   minv[3 * N + i] = q1.x; minv[4 * N + i] = q1.y; minv[5 * N + i] = q1.z;
   minv[6 * N + i] = q2.x; minv[7 * N + i] = q2.y; minv[8 * N + i] = q2.z;
