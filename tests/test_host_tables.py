@@ -85,3 +85,27 @@ def test_bad_inputs_are_rejected():
         e.set_mesh(V, F2)
     with pytest.raises(capi.DcError):
         e.build()                                            # no valid mesh
+
+
+@pytest.mark.parametrize("mesh,orient,dim,max_bw", [("tshirt", "BACK", 6.0, 511), ("hat", "FRONT", 6.0, 511), ("sock", "FRONT", 5.0, 511),
+                                                    ("dress", "FRONT", 8.0, 511), ("dress7k", "FRONT", 8.0, 511)])
+def test_shipped_garments_get_the_resident_kernel_set(mesh, orient, dim, max_bw):
+    """dc_get_layout on a host-only context (no GPU): every garment mesh of the reference is renumbered to a system-matrix bandwidth
+    the 10-bit packet deltas can hold, and gets the packet matrix and the LDS element windows — not the global-memory fallbacks."""
+    import scenes
+    V, F = scenes.load_mesh(mesh)
+    P, _, _ = scenes.normalise_model(V, orient, dim)
+    e = capi.Engine(-1)
+    e.set_mesh(P, F); e.set_attachments([0])
+    e.set_params(time_step=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
+    e.set_primitives([]); e.build()
+    lay = e.layout()
+    assert lay["renumbered"] and 0 < lay["bandwidth"] <= max_bw, lay
+    assert lay["packet_kernel"] and lay["element_windows"] and lay["windows"] >= 1, lay
+    V2, F2 = meshes.grid_cloth(100, 100, 4.5, 4.5, "DOWN")
+    g = capi.Engine(-1)
+    g.set_mesh(V2, F2); g.set_attachments([]); g.set_params(time_step=1.0 / 180, density=0.3, k_stretch=150.0, k_bend=1e-5)
+    g.set_primitives([]); g.build()
+    lg = g.layout()
+    assert not lg["renumbered"] and lg["packet_kernel"] and lg["element_windows"] and lg["windows"] == 10, lg
+
