@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
-    "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout",
+    "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout", "dc_comm_unique_id", "dc_comm_init", "dc_allreduce_sum", "dc_comm_destroy",
 ]
 
 _lib = None
@@ -332,6 +332,27 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))
+
+    # ---- RCCL collective of the C-ABI (C++ callers; Python callers normally use torch.distributed) ----
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.dc_comm_unique_id(buf)
+        if rc != 0:
+            raise DcError(f"code {rc}: dc_comm_unique_id failed (RCCL not available?)")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        self._chk(self.lib.dc_comm_init(self.h, C.c_int(nranks), C.c_int(rank), C.c_char_p(unique_id)))
+
+    def allreduce_sum(self, values):
+        a = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1)).copy()
+        self._chk(self.lib.dc_allreduce_sum(self.h, _d(a), C.c_int(a.size)))
+        return a
+
+    def comm_destroy(self):
+        self._chk(self.lib.dc_comm_destroy(self.h))
 
     def layout(self):
         """which kernel set dc_build chose (dc_get_layout)"""

@@ -1,6 +1,8 @@
 // C-ABI layer of libdiffcloth_hip.so: context, device memory, tape, and the calls that enqueue the
 // persistent step kernels. See include/diffcloth_hip.h for the contract of every entry point.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library is bound with dlopen in dc_comm_* (no link-time dependency)
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -73,6 +75,8 @@ struct dc_ctx {
   float *FVS_S = nullptr;           // [(tape+1)][B] factor on fv of that step
   float *SEEDX = nullptr, *SEEDV = nullptr;   // [(tape+1)][B][3][N] loss gradient w.r.t. the state at the slot (allocated on first use)
   std::vector<char> sched_xf, sched_fu, sched_fvs, sched_seed;
+  void *comm = nullptr;             // RCCL communicator of dc_comm_init (ncclComm_t), one rank per context
+  int comm_ranks = 0;
   std::vector<void *> sched_pool;
   dc_step_stats *fstats = nullptr;  // [(tape+1)][B]
   dc_bwd_stats *bstats = nullptr;   // [(tape+1)][B], indexed by the slot whose record was differentiated
@@ -449,6 +453,7 @@ int dc_destroy(dc_ctx *c) {
   if (c->host_only) { delete c; return DC_OK; }
   (void) hipSetDevice(c->device);
   (void) hipStreamSynchronize(c->stream);
+  (void) dc_comm_destroy(c);
   free_cluster(c);
   free_pool(c->table_allocs);
   free_pool(c->batch_allocs);
@@ -1295,6 +1300,96 @@ int dc_get_layout(const dc_ctx *c, int *out6) {
   if (!c->built) return DC_ERR_STATE;
   out6[0] = c->user_of.empty() ? 0 : 1; out6[1] = c->bandwidth; out6[2] = c->S.pk_ok; out6[3] = c->S.win_ok; out6[4] = c->S.nwin;
   out6[5] = c->S.dense_inv ? 1 : 0;
+  return DC_OK;
+}
+
+// ---- collective for C++ callers (the L-BFGS side sums loss + parameter gradients over the ranks) ------------------
+// RCCL is bound at run time (dlopen) the first time one of these entry points is used: the library has no link-time dependency on it,
+// and a process that already carries an RCCL (torch.distributed) gets that same copy by its soname.
+extern "C++" {
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+RcclApi &rccl() {
+  static RcclApi api;
+  if (api.lib || !api.error.empty()) return api;
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) { api.error = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return api; }
+  api.GetUniqueId = (decltype(api.GetUniqueId)) dlsym(api.lib, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank)) dlsym(api.lib, "ncclCommInitRank");
+  api.AllReduce = (decltype(api.AllReduce)) dlsym(api.lib, "ncclAllReduce");
+  api.CommDestroy = (decltype(api.CommDestroy)) dlsym(api.lib, "ncclCommDestroy");
+  api.GetErrorString = (decltype(api.GetErrorString)) dlsym(api.lib, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { api.error = "RCCL library lacks the expected entry points"; api.lib = nullptr; }
+  return api;
+}
+int rccl_fail(dc_ctx *c, const char *what, ncclResult_t r) {
+  RcclApi &R = rccl();
+  return fail(c, DC_ERR_HIP, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error") + " (" + std::to_string((int) r) + ")");
+}
+}  // namespace
+}  // extern "C++"
+
+int dc_comm_unique_id(char *id128) {
+  if (!id128) return DC_ERR_INVALID;
+  RcclApi &R = rccl();
+  if (!R.lib) return DC_ERR_HIP;
+  ncclUniqueId id;
+  if (R.GetUniqueId(&id) != ncclSuccess) return DC_ERR_HIP;
+  std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return DC_OK;
+}
+
+int dc_comm_init(dc_ctx *c, int nranks, int rank, const char *id128) {
+  if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, DC_ERR_INVALID, "dc_comm_init: bad arguments");
+  if (c->host_only) return fail(c, DC_ERR_STATE, "dc_comm_init: host-only context");
+  RcclApi &R = rccl();
+  if (!R.lib) return fail(c, DC_ERR_HIP, R.error);
+  if (c->comm) { int rc = dc_comm_destroy(c); if (rc) return rc; }
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  ncclResult_t r = R.CommInitRank(&comm, nranks, id, rank);
+  if (r != ncclSuccess) return rccl_fail(c, "ncclCommInitRank", r);
+  c->comm = (void *) comm; c->comm_ranks = nranks;
+  return DC_OK;
+}
+
+int dc_allreduce_sum(dc_ctx *c, double *inout, int count) {
+  if (!c || !inout || count < 1) return fail(c, DC_ERR_INVALID, "dc_allreduce_sum: bad arguments");
+  if (!c->comm) return fail(c, DC_ERR_STATE, "dc_allreduce_sum: dc_comm_init has not been called");
+  RcclApi &R = rccl();
+  HIPCHK(c, hipSetDevice(c->device));
+  double *buf = nullptr;
+  HIPCHK(c, hipMalloc((void **) &buf, sizeof(double) * (size_t) count));
+  hipError_t e = hipMemcpyAsync(buf, inout, sizeof(double) * (size_t) count, hipMemcpyHostToDevice, c->stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = R.AllReduce(buf, buf, (size_t) count, ncclFloat64, ncclSum, (ncclComm_t) c->comm, c->stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(inout, buf, sizeof(double) * (size_t) count, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void) hipFree(buf);
+  if (r != ncclSuccess) return rccl_fail(c, "ncclAllReduce", r);
+  HIPCHK(c, e);
+  return DC_OK;
+}
+
+int dc_comm_destroy(dc_ctx *c) {
+  if (!c) return DC_ERR_INVALID;
+  if (!c->comm) return DC_OK;
+  RcclApi &R = rccl();
+  if (R.lib) (void) R.CommDestroy((ncclComm_t) c->comm);
+  c->comm = nullptr; c->comm_ranks = 0;
   return DC_OK;
 }
 

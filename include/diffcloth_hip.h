@@ -244,6 +244,17 @@ int dc_get_cluster(const dc_ctx *ctx, int *workgroups_per_rollout, int *rollouts
  * LDS element windows usable, number of element windows, explicit-inverse solve (small meshes)}. A mesh that fails the packet /
  * window conditions runs on the global-memory fallback kernels — correct, but several times slower. */
 int dc_get_layout(const dc_ctx *ctx, int *out6);
+
+/* ---- collective for C++ callers: one context (= one GPU) per rank; the optimiser sums [loss, dL/dtheta] over the ranks once per
+ * evaluation, the only exchange of the rollout-sharded job. RCCL is bound at run time when these are first used.
+ * rank 0 obtains a 128-byte id (dc_comm_unique_id) and hands it to the other ranks by whatever the caller has (MPI_Bcast, a file, a
+ * socket); every rank then calls dc_comm_init with the same id. dc_allreduce_sum: in-place sum of `count` doubles over the ranks
+ * through the context's stream (host buffer in, host buffer out; blocks). Python callers use torch.distributed instead
+ * (diffcloth_amd/distributed.py). */
+int dc_comm_unique_id(char *id128 /*128 bytes out*/);
+int dc_comm_init(dc_ctx *ctx, int nranks, int rank, const char *id128);
+int dc_allreduce_sum(dc_ctx *ctx, double *inout, int count);
+int dc_comm_destroy(dc_ctx *ctx);
 /* HIP-event timing of everything enqueued between the two calls on the context's stream (ms). */
 int dc_timer_start(dc_ctx *ctx);
 int dc_timer_stop(dc_ctx *ctx, float *ms);
