@@ -378,10 +378,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, V, F, center, field, xw[0], vw[0], MU[0, 0], ncpu, gscale)
         if world == 1 and args.tshirt:
             out["secondary"] = tshirt_evaluation0()
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio at communicator set-up, which sits in
+    # the C buffer (stdout is a pipe) until someone flushes it — flush it out first, then print the line.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
