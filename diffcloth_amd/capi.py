@@ -31,7 +31,8 @@ class dc_params(C.Structure):
                 ("selfcollision_enabled", C.c_int), ("gradient_clipping", C.c_int),
                 ("gradient_clipping_threshold", C.c_double), ("pd_iter_cap", C.c_int), ("adjoint_iter_cap", C.c_int),
                 ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int),
-                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double), ("adjoint_block_precond", C.c_int), ("max_self_contacts", C.c_int)]
+                ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double), ("adjoint_block_precond", C.c_int), ("adjoint_fp32_only", C.c_int),
+                ("max_self_contacts", C.c_int)]
 
 
 class dc_step_stats(C.Structure):
@@ -41,7 +42,7 @@ class dc_step_stats(C.Structure):
 
 class dc_bwd_stats(C.Structure):
     _fields_ = [("converged", C.c_int), ("adjoint_iters", C.c_int), ("cg_iters", C.c_int), ("clipped", C.c_int), ("used_direct", C.c_int),
-                ("last_udiff", C.c_float)]
+                ("last_udiff", C.c_float), ("refine_cycles", C.c_int), ("fp64_iters", C.c_int)]
 
 
 EXPORTED_SYMBOLS = [
@@ -63,9 +64,10 @@ def load_library():
     """Loads libdiffcloth_hip.so; raises if it has not been built (see diffcloth_amd/build.py)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise DcError(f"{LIB_PATH} not found: run `python -m diffcloth_amd.build` (hipcc, gfx950)")
-        lib = C.CDLL(LIB_PATH)
+        path = os.environ.get("DC_LIB", LIB_PATH)        # development switch: A/B runs of two builds of the library
+        if not os.path.exists(path):
+            raise DcError(f"{path} not found: run `python -m diffcloth_amd.build` (hipcc, gfx950)")
+        lib = C.CDLL(path)
         lib.dc_last_error.restype = C.c_char_p
         lib.dc_version.restype = C.c_char_p
         _lib = lib
@@ -258,7 +260,7 @@ class Engine:
         self._chk(self.lib.dc_step_backward(self.h, C.c_int(slot), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
                                             _d(dx), _d(dv), _d(dxf), _d(dmu), st))
         out = dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:, :3 * self.Af], dL_dmu=dmu)
-        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff"]))
+        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters"]))
         return out
 
     # ---- device-resident rollouts ----
@@ -328,7 +330,7 @@ class Engine:
         f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()
         self._chk(self.lib.dc_get_stats(self.h, C.c_int(slot), f, b))
         return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff", "self_overflow"]),
-                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff"]))
+                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters"]))
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))

@@ -20,10 +20,12 @@
 #include "dc_winlib.h"
 #include "dc_denselib.h"
 #include "dc_adjprecond.h"
+#include "dc_adjoint64.h"
 
 namespace dc {
 
-constexpr int kCycles = 1;      // BiCGSTAB cycles of the direct adjoint solve (see the comment at the loop)
+constexpr int kMaxRefine = 6;          // fp32 correction solves of the mixed-precision direct adjoint solve before the fp64 fall-back
+constexpr double kInnerFloor = 1e-3;   // an fp32 correction solve never aims below this fraction of its own right-hand side
 
 #ifdef DC_PROFILE_PHASES
 #define PH_DECL long long ph_t = clock64(); long long ph_acc[4] = {0, 0, 0, 0};
@@ -224,12 +226,132 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
 
 }  // namespace
 
+// vectors of the fp32 correction solve (planar [3][N] of one rollout)
+struct Krylov32 {
+  float *rhs, *d, *r, *p, *v, *t, *rhat, *ph, *sh, *minv;
+};
+
+// One fp32 correction solve of the direct adjoint solve: right-preconditioned BiCGSTAB on K d = rhs from d = 0 until the recurrence
+// residual satisfies |r|^2 <= in_stop (in_status 1), a breakdown / stall (2) or the iteration cap (0). BLK: preconditioner = K's own
+// inverted 3 x 3 diagonal blocks (V.minv), else diag(P)^-1 inside the operator. A function of its own (not inlined) so that its
+// register allocation is that of this loop alone — inlined into the kernel next to the fp64 code, the loop reloaded 400 spilled
+// values per iteration.
+struct Ret32 {
+  int status, kdone, iters;
+  double rr;
+};
+template <int THREADS, bool WIN, bool BLK>
+__device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Krylov32 V, double in_stop, int kcap, int stall_window,
+                                                            double *red, int kdone, int iters) {
+  const int N = S.N, tid = threadIdx.x;
+  constexpr int VB = 4;
+  float *gin = V.rhs, *u = V.d, *r = V.r, *p = V.p, *v = V.v, *t = V.t, *rhat = V.rhat, *ph = V.ph, *sh = V.sh;
+  const float *minv = V.minv;
+  auto pre = [&](int i, f3 z) { return block_pre(minv, i, N, z); };
+  float d1, d2, part;
+  double rr;
+    // r = rhat = p = rhs, d = 0 (K d = 0 without applying the operator)
+    part = 0.f;
+    for (int i = tid; i < N; i += THREADS) {
+      f3 q = ld3(gin, i, N);
+      st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q); st3(u, i, N, mk(0, 0, 0));
+      if constexpr (BLK) st3(ph, i, N, pre(i, q));
+      part += dot(q, q);
+    }
+    double rho = block_sum<THREADS>((double) part, red);   // rhat.r = r.r
+    rr = rho;
+    double best_rr = rr;
+    int since_progress = 0;
+    int in_status = (rr <= in_stop) ? 1 : 0;
+    for (int k = kdone; k < kcap && in_status == 0; k++, kdone++) {
+      // v = K M^-1 p ;  alpha = rho / (rhat . v)
+      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, ph, false, v, rhat, d1, d2);
+      else adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
+      double rv = block_sum<THREADS>((double) d1, red);
+      if (!(fabs(rv) > 1e-300)) { in_status = 2; break; }
+      const float alpha = (float) (rho / rv);
+      // s = r - alpha v  (in place)
+      // (vector updates: VB vertices of a thread per round, all loads issued before the first store)
+      part = 0.f;
+      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+        f3 rq[VB], vq[VB];
+#pragma unroll
+        for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); vq[j] = ld3(v, ic, N); }
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int i = i0 + j * THREADS;
+          f3 s = rq[j] - vq[j] * alpha;
+          if (i < N) { st3(r, i, N, s); if constexpr (BLK) st3(sh, i, N, pre(i, s)); part += dot(s, s); }
+        }
+      }
+      double ss = block_sum<THREADS>((double) part, red);
+      iters++;
+      if (ss <= in_stop) {
+        for (int i = tid; i < N; i += THREADS) st3(u, i, N, ld3(u, i, N) + (BLK ? ld3(ph, i, N) * alpha : ld3(p, i, N) * (alpha * S.dinv[i])));
+        rr = ss; in_status = 1; break;
+      }
+      // t = K M^-1 s ;  omega = (t . s) / (t . t)
+      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, sh, false, t, r, d1, d2);
+      else adjoint_operator<THREADS, WIN>(S, C, r, true, t, r, d1, d2);
+      double ts = (double) d1, tt = (double) d2;
+      block_sum2<THREADS>(ts, tt, red);
+      if (!(tt > 1e-300)) { in_status = 2; break; }
+      const float omega = (float) (ts / tt);
+      // d += alpha M^-1 p + omega M^-1 s ;  r = s - omega t ;  rho_new = rhat . r
+      float pa = 0.f, pb = 0.f;
+      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB], zq[VB];
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int ic = min(i0 + j * THREADS, N - 1);
+          sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
+          if constexpr (BLK) { zq[j] = ld3(sh, ic, N); pq[j] = ld3(ph, ic, N); }
+          else { const float di = S.dinv[ic]; zq[j] = sq[j] * di; pq[j] = ld3(p, ic, N) * di; }
+        }
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int i = i0 + j * THREADS;
+          f3 rn = sq[j] - tq[j] * omega;
+          if (i < N) {
+            st3(u, i, N, uq[j] + pq[j] * alpha + zq[j] * omega);
+            st3(r, i, N, rn);
+            pa += dot(rn, hq[j]);
+            pb += dot(rn, rn);
+          }
+        }
+      }
+      double rho_new = (double) pa;
+      rr = (double) pb;
+      block_sum2<THREADS>(rho_new, rr, red);
+      if (rr <= in_stop) { in_status = 1; break; }
+      if (rr < best_rr) { best_rr = rr; since_progress = 0; }
+      else if (++since_progress >= stall_window) { in_status = 2; break; }
+      if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { in_status = 2; break; }
+      const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));
+      rho = rho_new;
+      // p = r + beta (p - omega v)
+      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+        f3 rq[VB], pq[VB], vq[VB];
+#pragma unroll
+        for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); pq[j] = ld3(p, ic, N); vq[j] = ld3(v, ic, N); }
+#pragma unroll
+        for (int j = 0; j < VB; j++) {
+          const int i = i0 + j * THREADS;
+          if (i < N) { const f3 pn = rq[j] + (pq[j] - vq[j] * omega) * beta; st3(p, i, N, pn); if constexpr (BLK) st3(ph, i, N, pre(i, pn)); }
+        }
+      }
+      __syncthreads();
+    }
+  __syncthreads();
+  return Ret32{in_status, kdone, iters, rr};
+}
+
 // BLK: direct solve preconditioned with K's own 3 x 3 diagonal blocks (dc_adjprecond.h) instead of diag(P)^-1
 template <int THREADS, bool WIN, bool DENSE, bool BLK>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
   const DevSystem &S = *Sp;
-  extern __shared__ float dyn_lds[];      // element windows (S.win_lds_bytes)
-  __shared__ double red[2 * (THREADS / 64)];
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];      // element windows (S.win_lds_bytes)
+  __shared__ double red[3 * (THREADS / 64)];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = S.N;
   const size_t off = (size_t) b * 3 * N;
@@ -257,11 +379,9 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   C.y = W.vbest + off; C.corner = W.corner + (size_t) b * 3 * S.NC;
   C.self = A.self; C.b = b;
   C.nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;
-  float *gx = A.gx + off, *gv = A.gv + off;
+  float *gx = A.gx + off;
   float *gin = W.g + off, *u = W.vnow + off;
   float *cg_r = W.cg_r + off, *cg_p = W.cg_p + off, *cg_ap = W.cg_ap + off, *cg_x = W.cg_x + off;
-  const float h = S.h, h2 = S.h * S.h;
-
   // ---- gradient clipping (Simulation.cpp:1460-1466) and u = 0 ----
   float part = 0.f;
   for (int i = tid; i < N; i += THREADS) { f3 q = ld3(gx, i, N); part += dot(q, q); }
@@ -336,233 +456,111 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     __syncthreads();
   }
 
+  // fp64 side (dc_adjoint64.h): true residual of the mixed-precision refinement, fall-back solve, gradient assembly
+  TeamOne<THREADS> tm{N, red};
+  Adj64 C64;
+  C64.xnew = C.xnew; C64.rec_f = C.rec_f; C64.rec_n = C.rec_n; C64.mu = C.mu; C64.rec_prim = C.rec_prim;
+  C64.self = C.self; C64.nself = C.nself; C64.b = b; C64.lds = dyn_lds; C64.lds_floats = C.lds_floats;
+  Work64 W64;
+  W64.u = W.u64 + off; W64.r = W.r64 + off; W64.y = W.y64 + off;
+  W64.rhat = W.k64[0] + off; W64.p = W.k64[1] + off; W64.v = W.k64[2] + off; W64.t = W.k64[3] + off; W64.ph = W.k64[4] + off; W64.sh = W.k64[5] + off;
+  int cycles = 0, iters64 = 0;
+  // u64 = the result of the reference iteration (mode 0), or 0
+  for (int i = tid; i < N; i += THREADS) st3d(W64.u, i, N, (A.mode == 0) ? tod(ld3(u, i, N)) : mkd(0, 0, 0));
+  __syncthreads();
+
   if (need_direct && gnorm > 0) {
-    // ---- block-Jacobi preconditioned BiCGSTAB on K u = g, starting from the current u ----
+    // ---- direct solve of K u = g in mixed precision: block-Jacobi preconditioned BiCGSTAB in fp32 for corrections d of the
+    //      residual r = g - K u evaluated in fp64 (u += d), until |r| <= rel_tol |g| in fp64; fp64 BiCGSTAB when that stalls ----
     used_direct = 1;
-    constexpr int VB = 4;
     PH(0)
     float *r = cg_r, *p = cg_p, *v = cg_ap, *t = cg_x, *rhat = W.sd_sx + off;    // (detection scratch, idle in the backward pass)
     float *ph = W.pre_p + off, *sh = W.pre_s + off, *minv = W.minv + (size_t) b * 9 * N;   // M^-1 p, M^-1 s, the block inverses
-    if constexpr (BLK) {   // K's own 3 x 3 diagonal blocks at this step's x_new, inverted (dc_adjprecond.h)
+    auto build_blocks = [&]() {   // K's own 3 x 3 diagonal blocks at this step's x_new, inverted (dc_adjprecond.h)
       for (int i = tid; i < N; i += THREADS)
         store_block_inverse(elastic_diag_block(S, C.xnew, i), S.mass[i], [&](f3 e) { return contact_JT(S, C, i, e); }, minv, i, N);
-    }
-    auto pre = [&](int i, f3 z) { return block_pre(minv, i, N, z); };
-    float d1, d2;
+    };
+    if constexpr (BLK) build_blocks();
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
     const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
-    double rr = 0;
-    // kCycles > 1: when the recurrence residual says "converged", recompute g - K u and restart from u if that is not below the
-    // tolerance. Measured on the C4 workload (r02m): +4 iterations of 41, gradient error against the fp64 oracle unchanged to three
-    // digits (7.31e-5 -> 7.31e-5) — the fp32 floor of this solve is eps * cond(K) in the operator's coefficients, not residual
-    // drift — so one cycle is the default.
-    for (int cycle = 0, kdone = 0; cycle < kCycles; cycle++) {
-    // r = rhat = p = g - K u; the direct mode starts from u = 0: K u = 0 without applying the operator (one of ~75 applications)
-    const bool u_is_zero = (A.mode == 1 && cycle == 0);
-    if (!u_is_zero) {
-      adjoint_operator<THREADS, WIN>(S, C, u, false, v, nullptr, d1, d2);
-      __syncthreads();            // (as above; inside the loop the block reductions that follow every application do this)
-    }
-    part = 0.f;
-    for (int i = tid; i < N; i += THREADS) {
-      f3 q = ld3(gin, i, N);
-      if (!u_is_zero) q = q - ld3(v, i, N);
-      st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
-      if constexpr (BLK) st3(ph, i, N, pre(i, q));
-      part += dot(q, q);
-    }
-    double rho = block_sum<THREADS>((double) part, red);   // rhat.r = r.r
-    rr = rho;
-    double best_rr = rr;
-    int since_progress = 0;
-    status = (rr <= stop) ? 1 : 0;
-    if (status == 0 && cycle > 0 && cycle == kCycles - 1) status = 2;      // still above the tolerance after two restarts: the fp32 floor of this system
-    if (status != 0) break;
-    for (int k = kdone; k < kcap && status == 0; k++, kdone++) {
-      // v = K M^-1 p ;  alpha = rho / (rhat . v)
-      PH(2)
-      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, ph, false, v, rhat, d1, d2);
-      else adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
-      double rv = block_sum<THREADS>((double) d1, red);
-      PH(1)
-      if (!(fabs(rv) > 1e-300)) { status = 2; break; }
-      const float alpha = (float) (rho / rv);
-      // s = r - alpha v  (in place)
-      // (vector updates: VB vertices of a thread per round, all loads issued before the first store)
-      part = 0.f;
-      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
-        f3 rq[VB], vq[VB];
-#pragma unroll
-        for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); vq[j] = ld3(v, ic, N); }
-#pragma unroll
-        for (int j = 0; j < VB; j++) {
-          const int i = i0 + j * THREADS;
-          f3 s = rq[j] - vq[j] * alpha;
-          if (i < N) { st3(r, i, N, s); if constexpr (BLK) st3(sh, i, N, pre(i, s)); part += dot(s, s); }
-        }
-      }
-      double ss = block_sum<THREADS>((double) part, red);
-      iters++;
-      if (ss <= stop) {
-        for (int i = tid; i < N; i += THREADS) st3(u, i, N, ld3(u, i, N) + (BLK ? ld3(ph, i, N) * alpha : ld3(p, i, N) * (alpha * S.dinv[i])));
-        rr = ss; status = 1; break;
-      }
-      // t = K M^-1 s ;  omega = (t . s) / (t . t)
-      PH(2)
-      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, sh, false, t, r, d1, d2);
-      else adjoint_operator<THREADS, WIN>(S, C, r, true, t, r, d1, d2);
-      double ts = (double) d1, tt = (double) d2;
-      block_sum2<THREADS>(ts, tt, red);
-      PH(1)
-      if (!(tt > 1e-300)) { status = 2; break; }
-      const float omega = (float) (ts / tt);
-      // u += alpha M^-1 p + omega M^-1 s ;  r = s - omega t ;  rho_new = rhat . r
-      float pa = 0.f, pb = 0.f;
-      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
-        f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB], zq[VB];
-#pragma unroll
-        for (int j = 0; j < VB; j++) {
-          const int ic = min(i0 + j * THREADS, N - 1);
-          sq[j] = ld3(r, ic, N); uq[j] = ld3(u, ic, N); tq[j] = ld3(t, ic, N); hq[j] = ld3(rhat, ic, N);
-          if constexpr (BLK) { zq[j] = ld3(sh, ic, N); pq[j] = ld3(ph, ic, N); }
-          else { const float di = S.dinv[ic]; zq[j] = sq[j] * di; pq[j] = ld3(p, ic, N) * di; }
-        }
-#pragma unroll
-        for (int j = 0; j < VB; j++) {
-          const int i = i0 + j * THREADS;
-          f3 rn = sq[j] - tq[j] * omega;
-          if (i < N) {
-            st3(u, i, N, uq[j] + pq[j] * alpha + zq[j] * omega);
-            st3(r, i, N, rn);
-            pa += dot(rn, hq[j]);
-            pb += dot(rn, rn);
-          }
-        }
-      }
-      double rho_new = (double) pa;
-      rr = (double) pb;
-      block_sum2<THREADS>(rho_new, rr, red);
-      if (rr <= stop) { status = 1; break; }
-      if (rr < best_rr) { best_rr = rr; since_progress = 0; }
-      else if (++since_progress >= A.stall_window) { status = 2; break; }
-      if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { status = 2; break; }
-      const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));
-      rho = rho_new;
-      // p = r + beta (p - omega v)
-      for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
-        f3 rq[VB], pq[VB], vq[VB];
-#pragma unroll
-        for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); pq[j] = ld3(p, ic, N); vq[j] = ld3(v, ic, N); }
-#pragma unroll
-        for (int j = 0; j < VB; j++) {
-          const int i = i0 + j * THREADS;
-          if (i < N) { const f3 pn = rq[j] + (pq[j] - vq[j] * omega) * beta; st3(p, i, N, pn); if constexpr (BLK) st3(ph, i, N, pre(i, pn)); }
-        }
-      }
+    // true residual of the start: g itself for u = 0 (mode 1), g - K u after the reference iteration hit its cap (mode 0);
+    // `gin` holds the right-hand side of the next fp32 solve: g, later the fp64 residual rounded to fp32
+    double rr_true = gnorm * gnorm;
+    if (A.mode == 0) {
+      rr_true = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;
+      for (int i = tid; i < N; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));
       __syncthreads();
     }
-    if (status != 1) break;       // cap, breakdown or stall: no further cycle
+    double rr = rr_true;
+    bool fallback = false;
+    status = (rr_true <= stop) ? 1 : 0;
+    for (int kdone = 0; status == 0 && !fallback; cycles++) {
+    // inner tolerance of this cycle: what is left to the target, but never below kInnerFloor of the cycle's own right-hand side
+    // (an fp32 solve does not resolve more than that of an fp64 residual; measured on the prototype tests/proto_adjoint.py:
+    // 1e-3 -> two cycles of 20 + 16 iterations where one solve to 1e-6 takes 41)
+    const double rel_now = sqrt(rr_true) / gnorm;
+    const double in_tol = A.fp32_only ? (double) A.rel_tol : fmax(0.3 * (double) A.rel_tol / rel_now, kInnerFloor);
+    const double in_stop = in_tol * in_tol * rr_true;
+    Krylov32 KV{gin, u, r, p, v, t, rhat, ph, sh, minv};
+    const Ret32 r32 = bicgstab32_solve<THREADS, WIN, BLK>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone, iters);
+    const int in_status = r32.status;
+    kdone = r32.kdone; iters = r32.iters; rr = r32.rr;
     __syncthreads();
+    PH(2)
+    // u += d (fp64)
+    for (int i = tid; i < N; i += THREADS) st3d(W64.u, i, N, ld3d(W64.u, i, N) + tod(ld3(u, i, N)));
+    __syncthreads();
+    if (A.fp32_only) {      // round-2 behaviour: the recurrence residual is all there is
+      status = in_status;
+      if (status == 2 && rr > 1e4 * stop) status = 0;
+      rr_true = rr;
+      cycles++;
+      break;
+    }
+    // the true residual, in fp64
+    double rr_new = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;
+    PH(1)
+    if (rr_new <= stop) { rr_true = rr_new; status = 1; cycles++; break; }
+    // progress of this cycle: at least a factor 4 in the norm, else the fp32 solve is of no further use
+    // (NaN-safe: a diverged correction fails the comparison and is taken back)
+    const bool better = rr_new < rr_true;
+    if (!better) {
+      for (int i = tid; i < N; i += THREADS) st3d(W64.u, i, N, ld3d(W64.u, i, N) - tod(ld3(u, i, N)));
+      __syncthreads();
+      rr_new = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;
+    }
+    if (!(rr_new < 0.0625 * rr_true) || in_status != 1 || cycles + 1 >= kMaxRefine || kdone >= kcap) fallback = true;
+    rr_true = rr_new;
+    if (!fallback) {
+      for (int i = tid; i < N; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));
+      __syncthreads();
+    }
     }   // cycle
-    // "stalled at the fp32 floor" (2) is only claimed near the tolerance: a breakdown or stall with the residual still more than 100 x
-    // above it (an adjoint system beyond an fp32 Krylov solve, e.g. a strongly compressed fine garment) is reported as NOT converged
-    if (status == 2 && rr > 1e4 * stop) status = 0;
-    udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual (of the last recomputed or recurrence residual)
+    if (fallback) {
+      // ---- fp64 BiCGSTAB on the same operator from (u, r): the reference's SparseLU always returns a solution ----
+      if constexpr (!BLK) build_blocks();
+      __syncthreads();
+      double rr64 = rr_true;
+      for (int pass = 0; pass < 3 && status == 0; pass++) {
+        const auto r64 = bicgstab64<THREADS>(S, C64, tm, W64, minv, stop, 20000, rr64, iters64);
+        iters64 = r64.iters;
+        rr64 = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;     // the recurrence drifts over thousands of iterations: check, go again
+        if (rr64 <= stop) status = 1;
+        else if (r64.res == 0) break;
+      }
+      rr_true = rr64;
+    }
+    udiff = sqrt(rr_true) / (gnorm > 0 ? gnorm : 1.0);     // relative residual: fp64-evaluated (mixed precision) or the fp32 recurrence's
   }
   __syncthreads();
   PH(2)
-  // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650) ----
-  float dmu_part[kMaxPrims];
-#pragma unroll
-  for (int k = 0; k < kMaxPrims; k++) dmu_part[k] = 0.f;
-  float *dxf = A.d_xfixed ? A.d_xfixed + (size_t) b * 3 * S.Af : nullptr;
-  contact_transpose<THREADS>(S, C, u, false, C.y);       // y = (I + dr_df)^T u*
-  // parameter gradients of this step (Simulation.cpp:1672-1764), all of the form  <y, d(rhs)/d(theta)>:
-  //   pacc[0..2]  sum over the elements of one type of  y . A^T (p(x_new) - A x_new)   -> dL/dk_type = h^2 / k * pacc
-  //   pacc[3]     density term (:1672-1679, adddr_dd = false)
-  //   pacc[4..6]  h^2 * sum_i y_i  (dL_dfext_vec summed, :1702-1764; the host applies the wind chain rule)
-  float pacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (A.d_param) {
-    const int T = S.T, E = S.E;
-    const float *xnew = C.xnew;
-    const float *yv = C.y;
-    for (int t = tid; t < T; t += THREADS) {
-      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
-      const float4 D = S.tri_D[t];
-      f3 x0 = ld3(xnew, i0, N);
-      f3 e0 = ld3(xnew, i1, N) - x0, e1 = ld3(xnew, i2, N) - x0;
-      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
-      Polar P = polar3x2(f0, f1);
-      f3 g0 = (P.t0 - f0) * S.tri_w2[t], g1 = (P.t1 - f1) * S.tri_w2[t];
-      f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
-      f3 q0 = ld3(yv, i0, N);
-      pacc[0] += dot(c1, ld3(yv, i1, N) - q0) + dot(c2, ld3(yv, i2, N) - q0);
-    }
-    for (int e = tid; e < E; e += THREADS) {
-      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
-      const float4 w = S.bend_w[e];
-      const float2 nw = S.bend_nw[e];
-      f3 x0 = ld3(xnew, i0, N);
-      f3 ev = (ld3(xnew, i1, N) - x0) * w.y + (ld3(xnew, i2, N) - x0) * w.z + (ld3(xnew, i3, N) - x0) * w.w;
-      f3 p = mk(0, 0, 0);
-      if (nw.x > 1e-6f) p = normalized(ev) * nw.x;
-      f3 q0 = ld3(yv, i0, N);
-      f3 ey = (ld3(yv, i1, N) - q0) * w.y + (ld3(yv, i2, N) - q0) * w.z + (ld3(yv, i3, N) - q0) * w.w;
-      pacc[1] += dot((p - ev) * nw.y, ey);
-    }
-  }
-  const f3 grav = mk(S.gx, S.gy, S.gz);
-  for (int i = tid; i < N; i += THREADS) {
-    f3 ui = ld3(u, i, N);
-    const float m = S.mass[i];
-    f3 w = ld3(C.y, i, N) - ui;
-    if (A.d_param) {
-      f3 yi = ui + w;
-      const int a = S.att_of_vertex[i];
-      if (a >= 0) pacc[2] += S.k_att * dot(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af) - ld3(C.xnew, i, N), yi);
-      const float ar = m / S.density;
-      f3 xp = ld3(A.x_prev + off, i, N), vp = ld3(A.v_prev + off, i, N);
-      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - ld3(C.xnew, i, N)) + h * dot(w, vp + grav * h));
-      pacc[4] += h2 * yi.x; pacc[5] += h2 * yi.y; pacc[6] += h2 * yi.z;
-    }
-    const int prim = C.rec_prim[i];
-    if (prim >= 0) {
-      f3 n = ld3(C.rec_n, i, N);
-      f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * m;
-      const int grp = S.prims[prim].group;
-      const float contrib = dot(dri_dmu(n, d, C.mu[grp]), ui) * h;
-#pragma unroll
-      for (int k = 0; k < kMaxPrims; k++) dmu_part[k] += (k == grp) ? contrib : 0.f;
-    }
-    f3 dx = ui * m - ld3(gv, i, N) * (1.0f / h);
-    f3 dv = (ui + w) * (h * m);
-    if (A.ix) dx = dx + ld3(A.ix + off, i, N);
-    if (A.iv) dv = dv + ld3(A.iv + off, i, N);
-    if (!A.is_start) dx = dx + dv * (1.0f / h);
-    st3(gx, i, N, dx);
-    st3(gv, i, N, dv);
-    const int a = S.att_of_vertex[i];
-    if (a >= 0 && dxf) st3(dxf, a, S.Af, (ui + w) * (h2 * S.k_att));   // A_t_dp_dxfixed (Simulation.cpp:3035-3048)
-  }
-  if (A.d_mu) {
-    for (int k = 0; k < S.ngroups; k++) {
-      const double s = block_sum<THREADS>((double) dmu_part[k], red);
-      if (tid == 0) A.d_mu[(size_t) b * S.ngroups + k] += (float) s;
-    }
-  }
-  if (A.d_param) {
-    float *dp = A.d_param + (size_t) b * 8;
-    const float scale[7] = {S.k_stretch > 0.f ? h2 / S.k_stretch : 0.f, S.k_bend > 0.f ? h2 / S.k_bend : 0.f,
-                            S.k_att > 0.f ? h2 / S.k_att : 0.f, 1.f, 1.f, 1.f, 1.f};
-    for (int k = 0; k < 7; k++) {
-      const double s = block_sum<THREADS>((double) pacc[k], red);
-      if (tid == 0) dp[k] = (float) (s * scale[k]);
-    }
-  }
+  // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650), in fp64 from u ----
+  finish_gradients64<THREADS>(S, C64, tm, W64, A, C.y);
   if (tid == 0) {
     dc_bwd_stats s;
     s.converged = status; s.adjoint_iters = iters; s.cg_iters = cg_total; s.clipped = clipped;
     s.used_direct = used_direct; s.last_udiff = (float) udiff;
+    s.refine_cycles = cycles; s.fp64_iters = iters64;
     A.stats[b] = s;
   }
   PH(3)

@@ -1,0 +1,538 @@
+// fp64 side of the adjoint step (Simulation::stepBackward, reference Simulation.cpp:1455-1780): the reference solves
+// (P - dP^T) u = g in fp64 (SimplicialLLT / SparseLU, :1431-1440, :1561-1600); the fp32 Krylov solve of dc_adjoint.hip alone sits
+// at eps_fp32 * cond(K) in the operator's coefficients (1-3e-4 relative on the 10k-vertex cloth and the hat, no answer at all on a
+// compressed fine garment). This header holds what lifts it to the reference's accuracy and robustness:
+//   * K u evaluated matrix-free in fp64 from the fp64 rest-shape tables (DevSystem::*64) — the true residual g - K u of the
+//     mixed-precision refinement (fp32 BiCGSTAB solves for corrections, dc_adjoint.hip / dc_adjoint_cl.hip);
+//   * a block-Jacobi preconditioned BiCGSTAB in fp64 on the same operator — the fall-back when the fp32 solve makes no progress
+//     (adjoint systems beyond fp32: cond(K) ~ 3e7 on the squashed 7 742-vertex dress), standing in for SparseLU's "always
+//     returns a solution";
+//   * the state / parameter gradients of the step (Simulation.cpp:1534, 1608-1650, 1672-1764) accumulated in fp64.
+// Everything is written once over a Team: TeamOne (one workgroup owns the rollout, dc_adjoint.hip) or TeamParts (K workgroups,
+// part p owns rows [r0, r1), dc_adjoint_cl.hip); a Team supplies the row range, barriers, sums and the access path to the one
+// vector that crosses parts (y = (I + dr_df)^T z).
+// The element pass is vertex-centred: a vertex re-evaluates its incident elements (no corner array: ~3.5 x the arithmetic, none
+// of the 72 B per element of fp64 corner traffic, and a part writes nothing but its own rows).
+#pragma once
+#include "dc_devlib.h"
+#include "dc_adjprecond.h"
+
+// Out-of-line by default (see the note at Ret64); -DDC_ADJ_INLINE inlines them again (A/B builds)
+#ifdef DC_ADJ_INLINE
+#define DC_OUTLINED __forceinline__
+#else
+#define DC_OUTLINED __attribute__((noinline))
+#endif
+
+namespace dc {
+
+struct d3 {
+  double x, y, z;
+};
+__device__ __forceinline__ d3 mkd(double x, double y, double z) { return {x, y, z}; }
+__device__ __forceinline__ d3 tod(f3 a) { return {(double) a.x, (double) a.y, (double) a.z}; }
+__device__ __forceinline__ f3 tof(d3 a) { return {(float) a.x, (float) a.y, (float) a.z}; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ d3 ld3d(const double *p, int i, int n) { return {p[i], p[n + i], p[2 * n + i]}; }
+__device__ __forceinline__ void st3d(double *p, int i, int n, d3 v) { p[i] = v.x; p[n + i] = v.y; p[2 * n + i] = v.z; }
+
+// fp64 work vectors of one rollout (planar [3][N] each)
+struct Work64 {
+  double *u, *r, *y;                        // solution, true residual g - K u, y = (I + dr_df)^T z (crosses parts)
+  double *rhat, *p, *v, *t, *ph, *sh;       // fall-back BiCGSTAB
+};
+
+// what the fp64 operator reads of the step being differentiated
+struct Adj64 {
+  const float *xnew, *rec_f, *rec_n, *mu;
+  const int *rec_prim;
+  SelfRec self;
+  int nself, b;
+  float *lds;                               // LDS scratch of the layered self-contact pass
+  int lds_floats;
+};
+
+// ---- one workgroup owns the rollout ----
+template <int THREADS>
+struct TeamOne {
+  int N;
+  double *red;                              // LDS [3 * THREADS / 64]
+  __device__ __forceinline__ int r0() const { return 0; }
+  __device__ __forceinline__ int r1() const { return N; }
+  __device__ __forceinline__ bool leader() const { return true; }
+  __device__ __forceinline__ int part() const { return 0; }
+  __device__ __forceinline__ int parts() const { return 1; }
+  __device__ __forceinline__ bool barrier() { __syncthreads(); return true; }
+  __device__ __forceinline__ bool sum3(double a, double b, double c, double (&s)[3]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    constexpr int NW = THREADS / 64;
+    __syncthreads();
+    if (l == 0) { red[w] = a; red[NW + w] = b; red[2 * NW + w] = c; }
+    __syncthreads();
+    double sa = 0, sb = 0, sc = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { sa += red[k]; sb += red[NW + k]; sc += red[2 * NW + k]; }
+    s[0] = sa; s[1] = sb; s[2] = sc;
+    return true;
+  }
+  // access to y (plain: the workgroup's own L1 / L2 path)
+  struct YV {
+    double *p;
+    __device__ __forceinline__ double ld(int idx) const { return p[idx]; }
+    __device__ __forceinline__ void st(int idx, double v) const { p[idx] = v; }
+  };
+  __device__ __forceinline__ YV yv(double *y) const { return YV{y}; }
+};
+
+template <class YV> __device__ __forceinline__ d3 ld3y(const YV &a, int i, int n) { return mkd(a.ld(i), a.ld(n + i), a.ld(2 * n + i)); }
+template <class YV> __device__ __forceinline__ void st3y(const YV &a, int i, int n, d3 v) { a.st(i, v.x); a.st(n + i, v.y); a.st(2 * n + i, v.z); }
+
+// ---- closed forms in fp64 (same formulas as dc_devlib.h / dc_winlib.h) ----
+struct PolarD {
+  d3 t0, t1;
+  double i00, i01, i11, trS;
+};
+__device__ __forceinline__ PolarD polar3x2d(d3 f0, d3 f1) {
+  const double a = dot(f0, f0), b = dot(f0, f1), c = dot(f1, f1);
+  const double det = fmax(a * c - b * b, 1e-300);
+  const double s = sqrt(det), t = sqrt(a + c + 2.0 * s), inv = 1.0 / (t * s);
+  PolarD P;
+  P.i00 = (c + s) * inv; P.i01 = -b * inv; P.i11 = (a + s) * inv; P.trS = t;
+  P.t0 = f0 * P.i00 + f1 * P.i01;
+  P.t1 = f0 * P.i01 + f1 * P.i11;
+  return P;
+}
+// J^T u of one contact (Simulation::calculatedri_dfi, Simulation.cpp:881-919). The CASE (take-off / stick / slide) is decided by the
+// fp32 arithmetic of dri_dfi_T on the fp32 record, so that the fp64 operator and the fp32 operator it refines are the same matrix
+// up to rounding; the formula is then evaluated in fp64.
+__device__ __forceinline__ d3 dri_dfi_T_d(f3 nf, f3 df, float mu, d3 u) {
+  const float sdf = dot(df, nf);
+  if (sdf >= 0.f) return mkd(0, 0, 0);
+  const f3 dTf = df - nf * sdf;
+  const float nTf = sqrtf(dot(dTf, dTf));
+  if (nTf <= mu * fabsf(sdf)) return mkd(0, 0, 0) - u;
+  const d3 n = tod(nf), d = tod(df);
+  const double sd = dot(d, n);
+  const d3 dT = d - n * sd;
+  const double nT = sqrt(dot(dT, dT));
+  const d3 a = dT * (1.0 / nT);
+  d3 q = u - a * dot(a, u);
+  q = q - n * dot(n, q);
+  d3 w = n * (-dot(n, u));
+  w = w + (q * (sd / nT) + n * dot(a, u)) * (double) mu;
+  return w;
+}
+// dr/dmu (Simulation::calculatedri_dmu, Simulation.cpp:865-879), case decided in fp32 like above
+__device__ __forceinline__ d3 dri_dmu_d(f3 nf, f3 df, float mu) {
+  const float sdf = dot(df, nf);
+  if (sdf >= 0.f) return mkd(0, 0, 0);
+  const f3 dTf = df - nf * sdf;
+  const float nTf = sqrtf(dot(dTf, dTf));
+  if (!(nTf > mu * fabsf(sdf))) return mkd(0, 0, 0);
+  const d3 n = tod(nf), d = tod(df);
+  const double sd = dot(d, n);
+  const d3 dT = d - n * sd;
+  return dT * (-fabs(sd) / sqrt(dot(dT, dT)));
+}
+// w = dr_df^T z of the vertex's primitive contact (Simulation::calculatedr_df, Simulation.cpp:700-711)
+__device__ __forceinline__ d3 contact_JT_d(const DevSystem &S, const Adj64 &C, int i, d3 z) {
+  const int prim = C.rec_prim[i];
+  if (prim < 0) return mkd(0, 0, 0);
+  const int N = S.N;
+  const f3 n = ld3(C.rec_n, i, N);
+  const f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];     // the fp32 record of the forward pass
+  return dri_dfi_T_d(n, d, C.mu[S.prims[prim].group], z);
+}
+
+// ---- layered self contacts, transposed (calculatedr_df, Simulation.cpp:713-760): z <- (I + J_0)^T ... (I + J_L)^T z in fp64 ----
+// One workgroup (the Team's leader) runs it; `z` is the rollout's y through the Team's access path. In LDS when the working set
+// fits (one wave walks the layers, see self_JT_layers_lds_v in dc_devlib.h), else through global memory with a barrier per layer.
+template <int THREADS, class YV>
+__device__ __forceinline__ void self_JT_layers_d(const DevSystem &S, const Adj64 &C, const YV &z) {
+  const int cap = S.self_cap, N = S.N, tid = threadIdx.x, b = C.b;
+  const SelfRec &R = C.self;
+  const int *meta = R.meta + (size_t) b * kMetaStride;
+  const int Cn = min(meta[0], cap), nl = meta[1], M = meta[kMetaStride - 1];
+  const int2 *pair = R.pair + (size_t) b * cap;
+  const float4 *nrm = R.nrm + (size_t) b * cap;
+  const float4 *dvec = R.dvec + (size_t) b * cap;
+  const int need = 8 * M + 8 * Cn + nl + 8;      // floats: 3 M doubles z, M doubles 1/m, 2 C float4, nl + 1 offsets
+  if (S.self_lds && need <= C.lds_floats) {
+    const int *verts = R.verts + (size_t) b * 2 * cap;
+    double *lz = (double *) C.lds, *lim = lz + 3 * M;
+    float4 *ln = (float4 *) (lim + M + (M & 1));       // 16-byte aligned
+    float4 *ld = ln + Cn;
+    int *loff = (int *) (ld + Cn);
+    __syncthreads();
+    for (int s = tid; s < M; s += THREADS) {
+      const int v = verts[s];
+      lz[s] = z.ld(v); lz[M + s] = z.ld(N + v); lz[2 * M + s] = z.ld(2 * N + v);
+      lim[s] = 1.0 / S.mass64[v];
+    }
+    for (int k = tid; k < Cn; k += THREADS) { ln[k] = nrm[k]; ld[k] = dvec[k]; }
+    for (int l = tid; l <= nl; l += THREADS) loff[l] = meta[2 + l];
+    __syncthreads();
+    auto contact = [&](int k) {
+      const float4 n4 = ln[k], d4 = ld[k];
+      const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
+      const double iA = lim[sa], iB = lim[sb];
+      d3 zA = mkd(lz[sa], lz[M + sa], lz[2 * M + sa]), zB = mkd(lz[sb], lz[M + sb], lz[2 * M + sb]);
+      d3 g = dri_dfi_T_d(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * (1.0 / (iA + iB));
+      zA = zA + g * iA; zB = zB - g * iB;
+      lz[sa] = zA.x; lz[M + sa] = zA.y; lz[2 * M + sa] = zA.z;
+      lz[sb] = zB.x; lz[M + sb] = zB.y; lz[2 * M + sb] = zB.z;
+    };
+    if (nl <= kWideLayers) {
+      for (int l = nl - 1; l >= 0; l--) {
+        const int k1 = loff[l + 1];
+        for (int k = loff[l] + tid; k < k1; k += THREADS) contact(k);
+        __syncthreads();
+      }
+    } else {
+      if (tid < 64) {
+        for (int l = nl - 1; l >= 0; l--) {
+          const int k1 = loff[l + 1];
+          for (int k = loff[l] + tid; k < k1; k += 64) contact(k);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+      }
+      __syncthreads();
+    }
+    for (int s = tid; s < M; s += THREADS) { const int v = verts[s]; z.st(v, lz[s]); z.st(N + v, lz[M + s]); z.st(2 * N + v, lz[2 * M + s]); }
+    __syncthreads();
+    return;
+  }
+  __syncthreads();
+  for (int l = nl - 1; l >= 0; l--) {
+    const int k1 = meta[2 + l + 1];
+    for (int k = meta[2 + l] + tid; k < k1; k += THREADS) {
+      const int2 ab = pair[k];
+      const float4 n4 = nrm[k], d4 = dvec[k];
+      const double mA = S.mass64[ab.x], mB = S.mass64[ab.y];
+      d3 zA = ld3y(z, ab.x, N), zB = ld3y(z, ab.y, N);
+      d3 g = dri_dfi_T_d(mk(n4.x, n4.y, n4.z), mk(d4.x, d4.y, d4.z), kClothMu, zA - zB) * ((mA * mB) / (mA + mB));
+      st3y(z, ab.x, N, zA + g * (1.0 / mA));
+      st3y(z, ab.y, N, zB - g * (1.0 / mB));
+    }
+    __syncthreads();
+  }
+}
+
+// y = (I + dr_df)^T z on the Team's rows (z: own rows, plain), left in W.y through the Team's access path: self layers L..0 first,
+// the block-diagonal primitive part last (calculatedr_df, Simulation.cpp:686-768). Ends with a Team barrier: y is complete.
+template <int THREADS, class Team>
+__device__ __forceinline__ bool form_y64(const DevSystem &S, const Adj64 &C, Team &tm, const double *z, double *y) {
+  const int N = S.N;
+  const auto Y = tm.yv(y);
+  if (C.nself > 0) {
+    for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) st3y(Y, i, N, ld3d(z, i, N));
+    if (!tm.barrier()) return false;
+    if (tm.leader()) self_JT_layers_d<THREADS>(S, C, Y);
+    if (!tm.barrier()) return false;
+    for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) { const d3 q = ld3y(Y, i, N); st3y(Y, i, N, q + contact_JT_d(S, C, i, q)); }
+  } else {
+    for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) { const d3 q = ld3d(z, i, N); st3y(Y, i, N, q + contact_JT_d(S, C, i, q)); }
+  }
+  return tm.barrier();
+}
+
+// The element terms of vertex i: sum over its incident constraint corners of h^2 w^2 [(A - dp/dx)^T A y]_corner
+// (Triangle::projectToManifoldBackward Triangle.cpp:354-451 in closed form, TriangleBending::backwardGradient
+// TriangleBending.cpp:154-172), y read through the Team's access path, x_new from the fp32 tape.
+template <class YV>
+__device__ __forceinline__ d3 element_terms64(const DevSystem &S, const float *__restrict__ xnew, const YV &Y, int i) {
+  const int N = S.N, T = S.T, E = S.E;
+  const double h2 = S.h64 * S.h64;
+  d3 acc = mkd(0, 0, 0);
+  const int k1 = S.inc_ptr[i + 1];
+  for (int k = S.inc_ptr[i]; k < k1; k++) {
+    const int idx = S.inc_idx[k];
+    if (idx < 3 * T) {
+      const int corner = idx / T, t = idx - corner * T;
+      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+      const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
+      const d3 x0 = tod(ld3(xnew, i0, N));
+      const d3 e0 = tod(ld3(xnew, i1, N)) - x0, e1 = tod(ld3(xnew, i2, N)) - x0;
+      const PolarD P = polar3x2d(e0 * Dx + e1 * Dz, e0 * Dy + e1 * Dw);
+      const d3 q0 = ld3y(Y, i0, N);
+      const d3 d0 = ld3y(Y, i1, N) - q0, d1 = ld3y(Y, i2, N) - q0;
+      const d3 y0 = d0 * Dx + d1 * Dz, y1 = d0 * Dy + d1 * Dw;
+      const double c = (dot(P.t1, y0) - dot(P.t0, y1)) / P.trS;
+      d3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
+      z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
+      z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
+      const double s = h2 * S.tri_w2_64[t];
+      const d3 r0 = (y0 - (P.t1 * c + z0)) * s, r1 = (y1 - (z1 - P.t0 * c)) * s;
+      const d3 c1 = r0 * Dx + r1 * Dy, c2 = r0 * Dz + r1 * Dw;
+      acc = acc + (corner == 1 ? c1 : (corner == 2 ? c2 : mkd(0, 0, 0) - c1 - c2));
+    } else {
+      const int q = idx - 3 * T, corner = q / E, e = q - corner * E;
+      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+      const double w0 = S.bend_w64[e], w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
+      const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
+      const d3 q0 = ld3y(Y, i0, N);
+      const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
+      d3 res = ey;
+      if (nrest > 1e-6) {
+        const d3 x0 = tod(ld3(xnew, i0, N));
+        const d3 ev = (tod(ld3(xnew, i1, N)) - x0) * w1 + (tod(ld3(xnew, i2, N)) - x0) * w2 + (tod(ld3(xnew, i3, N)) - x0) * w3;
+        const double en = sqrt(dot(ev, ev));
+        const d3 eh = ev * (1.0 / en);
+        res = ey - (ey - eh * dot(eh, ey)) * (nrest / en);
+      }
+      res = res * (h2 * wsq);
+      acc = acc + res * (corner == 0 ? w0 : (corner == 1 ? w1 : (corner == 2 ? w2 : w3)));
+    }
+  }
+  return acc;
+}
+
+// out = K z on the Team's rows (fp64): K = M + h^2 (A - dp/dx)^T A (I + dr_df)^T. vert(i, K z at vertex i) is called for every own
+// row exactly once (store, accumulate dot products ...). Ends WITHOUT a barrier: the caller reduces next (which is also what
+// keeps a part from overwriting y while a neighbour still gathers from it).
+template <int THREADS, class Team, class VertOp>
+__device__ __forceinline__ bool apply_K64(const DevSystem &S, const Adj64 &C, Team &tm, const double *z, double *y, VertOp vert) {
+  if (!form_y64<THREADS>(S, C, tm, z, y)) return false;
+  const int N = S.N;
+  const auto Y = tm.yv(y);
+  const double hk = S.h64 * S.h64 * S.k_att64;
+  for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) {
+    d3 o = ld3d(z, i, N) * S.mass64[i] + element_terms64(S, C.xnew, Y, i);
+    if (S.att_of_vertex[i] >= 0) o = o + ld3y(Y, i, N) * hk;       // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
+    vert(i, o);
+  }
+  return true;
+}
+
+__device__ __forceinline__ d3 block_pre_d(const float *__restrict__ minv, int i, int N, d3 r) {
+  return mkd((double) minv[i] * r.x + (double) minv[N + i] * r.y + (double) minv[2 * N + i] * r.z,
+             (double) minv[3 * N + i] * r.x + (double) minv[4 * N + i] * r.y + (double) minv[5 * N + i] * r.z,
+             (double) minv[6 * N + i] * r.x + (double) minv[7 * N + i] * r.y + (double) minv[8 * N + i] * r.z);
+}
+
+// Fall-back: right-preconditioned BiCGSTAB in fp64 on K u = g, continuing from (W.u, W.r = g - K u, rr = |r|^2). Preconditioner:
+// the inverted 3 x 3 diagonal blocks of K in `minv` (dc_adjprecond.h; fp32 storage, applied in fp64). A breakdown (rho, omega or
+// rhat.v vanishing) restarts the recurrence from the current residual. Returns 1 when |r|^2 <= stop2 by the recurrence (the caller
+// re-evaluates the true residual), 0 at the cap, -1 when an exchange of the Team failed. `rr` and `iters` are updated.
+// (Structs travel BY VALUE into these non-inlined functions: an object whose address is passed to a call lives in scratch memory
+// for the whole kernel, and every later read of one of its fields becomes a scratch load.)
+template <class Team>
+struct Ret64 {
+  int res;            // 1 converged by the recurrence, 0 cap / breakdown, -1 an exchange of the Team failed
+  int iters;
+  double rr;
+  Team tm;            // the Team's exchange state moves on inside the call
+};
+template <int THREADS, class Team>
+__device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team tm, Work64 W, const float *__restrict__ minv,
+                                                            double stop2, int kcap, double rr, int iters) {
+  const int N = S.N, tid = threadIdx.x;
+  auto ret = [&](int res) { return Ret64<Team>{res, iters, rr, tm}; };
+  double s3[3];
+  double rho = rr;
+  int restarts = 0;
+  for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+    const d3 q = ld3d(W.r, i, N);
+    st3d(W.rhat, i, N, q); st3d(W.p, i, N, q); st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
+  }
+  if (!tm.barrier()) return ret(-1);
+  for (int k = 0; k < kcap; k++) {
+    if (rr <= stop2) return ret(1);
+    bool restart = false;
+    // v = K M^-1 p ; alpha = rho / (rhat . v)
+    double a1 = 0;
+    if (!apply_K64<THREADS>(S, C, tm, W.ph, W.y, [&](int i, d3 o) { st3d(W.v, i, N, o); a1 += dot(o, ld3d(W.rhat, i, N)); })) return ret(-1);
+    if (!tm.sum3(a1, 0, 0, s3)) return ret(-1);
+    const double rv = s3[0];
+    double alpha = 0, omega = 0;
+    if (!(fabs(rv) > 1e-300 * fmax(1.0, fabs(rho)))) restart = true;
+    if (!restart) {
+      alpha = rho / rv;
+      // s = r - alpha v (in place), sh = M^-1 s
+      double ss = 0;
+      for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+        const d3 s = ld3d(W.r, i, N) - ld3d(W.v, i, N) * alpha;
+        st3d(W.r, i, N, s); st3d(W.sh, i, N, block_pre_d(minv, i, N, s));
+        ss += dot(s, s);
+      }
+      if (!tm.sum3(ss, 0, 0, s3)) return ret(-1);
+      iters++;
+      if (s3[0] <= stop2) {
+        for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) st3d(W.u, i, N, ld3d(W.u, i, N) + ld3d(W.ph, i, N) * alpha);
+        rr = s3[0];
+        return ret(1);
+      }
+      // t = K M^-1 s ; omega = (t . s) / (t . t)
+      double b1 = 0, b2 = 0;
+      if (!apply_K64<THREADS>(S, C, tm, W.sh, W.y, [&](int i, d3 o) { st3d(W.t, i, N, o); b1 += dot(o, ld3d(W.r, i, N)); b2 += dot(o, o); })) return ret(-1);
+      if (!tm.sum3(b1, b2, 0, s3)) return ret(-1);
+      omega = s3[1] > 1e-300 ? s3[0] / s3[1] : 0.0;
+      // u += alpha M^-1 p + omega M^-1 s ; r = s - omega t ; rho_new = rhat . r
+      double pa = 0, pb = 0;
+      for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+        const d3 rn = ld3d(W.r, i, N) - ld3d(W.t, i, N) * omega;
+        st3d(W.u, i, N, ld3d(W.u, i, N) + ld3d(W.ph, i, N) * alpha + ld3d(W.sh, i, N) * omega);
+        st3d(W.r, i, N, rn);
+        pa += dot(rn, ld3d(W.rhat, i, N)); pb += dot(rn, rn);
+      }
+      if (!tm.sum3(pa, pb, 0, s3)) return ret(-1);
+      const double rho_new = s3[0];
+      rr = s3[1];
+      if (rr <= stop2) return ret(1);
+      if (!(fabs(rho_new) > 1e-30 * rr) || !(fabs(omega) > 0.0) || !isfinite(rr)) restart = true;
+      else {
+        const double beta = (rho_new / rho) * (alpha / omega);
+        rho = rho_new;
+        for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+          const d3 pn = ld3d(W.r, i, N) + (ld3d(W.p, i, N) - ld3d(W.v, i, N) * omega) * beta;
+          st3d(W.p, i, N, pn); st3d(W.ph, i, N, block_pre_d(minv, i, N, pn));
+        }
+      }
+    }
+    if (restart) {
+      if (++restarts > 50 || !isfinite(rr)) return ret(0);
+      for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+        const d3 q = ld3d(W.r, i, N);
+        st3d(W.rhat, i, N, q); st3d(W.p, i, N, q); st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
+      }
+      rho = rr;
+    }
+    if (!tm.barrier()) return ret(-1);
+  }
+  return ret(rr <= stop2 ? 1 : 0);
+}
+
+// r = g - K u on the Team's rows, g = gscale * gx (the clipped carried gradient, fp32); returns |r|^2 in Ret64::rr.
+template <int THREADS, class Team>
+__device__ DC_OUTLINED Ret64<Team> residual64(const DevSystem &S, Adj64 C, Team tm, Work64 W, const float *__restrict__ gx, float gscale) {
+  const int N = S.N;
+  double a = 0;
+  if (!apply_K64<THREADS>(S, C, tm, W.u, W.y, [&](int i, d3 o) {
+        const d3 q = tod(ld3(gx, i, N) * gscale) - o;
+        st3d(W.r, i, N, q);
+        a += dot(q, q);
+      })) return Ret64<Team>{-1, 0, 0.0, tm};
+  double s3[3];
+  if (!tm.sum3(a, 0, 0, s3)) return Ret64<Team>{-1, 0, 0.0, tm};
+  return Ret64<Team>{1, 0, s3[0], tm};
+}
+
+// Gradients of the step from the converged u (W.u), all in fp64 (Simulation.cpp:1534, 1608-1650, 1672-1764): dL_dx / dL_dv into the
+// carried gx / gv (fp32 storage), dL_dxfixed, dL_dmu (accumulated), the per-step parameter terms d_param[0..6]
+//   [0..2]  sum over the elements of one type of  y . A^T (p(x_new) - A x_new)   -> dL/dk_type = h^2 / k * sum
+//   [3]     density term (:1672-1679, adddr_dd = false)
+//   [4..6]  h^2 * sum_i y_i  (dL_dfext_vec summed, :1702-1764; the host applies the wind chain rule)
+// and y = (I + dr_df)^T u as fp32 in y32 (dc_get_force_gradient reads it). Elements are dealt to the Team's parts in contiguous ranges.
+template <int THREADS, class Team>
+__device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 C, Team tm, Work64 W, BwdArgs A, float *__restrict__ y32) {
+  auto ret = [&](int res) { return Ret64<Team>{res, 0, 0.0, tm}; };
+  const int N = S.N, tid = threadIdx.x, b = C.b;
+  const size_t off = (size_t) b * 3 * N;
+  float *gx = A.gx + off, *gv = A.gv + off;
+  const double h = S.h64, h2 = h * h;
+  if (!form_y64<THREADS>(S, C, tm, W.u, W.y)) return ret(-1);
+  const auto Y = tm.yv(W.y);
+  double pacc[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (A.d_param) {
+    const int T = S.T, E = S.E, K = tm.parts(), part = tm.part();
+    const float *xnew = C.xnew;
+    const int t0 = (int) ((long long) T * part / K), t1 = (int) ((long long) T * (part + 1) / K);
+    for (int t = t0 + tid; t < t1; t += THREADS) {
+      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+      const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
+      const d3 x0 = tod(ld3(xnew, i0, N));
+      const d3 e0 = tod(ld3(xnew, i1, N)) - x0, e1 = tod(ld3(xnew, i2, N)) - x0;
+      const d3 f0 = e0 * Dx + e1 * Dz, f1 = e0 * Dy + e1 * Dw;
+      const PolarD P = polar3x2d(f0, f1);
+      const double w2 = S.tri_w2_64[t];
+      const d3 g0 = (P.t0 - f0) * w2, g1 = (P.t1 - f1) * w2;
+      const d3 c1 = g0 * Dx + g1 * Dy, c2 = g0 * Dz + g1 * Dw;
+      const d3 q0 = ld3y(Y, i0, N);
+      pacc[0] += dot(c1, ld3y(Y, i1, N) - q0) + dot(c2, ld3y(Y, i2, N) - q0);
+    }
+    const int e0i = (int) ((long long) E * part / K), e1i = (int) ((long long) E * (part + 1) / K);
+    for (int e = e0i + tid; e < e1i; e += THREADS) {
+      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+      const double w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
+      const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
+      const d3 x0 = tod(ld3(xnew, i0, N));
+      const d3 ev = (tod(ld3(xnew, i1, N)) - x0) * w1 + (tod(ld3(xnew, i2, N)) - x0) * w2 + (tod(ld3(xnew, i3, N)) - x0) * w3;
+      d3 p = mkd(0, 0, 0);
+      if (nrest > 1e-6) { const double n2 = dot(ev, ev); p = n2 > 0 ? ev * (nrest / sqrt(n2)) : ev * nrest; }
+      const d3 q0 = ld3y(Y, i0, N);
+      const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
+      pacc[1] += dot((p - ev) * wsq, ey);
+    }
+  }
+  double dmu_part[kMaxPrims];
+#pragma unroll
+  for (int k = 0; k < kMaxPrims; k++) dmu_part[k] = 0.0;
+  float *dxf = A.d_xfixed ? A.d_xfixed + (size_t) b * 3 * S.Af : nullptr;
+  const d3 grav = mkd(S.g64[0], S.g64[1], S.g64[2]);
+  for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+    const d3 ui = ld3d(W.u, i, N), yi = ld3y(Y, i, N), w = yi - ui;
+    const double m = S.mass64[i];
+    if (A.d_param) {
+      const int a = S.att_of_vertex[i];
+      if (a >= 0) pacc[2] += S.k_att64 * dot(tod(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af)) - tod(ld3(C.xnew, i, N)), yi);
+      const double ar = m / S.density64;
+      const d3 xp = tod(ld3(A.x_prev + off, i, N)), vp = tod(ld3(A.v_prev + off, i, N));
+      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - tod(ld3(C.xnew, i, N))) + h * dot(w, vp + grav * h));
+      pacc[4] += h2 * yi.x; pacc[5] += h2 * yi.y; pacc[6] += h2 * yi.z;
+    }
+    const int prim = C.rec_prim[i];
+    if (prim >= 0) {
+      const f3 n = ld3(C.rec_n, i, N);
+      const f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];
+      const int grp = S.prims[prim].group;
+      const double contrib = dot(dri_dmu_d(n, d, C.mu[grp]), ui) * h;
+#pragma unroll
+      for (int k = 0; k < kMaxPrims; k++) dmu_part[k] += (k == grp) ? contrib : 0.0;
+    }
+    d3 dx = ui * m - tod(ld3(gv, i, N)) * (1.0 / h);
+    d3 dv = yi * (h * m);
+    if (A.ix) dx = dx + tod(ld3(A.ix + off, i, N));
+    if (A.iv) dv = dv + tod(ld3(A.iv + off, i, N));
+    if (!A.is_start) dx = dx + dv * (1.0 / h);
+    st3(gx, i, N, tof(dx));
+    st3(gv, i, N, tof(dv));
+    st3(y32, i, N, tof(yi));
+    const int a = S.att_of_vertex[i];
+    if (a >= 0 && dxf) st3(dxf, a, S.Af, tof(yi * (h2 * S.k_att64)));   // A_t_dp_dxfixed (Simulation.cpp:3035-3048)
+  }
+  double s3[3];
+  const bool writer = tid == 0 && tm.leader();
+  if (A.d_mu) {
+    for (int k0 = 0; k0 < S.ngroups; k0 += 3) {
+      double val[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        val[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < kMaxPrims; k++) val[c] += (k == k0 + c) ? dmu_part[k] : 0.0;
+      }
+      if (!tm.sum3(val[0], val[1], val[2], s3)) return ret(-1);
+      if (writer)
+        for (int c = 0; c < 3 && k0 + c < S.ngroups; c++) A.d_mu[(size_t) b * S.ngroups + k0 + c] += (float) s3[c];
+    }
+  }
+  if (A.d_param) {
+    float *dp = A.d_param + (size_t) b * 8;
+    const double scale[9] = {S.k_stretch64 > 0 ? h2 / S.k_stretch64 : 0.0, S.k_bend64 > 0 ? h2 / S.k_bend64 : 0.0,
+                             S.k_att64 > 0 ? h2 / S.k_att64 : 0.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < 7; k0 += 3) {
+      if (!tm.sum3(pacc[k0], k0 + 1 < 7 ? pacc[k0 + 1 < 7 ? k0 + 1 : 6] : 0.0, k0 + 2 < 7 ? pacc[k0 + 2 < 7 ? k0 + 2 : 6] : 0.0, s3)) return ret(-1);
+      if (writer)
+        for (int c = 0; c < 3 && k0 + c < 7; c++) dp[k0 + c] = (float) (s3[c] * scale[k0 + c]);
+    }
+  }
+  return ret(1);
+}
+
+}  // namespace dc

@@ -439,6 +439,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     dc_bwd_stats s;
     s.converged = status; s.adjoint_iters = iters; s.cg_iters = 0; s.clipped = clipped;
     s.used_direct = 1; s.last_udiff = (float) udiff;
+    s.refine_cycles = 0; s.fp64_iters = 0;
     A.stats[b] = s;
   }
   (void) none;

@@ -95,6 +95,16 @@ struct DevSystem {
   float h, k_att, gx, gy, gz;
   float k_stretch, k_bend, density;
   int contact_enabled, self_enabled, pad1;
+  // fp64 copies of the rest-shape tables and parameters: the adjoint's fp64 operator / gradient assembly (dc_adjoint64.h).
+  // The reference computes these in fp64 (Triangle.cpp:587-645, TriangleBending.cpp:186-239, Simulation.cpp:2894-2966); the fp32
+  // tables above are their roundings.
+  const double DC_G *tri_D64;        // [4][T] planar: inv_deltaUV d00, d01, d10, d11
+  const double DC_G *tri_w2_64;      // [T]
+  const double DC_G *bend_w64;       // [4][E] planar cotan weights
+  const double DC_G *bend_nw64;      // [2][E] planar: rest norm, weight^2
+  const double DC_G *mass64;         // [N]
+  double h64, k_att64, k_stretch64, k_bend64, density64;
+  double g64[3];
   DevPrim prims[kMaxPrims];
   // device-resident copy of this struct: kernels receive THIS pointer and read fields with scalar loads on
   // demand (passing the ~450-byte struct by value cost > 100 spilled SGPRs per kernel)
@@ -112,6 +122,9 @@ struct DevWork {
   // adjoint, direct solve: preconditioned search direction / residual (M^-1 p, M^-1 s) and the 3 x 3 block inverses (dc_adjprecond.h)
   float *pre_p, *pre_s;   // [B][3][N]
   float *minv;            // [B][9][N]
+  // adjoint in mixed precision (dc_adjoint64.h): solution, true residual, y = (I + dr_df)^T z, and the six further vectors of the
+  // fp64 fall-back BiCGSTAB; [B][3][N] doubles each
+  double *u64, *r64, *y64, *k64[6];
   // self-collision detection / layering scratch (k_self_detect)
   int *sd_cell, *sd_order;      // [B][N]
   float *sd_sx;                 // [B][3][N] positions in cell-sorted order
@@ -172,6 +185,7 @@ struct BwdArgs {
   int mode;                     // 0: reference fixed-point iteration (+ direct fallback), 1: direct Krylov solve
   int it_cap, cg_max, is_start, clip, stall_window;
   int block_pre;                // direct solve: 1 = block-Jacobi from K's own diagonal blocks (dc_adjprecond.h), 0 = Jacobi from diag(P)
+  int fp32_only;                // direct solve: 1 = the fp32 Krylov solve alone (no fp64 residual, no refinement, no fp64 fall-back)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;
   size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements); d_xfixed steps by slot_xf too

@@ -225,6 +225,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.rel_tol = (float) (c->params.adjoint_rel_tol > 0 ? c->params.adjoint_rel_tol : 1e-6);
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   { const char *envp = getenv("DC_BLOCK_PRE"); A.block_pre = envp ? (envp[0] != '0') : (c->params.adjoint_block_precond != 0); }   // (development switch)
+  { const char *envp = getenv("DC_ADJ_FP32"); A.fp32_only = envp ? (envp[0] == '1') : (c->params.adjoint_fp32_only != 0); }     // (development switch)
   A.nsteps = 1; A.slot = slot;
   A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   A.slot_param = (size_t) c->B * 8; A.slot_xf = (size_t) c->B * 3 * c->S.Af; A.slot_stats = (size_t) c->B;
@@ -416,7 +417,7 @@ void dc_default_params(dc_params *p) {
   p->gravity_enabled = 1; p->contact_enabled = 1; p->selfcollision_enabled = 0;
   p->gradient_clipping = 1; p->gradient_clipping_threshold = 16.0;                                      // Simulation.h:330-331
   p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 0;
-  p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6; p->adjoint_block_precond = 1;
+  p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6; p->adjoint_block_precond = 1; p->adjoint_fp32_only = 0;
   p->max_self_contacts = 0;      /* sized from the mesh in dc_build */
 }
 
@@ -591,6 +592,19 @@ int dc_build(dc_ctx *c) {
   if ((rc = upload<int>(c, &S.att_of_vertex, att_of))) return rc;
   if ((rc = upload<float>(c, &S.mass, H.mass))) return rc;
   if ((rc = upload<float>(c, &S.dinv, dinv))) return rc;
+  {  // fp64 rest-shape tables of the adjoint's fp64 operator (dc_adjoint64.h), planar
+    std::vector<double> d4(4 * (size_t) T), w4(4 * (size_t) E), nw2(2 * (size_t) E);
+    for (int t = 0; t < T; t++) for (int k = 0; k < 4; k++) d4[(size_t) k * T + t] = H.tri_D[4 * (size_t) t + k];
+    for (int e = 0; e < E; e++) {
+      for (int k = 0; k < 4; k++) w4[(size_t) k * E + e] = H.bend_w[4 * (size_t) e + k];
+      nw2[e] = H.bend_n[e]; nw2[(size_t) E + e] = H.bend_w2[e];
+    }
+    if ((rc = upload<double>(c, &S.tri_D64, d4))) return rc;
+    if ((rc = upload<double>(c, &S.tri_w2_64, H.tri_w2))) return rc;
+    if ((rc = upload<double>(c, &S.bend_w64, w4))) return rc;
+    if ((rc = upload<double>(c, &S.bend_nw64, nw2))) return rc;
+    if ((rc = upload<double>(c, &S.mass64, H.mass))) return rc;
+  }
   if ((rc = upload<int>(c, &S.P_ptr, H.P_ptr))) return rc;
   if ((rc = upload<int>(c, &S.P_col, H.P_col))) return rc;
   if ((rc = upload<float>(c, &S.P_val, H.P_val))) return rc;
@@ -687,6 +701,8 @@ int dc_build(dc_ctx *c) {
   S.gx = p.gravity_enabled ? (float) p.gravity[0] : 0.f;
   S.gy = p.gravity_enabled ? (float) p.gravity[1] : 0.f;
   S.gz = p.gravity_enabled ? (float) p.gravity[2] : 0.f;
+  S.h64 = p.time_step; S.k_att64 = p.k_att; S.k_stretch64 = p.k_stretch; S.k_bend64 = p.k_bend; S.density64 = p.density;
+  for (int k = 0; k < 3; k++) S.g64[k] = p.gravity_enabled ? p.gravity[k] : 0.0;
   S.contact_enabled = p.contact_enabled; S.self_enabled = p.selfcollision_enabled;
   S.nprim = (int) c->prims.size(); S.ngroups = std::max(c->ngroups, 1);
   for (int k = 0; k < S.nprim; k++) {
@@ -730,6 +746,7 @@ int dc_set_flags(dc_ctx *c, int gravity_enabled, int contact_enabled, int selfco
   S.gx = gravity_enabled ? (float) c->params.gravity[0] : 0.f;
   S.gy = gravity_enabled ? (float) c->params.gravity[1] : 0.f;
   S.gz = gravity_enabled ? (float) c->params.gravity[2] : 0.f;
+  for (int k = 0; k < 3; k++) S.g64[k] = gravity_enabled ? c->params.gravity[k] : 0.0;
   S.contact_enabled = contact_enabled; S.self_enabled = selfcollision_enabled;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy((void *) S.self_dev, &S, sizeof(DevSystem), hipMemcpyHostToDevice));
@@ -807,6 +824,10 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->W.pre_p, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.pre_s, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.minv, (size_t) B * 9 * N))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.u64, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.r64, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.y64, se))) return rc;
+  for (int k = 0; k < 6; k++) if ((rc = dev_alloc(c, pool, &c->W.k64[k], se))) return rc;
   {
     const int cap = c->S.self_cap;
     c->self_cap = cap;

@@ -80,6 +80,12 @@ typedef struct dc_params {
    * from x_new every backward step (in-plane stiff / normal soft, sticking contacts decoupled); 0 = the forward solve's Jacobi
    * diag(P)^-1. Changes the iteration count only, not what the solve converges to.                                      */
   int adjoint_block_precond;
+  /* direct adjoint solve, precision: 0 (default) = mixed — fp32 BiCGSTAB solves for corrections of the residual g - K u evaluated
+   * in fp64 from fp64 rest-shape tables, until |g - K u| <= adjoint_rel_tol |g| holds in fp64; when the fp32 solve makes no
+   * progress (adjoint systems beyond fp32, e.g. a compressed fine garment) a block-Jacobi BiCGSTAB in fp64 on the same operator
+   * takes over — the role of the reference's fp64 SparseLU (Simulation.cpp:1431-1440), which always returns a solution.
+   * 1 = the fp32 Krylov solve alone (round-2 behaviour: gradients at eps_fp32 * cond(K), 1-3e-4 on stiff / large scenes).   */
+  int adjoint_fp32_only;
   int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: sized from the mesh,
                                        max(2048, N) pairs (at most 16000); overflow is reported, never silent: dc_step_stats */
 } dc_params;
@@ -105,7 +111,10 @@ typedef struct dc_bwd_stats {
   int cg_iters;
   int clipped;
   int used_direct;       /* 1 when the direct (Krylov) solve ran; adjoint_iters then counts its iterations too */
-  float last_udiff;      /* mode 0: |u_new - u|_2 / N; direct solve: relative residual |g - K u| / |g| */
+  float last_udiff;      /* mode 0: |u_new - u|_2 / N; direct solve: relative residual |g - K u| / |g| (mixed precision: the TRUE
+                            residual, evaluated in fp64; adjoint_fp32_only: the fp32 recurrence's)                          */
+  int refine_cycles;     /* direct solve, mixed precision: fp32 solves run (each followed by an fp64 residual evaluation)    */
+  int fp64_iters;        /* BiCGSTAB iterations of the fp64 fall-back (0: the fp32 corrections were enough)                 */
 } dc_bwd_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

@@ -3,6 +3,7 @@
 #include "orc_sim.h"
 #include <cstring>
 #include <chrono>
+#include <omp.h>
 
 using namespace orc;
 
@@ -211,4 +212,21 @@ extern "C" void orc_round_record(void *s, int id, int which) {
     for (PrimContact &c : rec.prim) { c.d = V3((float) c.d.x, (float) c.d.y, (float) c.d.z); c.r = V3((float) c.r.x, (float) c.r.y, (float) c.r.z); }
     for (auto &L : rec.layers) for (SelfContact &c : L) c.d = V3((float) c.d.x, (float) c.d.y, (float) c.d.z);
   }
+}
+
+// Diagnostic for the solver prototypes (tests/proto_adjoint.py): K = P - dP^T of record `id` as CSC. Two calls: with rowidx == NULL
+// it returns the number of entries (and fills colptr), then the caller allocates and calls again.
+extern "C" int orc_adjoint_matrix(void *s, int id, int *colptr, int *rowidx, double *val) {
+  Sim *S = (Sim *) s;
+  static thread_local std::vector<int> cp, ri;
+  static thread_local std::vector<double> va;
+  if (!rowidx) {
+    omp_set_num_threads(S->P.threads);
+    S->adjointMatrix(S->records[id], cp, ri, va, 0.0);
+    std::memcpy(colptr, cp.data(), sizeof(int) * cp.size());
+    return (int) ri.size();
+  }
+  std::memcpy(rowidx, ri.data(), sizeof(int) * ri.size());
+  std::memcpy(val, va.data(), sizeof(double) * va.size());
+  return (int) ri.size();
 }

@@ -869,6 +869,91 @@ M3 mul33(const M3 &a, const M3 &b) {
 }
 }  // namespace
 
+namespace {
+// dr_df and the projection Jacobians of one record, and with them the operator dP^T of the adjoint fixed point
+// (Sim.cpp:1540-1551, 1573-1575). Shared by stepBackward and the diagnostic adjointMatrix.
+struct AdjointSystem {
+  const Sim &S;
+  const Record &rec;
+  BlockRows dr_df;
+  std::vector<Mat> Jtri, Jbend;
+  AdjointSystem(const Sim &sim, const Record &r) : S(sim), rec(r), dr_df(sim.N) {
+    const Params &P = S.P;
+    const auto &prims = S.prims; const auto &mass = S.mass; const auto &tris = S.tris; const auto &bends = S.bends;
+    const int N = S.N;
+    (void) N;
+    // --- dr_df (Sim.cpp:686-768) ---
+    if (P.contactEnabled) {
+      for (const PrimContact &info : rec.prim)
+        if (info.primitiveId != -1) dr_df.add(info.particleId, info.particleId, Sim::dri_dfi(info.normal, info.d, prims[info.primitiveId].mu));
+      if (P.selfcollisionEnabled)
+        for (const auto &layer : rec.layers) {
+          BlockRows last = dr_df;
+          for (const SelfContact &info : layer) {
+            int nA = info.particleId1, nB = info.particleId2;
+            double mA = mass[nA], mB = mass[nB], k = (mA * mB) / (mA + mB);
+            M3 dr_dd = Sim::dri_dfi(info.normal, info.d, 0.1);
+            M3 dA, dB;
+            for (int q = 0; q < 9; q++) { dA[q] = k * dr_dd[q] / mA; dB[q] = -k * dr_dd[q] / mB; }
+            dr_df.add(nA, nA, dA); dr_df.add(nA, nB, dB);
+            dr_df.add(nB, nA, dA, -1.0); dr_df.add(nB, nB, dB, -1.0);
+            for (auto &kv : last.rows[nA]) { M3 m = mul33(dA, kv.second); dr_df.add(nA, kv.first, m); dr_df.add(nB, kv.first, m, -1.0); }
+            for (auto &kv : last.rows[nB]) { M3 m = mul33(dB, kv.second); dr_df.add(nA, kv.first, m); dr_df.add(nB, kv.first, m, -1.0); }
+          }
+        }
+    }
+    // --- projection Jacobians at x_new (Sim.cpp:1540-1551) ---
+    const int T = (int) tris.size(), E = (int) bends.size();
+    Jtri.resize(T); Jbend.resize(E);
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < T; t++) Jtri[t] = S.triProjectBackward(tris[t], rec.x.data()) * tris[t].w;
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < E; e++) Jbend[e] = S.bendBackward(bends[e], rec.x.data());
+  }
+  // deltaU(u) = t2 * dproj^T * A * (dr_df^T u + u) - C^T (dr_df^T u)   (Sim.cpp:1573-1575)
+  void applyDeltaPT(const std::vector<double> &u, std::vector<double> &dU) const {
+    const size_t n3 = 3 * (size_t) S.N; const double t2 = S.P.h * S.P.h;
+    const auto &rows = S.rows; const auto &tris = S.tris; const auto &bends = S.bends;
+    const int T = (int) tris.size(), E = (int) bends.size();
+    std::vector<double> w, y(n3), Cw;
+    dr_df.mulT(u, w);
+    for (size_t k = 0; k < n3; k++) y[k] = w[k] + u[k];
+    dU.assign(n3, 0.0);
+    for (int t = 0; t < T; t++) {
+      double q[6];
+      for (int i = 0; i < 2; i++) {
+        const Sim::Row &rw = rows[2 * (size_t) t + i];
+        for (int d = 0; d < 3; d++) { double s = 0; for (int a = 0; a < 3; a++) s += rw.c[a] * y[3 * rw.v[a] + d]; q[3 * i + d] = s; }
+      }
+      const Mat &J = Jtri[t];
+      for (int a = 0; a < 3; a++) for (int d = 0; d < 3; d++) {
+        double s = 0; for (int k = 0; k < 6; k++) s += J(k, 3 * a + d) * q[k];
+        dU[3 * tris[t].v[a] + d] += t2 * s;
+      }
+    }
+    for (int e = 0; e < E; e++) {
+      const Sim::Row &rw = rows[2 * (size_t) T + e];
+      double q[3];
+      for (int d = 0; d < 3; d++) { double s = 0; for (int a = 0; a < 4; a++) s += rw.c[a] * y[3 * rw.v[a] + d]; q[d] = s; }
+      const Mat &J = Jbend[e];
+      for (int a = 0; a < 4; a++) for (int d = 0; d < 3; d++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += J(k, 3 * a + d) * q[k];
+        dU[3 * bends[e].v[a] + d] += t2 * s;
+      }
+    }
+    S.mulS(S.Cval, w, Cw);
+    for (size_t k = 0; k < n3; k++) dU[k] -= Cw[k];
+  }
+  // K u = (P - dP^T) u, the matrix of the direct adjoint solve (Sim.cpp:1431-1440, 1589-1594)
+  void applyK(const std::vector<double> &u, std::vector<double> &out) const {
+    std::vector<double> d;
+    S.mulS(S.Pval, u, out);
+    applyDeltaPT(u, d);
+    for (size_t k = 0; k < out.size(); k++) out[k] -= d[k];
+  }
+};
+}  // namespace
+
 // Simulation::stepBackward Sim.cpp:1455-1780 (+ calculatedr_df Sim.cpp:686-768, calculatedr_dmu :770-804,
 // solveDirect :1431-1440).  The SparseLU fallback is replaced by GMRES on (P - dP^T) preconditioned with the
 // Cholesky factor of P, run to 1e-13 — same linear system, same solution.
@@ -885,66 +970,9 @@ BackwardOut Sim::stepBackward(const Record &rec, const double *dL_dxnew_in, cons
     nrm = std::sqrt(nrm);
     if (nrm > P.gradientClippingThreshold * N) for (double &v : g) v = v * P.gradientClippingThreshold * N / nrm;
   }
-  // --- dr_df (Sim.cpp:686-768) ---
-  BlockRows dr_df(N);
-  if (P.contactEnabled) {
-    for (const PrimContact &info : rec.prim)
-      if (info.primitiveId != -1) dr_df.add(info.particleId, info.particleId, dri_dfi(info.normal, info.d, prims[info.primitiveId].mu));
-    if (P.selfcollisionEnabled)
-      for (const auto &layer : rec.layers) {
-        BlockRows last = dr_df;
-        for (const SelfContact &info : layer) {
-          int nA = info.particleId1, nB = info.particleId2;
-          double mA = mass[nA], mB = mass[nB], k = (mA * mB) / (mA + mB);
-          M3 dr_dd = dri_dfi(info.normal, info.d, 0.1);
-          M3 dA, dB;
-          for (int q = 0; q < 9; q++) { dA[q] = k * dr_dd[q] / mA; dB[q] = -k * dr_dd[q] / mB; }
-          dr_df.add(nA, nA, dA); dr_df.add(nA, nB, dB);
-          dr_df.add(nB, nA, dA, -1.0); dr_df.add(nB, nB, dB, -1.0);
-          for (auto &kv : last.rows[nA]) { M3 m = mul33(dA, kv.second); dr_df.add(nA, kv.first, m); dr_df.add(nB, kv.first, m, -1.0); }
-          for (auto &kv : last.rows[nB]) { M3 m = mul33(dB, kv.second); dr_df.add(nA, kv.first, m); dr_df.add(nB, kv.first, m, -1.0); }
-        }
-      }
-  }
-  // --- projection Jacobians at x_new (Sim.cpp:1540-1551) ---
-  const int T = (int) tris.size(), E = (int) bends.size();
-  std::vector<Mat> Jtri(T), Jbend(E);
-#pragma omp parallel for schedule(static)
-  for (int t = 0; t < T; t++) Jtri[t] = triProjectBackward(tris[t], rec.x.data()) * tris[t].w;
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; e++) Jbend[e] = bendBackward(bends[e], rec.x.data());
-
-  // deltaU(u) = t2 * dproj^T * A * (dr_df^T u + u) - C^T (dr_df^T u)   (Sim.cpp:1573-1575)
-  auto applyDeltaPT = [&](const std::vector<double> &u, std::vector<double> &dU) {
-    std::vector<double> w, y(n3), Cw;
-    dr_df.mulT(u, w);
-    for (size_t k = 0; k < n3; k++) y[k] = w[k] + u[k];
-    dU.assign(n3, 0.0);
-    for (int t = 0; t < T; t++) {
-      double q[6];
-      for (int i = 0; i < 2; i++) {
-        const Row &rw = rows[2 * (size_t) t + i];
-        for (int d = 0; d < 3; d++) { double s = 0; for (int a = 0; a < 3; a++) s += rw.c[a] * y[3 * rw.v[a] + d]; q[3 * i + d] = s; }
-      }
-      const Mat &J = Jtri[t];
-      for (int a = 0; a < 3; a++) for (int d = 0; d < 3; d++) {
-        double s = 0; for (int k = 0; k < 6; k++) s += J(k, 3 * a + d) * q[k];
-        dU[3 * tris[t].v[a] + d] += t2 * s;
-      }
-    }
-    for (int e = 0; e < E; e++) {
-      const Row &rw = rows[2 * (size_t) T + e];
-      double q[3];
-      for (int d = 0; d < 3; d++) { double s = 0; for (int a = 0; a < 4; a++) s += rw.c[a] * y[3 * rw.v[a] + d]; q[d] = s; }
-      const Mat &J = Jbend[e];
-      for (int a = 0; a < 4; a++) for (int d = 0; d < 3; d++) {
-        double s = 0; for (int k = 0; k < 3; k++) s += J(k, 3 * a + d) * q[k];
-        dU[3 * bends[e].v[a] + d] += t2 * s;
-      }
-    }
-    mulS(Cval, w, Cw);
-    for (size_t k = 0; k < n3; k++) dU[k] -= Cw[k];
-  };
+  AdjointSystem sys(*this, rec);
+  const BlockRows &dr_df = sys.dr_df;
+  auto applyDeltaPT = [&](const std::vector<double> &u, std::vector<double> &dU) { sys.applyDeltaPT(u, dU); };
 
   std::vector<double> u(n3, 0.0), u_prev(n3, 0.0), dU, rhs(n3);
   auto solveDirect = [&]() {   // (P - dP^T) u = g  via right-preconditioned restarted GMRES
@@ -1098,6 +1126,26 @@ BackwardOut Sim::stepBackward(const Record &rec, const double *dL_dxnew_in, cons
     out.dL_dwind[4] = tot.dot(windForce) * c * 0.5;
   }
   return out;
+}
+
+// Diagnostic (tests/proto_*.py): the matrix K = P - dP^T of the direct adjoint solve of one record, column by column
+// (K e_j), as CSC triplets; entries below `drop` in magnitude are omitted.
+void Sim::adjointMatrix(const Record &rec, std::vector<int> &colptr, std::vector<int> &rowidx, std::vector<double> &val, double drop) const {
+  AdjointSystem sys(*this, rec);
+  const int n3 = 3 * N;
+  std::vector<std::vector<std::pair<int, double>>> cols(n3);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int j = 0; j < n3; j++) {
+    std::vector<double> e(n3, 0.0), out;
+    e[j] = 1.0;
+    sys.applyK(e, out);
+    for (int i = 0; i < n3; i++) if (std::fabs(out[i]) > drop) cols[j].emplace_back(i, out[i]);
+  }
+  colptr.assign(n3 + 1, 0); rowidx.clear(); val.clear();
+  for (int j = 0; j < n3; j++) {
+    for (auto &kv : cols[j]) { rowidx.push_back(kv.first); val.push_back(kv.second); }
+    colptr[j + 1] = (int) rowidx.size();
+  }
 }
 
 }  // namespace orc

@@ -157,6 +157,8 @@ struct Sim {
   BackwardOut stepBackward(const Record &rec, const double *dL_dxnew, const double *dL_dvnew,
                            const double *dL_dxinit, const double *dL_dvinit, bool isStart, bool forceDirect,
                            int numMu) const;
+  // diagnostic: K = P - dP^T of the direct adjoint solve of a record as CSC (tests/proto_adjoint.py)
+  void adjointMatrix(const Record &rec, std::vector<int> &colptr, std::vector<int> &rowidx, std::vector<double> &val, double drop) const;
 };
 
 }  // namespace orc

@@ -214,6 +214,19 @@ class Oracle:
                     converged=bool(info[0]), iters=int(info[1]),
                     used_direct=bool(info[2]))
 
+    def adjoint_matrix(self, rid):
+        """K = P - dP^T of the direct adjoint solve of record `rid` (3N x 3N, xyz-interleaved) as a scipy CSC matrix — diagnostic
+        for the solver prototypes (tests/proto_adjoint.py)."""
+        import scipy.sparse as sp
+        n3 = 3 * self.N
+        self._push_params()
+        colptr = i32(np.zeros(n3 + 1))
+        self.L.orc_adjoint_matrix.restype = C.c_int
+        nnz = self.L.orc_adjoint_matrix(self.h, C.c_int(rid), _i(colptr), None, None)
+        rows = i32(np.zeros(nnz)); vals = f64(np.zeros(nnz))
+        self.L.orc_adjoint_matrix(self.h, C.c_int(rid), _i(colptr), _i(rows), _d(vals))
+        return sp.csc_matrix((vals, rows, colptr), shape=(n3, n3))
+
     def detect(self, x, v):
         a = C.c_int(); b = C.c_int(); c = C.c_int()
         self.L.orc_detect(self.h, _d(f64(x)), _d(f64(v)), C.byref(a), C.byref(b), C.byref(c))
