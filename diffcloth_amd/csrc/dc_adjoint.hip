@@ -362,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   if (step > 0) {
     __syncthreads();
     A.x_new -= A.slot_state; A.rec_f -= A.slot_state; A.rec_n -= A.slot_state; A.rec_prim -= A.slot_prim;
-    A.x_prev -= A.slot_state; A.v_prev -= A.slot_state;
+    A.x_prev -= A.slot_state; A.v_prev -= A.slot_state; A.v_new -= A.slot_state;
     A.self.pair -= A.slot_self; A.self.nrm -= A.slot_self; A.self.dvec -= A.slot_self; A.self.meta -= A.slot_meta; A.self.verts -= 2 * A.slot_self;
     if (A.d_param) A.d_param -= A.slot_param;
     A.x_fixed -= A.slot_xf; A.stats -= A.slot_stats;
@@ -459,6 +459,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   // fp64 side (dc_adjoint64.h): true residual of the mixed-precision refinement, fall-back solve, gradient assembly
   TeamOne<THREADS> tm{N, red};
   Adj64 C64;
+  C64.xprev = A.x_prev + off; C64.vnew = A.v_new + off;
   C64.xnew = C.xnew; C64.rec_f = C.rec_f; C64.rec_n = C.rec_n; C64.mu = C.mu; C64.rec_prim = C.rec_prim;
   C64.self = C.self; C64.nself = C.nself; C64.b = b; C64.lds = dyn_lds; C64.lds_floats = C.lds_floats;
   Work64 W64;

@@ -17,11 +17,12 @@
 #include "dc_devlib.h"
 #include "dc_adjprecond.h"
 
-// Out-of-line by default (see the note at Ret64); -DDC_ADJ_INLINE inlines them again (A/B builds)
-#ifdef DC_ADJ_INLINE
-#define DC_OUTLINED __forceinline__
-#else
+// Inlined by default: out of line (-DDC_ADJ_OUTLINE, A/B builds) the fp32 correction solve pays the call ABI — measured r03a on the
+// 10k-vertex workload: 45.8 ms per fwd+bwd batch step out of line against 35.6 ms inlined.
+#ifdef DC_ADJ_OUTLINE
 #define DC_OUTLINED __attribute__((noinline))
+#else
+#define DC_OUTLINED __forceinline__
 #endif
 
 namespace dc {
@@ -49,6 +50,7 @@ struct Work64 {
 // what the fp64 operator reads of the step being differentiated
 struct Adj64 {
   const float *xnew, *rec_f, *rec_n, *mu;
+  const float *xprev, *vnew;                // state the step started from, velocity it ended with (tape slots k - 1 and k)
   const int *rec_prim;
   SelfRec self;
   int nself, b;
@@ -150,6 +152,18 @@ __device__ __forceinline__ d3 contact_JT_d(const DevSystem &S, const Adj64 &C, i
   return dri_dfi_T_d(n, d, C.mu[S.prims[prim].group], z);
 }
 
+// x_new of vertex i in fp64. The tape holds fl32(x_prev + h v_new) (the forward kernels' final update): positions of magnitude 2..8
+// carry 1.2e-7..4.8e-7 of storage rounding, which alone moves the gradient of a stiff scene by 2e-5..6e-5 (measured on the hat with
+// the fp64 oracle's own record rounded to fp32, tests/analyze_dump.py) — the unrounded sum is rebuilt from its fp32 terms. A state
+// that is not that sum (a step that hit the iteration cap and reverted, Simulation.cpp:1357-1367) is taken as stored.
+__device__ __forceinline__ d3 xnew64(const DevSystem &S, const Adj64 &C, int i) {
+  const int N = S.N;
+  const d3 xs = tod(ld3(C.xnew, i, N));
+  const d3 xh = tod(ld3(C.xprev, i, N)) + tod(ld3(C.vnew, i, N)) * S.h64;
+  auto pick = [](double s, double h) { return fabs(h - s) <= 2.4e-7 * fmax(fabs(s), 1e-3) ? h : s; };
+  return mkd(pick(xs.x, xh.x), pick(xs.y, xh.y), pick(xs.z, xh.z));
+}
+
 // ---- layered self contacts, transposed (calculatedr_df, Simulation.cpp:713-760): z <- (I + J_0)^T ... (I + J_L)^T z in fp64 ----
 // One workgroup (the Team's leader) runs it; `z` is the rollout's y through the Team's access path. In LDS when the working set
 // fits (one wave walks the layers, see self_JT_layers_lds_v in dc_devlib.h), else through global memory with a barrier per layer.
@@ -246,7 +260,7 @@ __device__ __forceinline__ bool form_y64(const DevSystem &S, const Adj64 &C, Tea
 // (Triangle::projectToManifoldBackward Triangle.cpp:354-451 in closed form, TriangleBending::backwardGradient
 // TriangleBending.cpp:154-172), y read through the Team's access path, x_new from the fp32 tape.
 template <class YV>
-__device__ __forceinline__ d3 element_terms64(const DevSystem &S, const float *__restrict__ xnew, const YV &Y, int i) {
+__device__ __forceinline__ d3 element_terms64(const DevSystem &S, const Adj64 &C, const YV &Y, int i) {
   const int N = S.N, T = S.T, E = S.E;
   const double h2 = S.h64 * S.h64;
   d3 acc = mkd(0, 0, 0);
@@ -257,8 +271,8 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const float *_
       const int corner = idx / T, t = idx - corner * T;
       const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
       const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
-      const d3 x0 = tod(ld3(xnew, i0, N));
-      const d3 e0 = tod(ld3(xnew, i1, N)) - x0, e1 = tod(ld3(xnew, i2, N)) - x0;
+      const d3 x0 = xnew64(S, C, i0);
+      const d3 e0 = xnew64(S, C, i1) - x0, e1 = xnew64(S, C, i2) - x0;
       const PolarD P = polar3x2d(e0 * Dx + e1 * Dz, e0 * Dy + e1 * Dw);
       const d3 q0 = ld3y(Y, i0, N);
       const d3 d0 = ld3y(Y, i1, N) - q0, d1 = ld3y(Y, i2, N) - q0;
@@ -280,8 +294,8 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const float *_
       const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
       d3 res = ey;
       if (nrest > 1e-6) {
-        const d3 x0 = tod(ld3(xnew, i0, N));
-        const d3 ev = (tod(ld3(xnew, i1, N)) - x0) * w1 + (tod(ld3(xnew, i2, N)) - x0) * w2 + (tod(ld3(xnew, i3, N)) - x0) * w3;
+        const d3 x0 = xnew64(S, C, i0);
+        const d3 ev = (xnew64(S, C, i1) - x0) * w1 + (xnew64(S, C, i2) - x0) * w2 + (xnew64(S, C, i3) - x0) * w3;
         const double en = sqrt(dot(ev, ev));
         const d3 eh = ev * (1.0 / en);
         res = ey - (ey - eh * dot(eh, ey)) * (nrest / en);
@@ -303,7 +317,7 @@ __device__ __forceinline__ bool apply_K64(const DevSystem &S, const Adj64 &C, Te
   const auto Y = tm.yv(y);
   const double hk = S.h64 * S.h64 * S.k_att64;
   for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) {
-    d3 o = ld3d(z, i, N) * S.mass64[i] + element_terms64(S, C.xnew, Y, i);
+    d3 o = ld3d(z, i, N) * S.mass64[i] + element_terms64(S, C, Y, i);
     if (S.att_of_vertex[i] >= 0) o = o + ld3y(Y, i, N) * hk;       // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
     vert(i, o);
   }
@@ -441,13 +455,12 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
   double pacc[7] = {0, 0, 0, 0, 0, 0, 0};
   if (A.d_param) {
     const int T = S.T, E = S.E, K = tm.parts(), part = tm.part();
-    const float *xnew = C.xnew;
     const int t0 = (int) ((long long) T * part / K), t1 = (int) ((long long) T * (part + 1) / K);
     for (int t = t0 + tid; t < t1; t += THREADS) {
       const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
       const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
-      const d3 x0 = tod(ld3(xnew, i0, N));
-      const d3 e0 = tod(ld3(xnew, i1, N)) - x0, e1 = tod(ld3(xnew, i2, N)) - x0;
+      const d3 x0 = xnew64(S, C, i0);
+      const d3 e0 = xnew64(S, C, i1) - x0, e1 = xnew64(S, C, i2) - x0;
       const d3 f0 = e0 * Dx + e1 * Dz, f1 = e0 * Dy + e1 * Dw;
       const PolarD P = polar3x2d(f0, f1);
       const double w2 = S.tri_w2_64[t];
@@ -461,8 +474,8 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
       const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
       const double w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
       const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
-      const d3 x0 = tod(ld3(xnew, i0, N));
-      const d3 ev = (tod(ld3(xnew, i1, N)) - x0) * w1 + (tod(ld3(xnew, i2, N)) - x0) * w2 + (tod(ld3(xnew, i3, N)) - x0) * w3;
+      const d3 x0 = xnew64(S, C, i0);
+      const d3 ev = (xnew64(S, C, i1) - x0) * w1 + (xnew64(S, C, i2) - x0) * w2 + (xnew64(S, C, i3) - x0) * w3;
       d3 p = mkd(0, 0, 0);
       if (nrest > 1e-6) { const double n2 = dot(ev, ev); p = n2 > 0 ? ev * (nrest / sqrt(n2)) : ev * nrest; }
       const d3 q0 = ld3y(Y, i0, N);
@@ -480,10 +493,10 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
     const double m = S.mass64[i];
     if (A.d_param) {
       const int a = S.att_of_vertex[i];
-      if (a >= 0) pacc[2] += S.k_att64 * dot(tod(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af)) - tod(ld3(C.xnew, i, N)), yi);
+      if (a >= 0) pacc[2] += S.k_att64 * dot(tod(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af)) - xnew64(S, C, i), yi);
       const double ar = m / S.density64;
       const d3 xp = tod(ld3(A.x_prev + off, i, N)), vp = tod(ld3(A.v_prev + off, i, N));
-      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - tod(ld3(C.xnew, i, N))) + h * dot(w, vp + grav * h));
+      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - xnew64(S, C, i)) + h * dot(w, vp + grav * h));
       pacc[4] += h2 * yi.x; pacc[5] += h2 * yi.y; pacc[6] += h2 * yi.z;
     }
     const int prim = C.rec_prim[i];

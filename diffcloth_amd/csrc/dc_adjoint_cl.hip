@@ -14,11 +14,44 @@
 #include "dc_winlib.h"
 #include "dc_cluster.h"
 #include "dc_adjprecond.h"
+#include "dc_adjoint64.h"
 #include <algorithm>
 
 namespace dc {
 
-constexpr int kCycles = 1;      // BiCGSTAB cycles of the direct adjoint solve (see the comment at the loop)
+constexpr int kMaxRefine = 6;          // fp32 correction solves of the mixed-precision direct adjoint solve before the fp64 fall-back
+constexpr double kInnerFloor = 1e-3;   // (dc_adjoint.hip)
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+// The parts of one rollout as a Team of dc_adjoint64.h: row range of this part, barriers and sums through the granule exchange
+// (partial sums travel as fp32: 1e-7 relative on a Krylov scalar or a residual norm), y through sc1 accesses.
+template <int THREADS>
+struct TeamParts {
+  Xch X;
+  int N, part_, K_, r0_, r1_;
+  __device__ __forceinline__ int r0() const { return r0_; }
+  __device__ __forceinline__ int r1() const { return r1_; }
+  __device__ __forceinline__ bool leader() const { return part_ == 0; }
+  __device__ __forceinline__ int part() const { return part_; }
+  __device__ __forceinline__ int parts() const { return K_; }
+  __device__ __forceinline__ bool barrier() { return xch_barrier<THREADS>(X); }
+  __device__ __forceinline__ bool sum3(double a, double b, double c, double (&s)[3]) { return xch_allsum<THREADS>(X, (float) a, (float) b, (float) c, s); }
+  struct YV {
+    __amdgpu_buffer_rsrc_t rs;
+    bool same;
+    __device__ __forceinline__ double ld(int idx) const {
+      const v2i q = __builtin_amdgcn_raw_buffer_load_b64(rs, idx * 8, 0, 16);
+      return __hiloint2double(q.y, q.x);
+    }
+    __device__ __forceinline__ void st(int idx, double v) const {
+      const v2i q = {__double2loint(v), __double2hiint(v)};
+      if (same) __builtin_amdgcn_raw_buffer_store_b64(q, rs, idx * 8, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b64(q, rs, idx * 8, 0, 16);
+    }
+  };
+  __device__ __forceinline__ YV yv(double *y) const { return YV{__builtin_amdgcn_make_buffer_rsrc((void *) y, 0, 3 * N * 8, 0x00020000), X.same_xcd}; }
+};
 
 namespace {
 
@@ -128,7 +161,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   if (step > 0) {
     __syncthreads();
     A.x_new -= A.slot_state; A.rec_f -= A.slot_state; A.rec_n -= A.slot_state; A.rec_prim -= A.slot_prim;
-    A.x_prev -= A.slot_state; A.v_prev -= A.slot_state;
+    A.x_prev -= A.slot_state; A.v_prev -= A.slot_state; A.v_new -= A.slot_state;
     A.self.pair -= A.slot_self; A.self.nrm -= A.slot_self; A.self.dvec -= A.slot_self; A.self.meta -= A.slot_meta; A.self.verts -= 2 * A.slot_self;
     if (A.d_param) A.d_param -= A.slot_param;
     A.x_fixed -= A.slot_xf; A.stats -= A.slot_stats;
@@ -146,7 +179,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   C.self = A.self; C.b = b; C.part = part; C.r0 = r0; C.r1 = r1; C.R = R; C.HB = HB;
   C.w0 = part * CL.wpp; C.w1 = min(CL.nwin, C.w0 + CL.wpp);
   C.nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;
-  float *gx = A.gx + off, *gv = A.gv + off;
+  float *gx = A.gx + off;
   float *gin = W.g + off, *u = W.vnow + off;
   float *r = W.cg_r + off, *p = W.cg_p + off, *v = W.cg_ap + off, *t = W.cg_x + off, *rhat = W.sd_sx + off;   // (detection scratch, idle here)
   float *ph = W.pre_p + off, *sh = W.pre_s + off, *minv = W.minv + (size_t) b * 9 * N;   // M^-1 p, M^-1 s, the block inverses
@@ -157,7 +190,6 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   // BLK: M^-1 = those block inverses, the vectors M^-1 p / M^-1 s are stored and are what the operator is applied to;
   // otherwise M^-1 = diag(P)^-1, applied inside the operator
   auto pre = [&](int i, f3 z) { return BLK ? block_pre(minv, i, N, z) : z; };
-  const float h = S.h, h2 = S.h * S.h;
 
   // ---- gradient clipping (Simulation.cpp:1460-1466), u = 0, r = rhat = p = g ----
   float part_s = 0.f;
@@ -171,33 +203,31 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   int iters = 0;
   double udiff = 0;
   for (int i = r0 + tid; i < r1; i += THREADS) { st3(gin, i, N, ld3(gx, i, N) * gscale); st3(u, i, N, mk(0, 0, 0)); }
-  double rr = 0;
+  // fp64 side (dc_adjoint64.h): true residual of the mixed-precision refinement, fall-back solve, gradient assembly — the same
+  // code as the one-workgroup kernel, over the parts of this rollout
+  TeamParts<THREADS> tm{X, N, part, K, r0, r1};
+  Adj64 C64;
+  C64.xprev = A.x_prev + off; C64.vnew = A.v_new + off;
+  C64.xnew = C.xnew; C64.rec_f = C.rec_f; C64.rec_n = C.rec_n; C64.mu = C.mu; C64.rec_prim = C.rec_prim;
+  C64.self = C.self; C64.nself = C.nself; C64.b = b; C64.lds = dyn_lds; C64.lds_floats = hc_off;
+  Work64 W64;
+  W64.u = W.u64 + off; W64.r = W.r64 + off; W64.y = W.y64 + off;
+  W64.rhat = W.k64[0] + off; W64.p = W.k64[1] + off; W64.v = W.k64[2] + off; W64.t = W.k64[3] + off; W64.ph = W.k64[4] + off; W64.sh = W.k64[5] + off;
+  int cycles = 0, iters64 = 0;
+  for (int i = r0 + tid; i < r1; i += THREADS) st3d(W64.u, i, N, mkd(0, 0, 0));
+  double rr_true = gnorm * gnorm;
   if (gnorm > 0) {
+    // ---- direct solve of K u = g in mixed precision (see dc_adjoint.hip): fp32 BiCGSTAB for corrections of the fp64 residual ----
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
     const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
     constexpr int VB = 4;
-    // kCycles > 1: when the recurrence residual says "converged", recompute g - K u and restart from u if that is not below the
-    // tolerance. Measured on the C4 workload (r02m): +4 iterations of 41, gradient error against the fp64 oracle unchanged to three
-    // digits (7.31e-5 -> 7.31e-5) — the fp32 floor of this solve is eps * cond(K) in the operator's coefficients, not residual
-    // drift — so one cycle is the default.
-    for (int cycle = 0, kdone = 0; cycle < kCycles; cycle++) {
-    // r = rhat = p = g - K u (u = 0 in the first cycle: K u = 0 without applying the operator)
-    if (cycle > 0) {
-      // u travels as the operator's input: its boundary rows first
-      xch_begin(X);
-      for (int l = tid; l < R; l += THREADS) {
-        const int i = r0 + l;
-        f3 q = i < N ? ld3(u, i, N) : mk(0, 0, 0);
-        xch_publish_boundary(X, l, R, q.x, q.y, q.z);
-      }
-      xch_publish_sums(X, 0.f, 0.f, 0.f);
-      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
-      halo_to_cache<THREADS, HPT>(C, hv);
-      __syncthreads();
-      float e1, e2;
-      if (!adjoint_operator_cl<THREADS>(S, CL, C, X, u, false, v, nullptr, e1, e2)) return;
-      __syncthreads();
-    }
+    bool fallback = false;
+    double rr = rr_true;
+    status = (rr_true <= stop) ? 1 : 0;
+    for (int kdone = 0; status == 0 && !fallback; cycles++) {
+    const double rel_now = sqrt(rr_true) / gnorm;
+    const double in_tol = A.fp32_only ? (double) A.rel_tol : fmax(0.3 * (double) A.rel_tol / rel_now, kInnerFloor);
+    // r = rhat = p = rhs (gin: g, later the fp64 residual rounded to fp32), d = 0; the operator's input travels to the neighbours
     xch_begin(X);
     part_s = 0.f;
     for (int l = tid; l < R; l += THREADS) {
@@ -205,8 +235,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       f3 q = mk(0, 0, 0);
       if (i < N) {
         q = ld3(gin, i, N);
-        if (cycle > 0) q = q - ld3(v, i, N);
-        st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q);
+        st3(r, i, N, q); st3(rhat, i, N, q); st3(p, i, N, q); st3(u, i, N, mk(0, 0, 0));
         part_s += dot(q, q);
         if constexpr (BLK) { q = pre(i, q); st3(ph, i, N, q); }
       }
@@ -218,18 +247,17 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     __syncthreads();
     double rho = sums[0];
     rr = rho;
+    const double in_stop = in_tol * in_tol * rho;
     double best_rr = rr;
     int since_progress = 0;
-    status = (rr <= stop) ? 1 : 0;
-    if (status == 0 && cycle > 0 && cycle == kCycles - 1) status = 2;      // still above the tolerance after two restarts: the fp32 floor of this system
-    if (status != 0) break;
-    for (int k = kdone; k < kcap && status == 0; k++, kdone++) {
+    int in_status = (rr <= in_stop || !(rr > 0)) ? 1 : 0;
+    for (int k = kdone; k < kcap && in_status == 0; k++, kdone++) {
       float d1, d2;
       // v = K M^-1 p ;  alpha = rho / (rhat . v)
       if (!adjoint_operator_cl<THREADS>(S, CL, C, X, BLK ? ph : p, !BLK, v, rhat, d1, d2)) return;
       if (!xch_allsum<THREADS>(X, d1, 0.f, 0.f, sums)) return;
       const double rv = sums[0];
-      if (!(fabs(rv) > 1e-300)) { status = 2; break; }
+      if (!(fabs(rv) > 1e-300)) { in_status = 2; break; }
       const float alpha = (float) (rho / rv);
       // s = r - alpha v  (in place), its boundary rows to the neighbours
       xch_begin(X);
@@ -255,17 +283,17 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       }
       const double ss = sums[0];
       iters++;
-      if (ss <= stop) {
+      if (ss <= in_stop) {
         for (int i = r0 + tid; i < r1; i += THREADS) st3(u, i, N, ld3(u, i, N) + (BLK ? ld3(ph, i, N) * alpha : ld3(p, i, N) * (alpha * S.dinv[i])));
-        rr = ss; status = 1; break;
+        rr = ss; in_status = 1; break;
       }
       // t = K M^-1 s ;  omega = (t . s) / (t . t)
       if (!adjoint_operator_cl<THREADS>(S, CL, C, X, BLK ? sh : r, !BLK, t, r, d1, d2)) return;
       if (!xch_allsum<THREADS>(X, d1, d2, 0.f, sums)) return;
       const double ts = sums[0], tt = sums[1];
-      if (!(tt > 1e-300)) { status = 2; break; }
+      if (!(tt > 1e-300)) { in_status = 2; break; }
       const float omega = (float) (ts / tt);
-      // u += alpha D^-1 p + omega D^-1 s ;  r = s - omega t ;  rho_new = rhat . r
+      // d += alpha D^-1 p + omega D^-1 s ;  r = s - omega t ;  rho_new = rhat . r
       float pa = 0.f, pb = 0.f;
       for (int l0 = tid; l0 < R; l0 += VB * THREADS) {
         f3 sq[VB], uq[VB], pq[VB], tq[VB], hq[VB], zq[VB];
@@ -291,10 +319,10 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       if (!xch_allsum<THREADS>(X, pa, pb, 0.f, sums)) return;
       const double rho_new = sums[0];
       rr = sums[1];
-      if (rr <= stop) { status = 1; break; }
+      if (rr <= in_stop) { in_status = 1; break; }
       if (rr < best_rr) { best_rr = rr; since_progress = 0; }
-      else if (++since_progress >= A.stall_window) { status = 2; break; }
-      if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { status = 2; break; }
+      else if (++since_progress >= A.stall_window) { in_status = 2; break; }
+      if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { in_status = 2; break; }
       const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));
       rho = rho_new;
       // p = r + beta (p - omega v), its boundary rows to the neighbours
@@ -317,129 +345,77 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       halo_to_cache<THREADS, HPT>(C, hv);
       __syncthreads();
     }
-    if (status != 1) break;       // cap, breakdown or stall: no further cycle
     __syncthreads();
+    // u += d (fp64)
+    for (int i = r0 + tid; i < r1; i += THREADS) st3d(W64.u, i, N, ld3d(W64.u, i, N) + tod(ld3(u, i, N)));
+    __syncthreads();
+    if (A.fp32_only) {      // round-2 behaviour: the recurrence residual is all there is
+      status = in_status;
+      if (status == 2 && rr > 1e4 * stop) status = 0;
+      rr_true = rr;
+      cycles++;
+      break;
+    }
+    // the true residual, in fp64
+    tm.X = X;
+    auto rs = residual64<THREADS>(S, C64, tm, W64, gx, gscale);
+    tm = rs.tm; X = tm.X;
+    if (rs.res < 0) return;
+    double rr_new = rs.rr;
+    if (rr_new <= stop) { rr_true = rr_new; status = 1; cycles++; break; }
+    if (!(rr_new < rr_true)) {      // a diverged correction (NaN-safe): take it back
+      for (int i = r0 + tid; i < r1; i += THREADS) st3d(W64.u, i, N, ld3d(W64.u, i, N) - tod(ld3(u, i, N)));
+      __syncthreads();
+      rs = residual64<THREADS>(S, C64, tm, W64, gx, gscale);
+      tm = rs.tm; X = tm.X;
+      if (rs.res < 0) return;
+      rr_new = rs.rr;
+    }
+    if (!(rr_new < 0.0625 * rr_true) || in_status != 1 || cycles + 1 >= kMaxRefine || kdone >= kcap) fallback = true;
+    rr_true = rr_new;
+    if (!fallback) {
+      for (int i = r0 + tid; i < r1; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));
+      __syncthreads();
+    }
     }   // cycle
-  }
-  // "stalled at the fp32 floor" (2) is only claimed near the tolerance: a breakdown or stall with the residual still more than 100 x
-  // above it (an adjoint system beyond an fp32 Krylov solve, e.g. a strongly compressed fine garment) is reported as NOT converged
-  if (status == 2 && rr > 1e4 * (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm) status = 0;
-  udiff = sqrt(rr) / (gnorm > 0 ? gnorm : 1.0);     // relative residual (of the last recomputed or recurrence residual)
-  __syncthreads();
-  // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650) ----
-  // y = (I + dr_df)^T u* in global memory (own rows; with self contacts the layered pass on part 0)
-  if (C.nself > 0) {
-    for (int i = r0 + tid; i < r1; i += THREADS) st3c(C.yb, i, ld3(u, i, N));
-    if (!xch_barrier<THREADS>(X)) return;
-    if (part == 0) {
-      if (!self_JT_layers_lds_v<THREADS>(S, C.self, b, C.yb, C.lds, C.lds_floats)) self_JT_layers_v<THREADS>(S, C.self, b, C.yb);
-    }
-    if (!xch_barrier<THREADS>(X)) return;
-    for (int i = r0 + tid; i < r1; i += THREADS) { f3 z = ld3c(C.yb, i); st3c(C.yb, i, z + contact_JT_cl(S, C, i, z)); }
-  } else {
-    for (int i = r0 + tid; i < r1; i += THREADS) { f3 z = ld3(u, i, N); st3c(C.yb, i, z + contact_JT_cl(S, C, i, z)); }
-  }
-  float pacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (A.d_param) {
-    // the element sums read y at arbitrary vertices: y changes hands; elements are dealt to the parts in contiguous ranges
-    if (!xch_barrier<THREADS>(X)) return;
-    const int T = S.T, E = S.E;
-    const float *xnew = C.xnew;
-    const BufVec &yv = C.yb;
-    const int t0 = (int) ((long long) T * part / K), t1 = (int) ((long long) T * (part + 1) / K);
-    for (int tt = t0 + tid; tt < t1; tt += THREADS) {
-      const int i0 = S.tri_v[tt], i1 = S.tri_v[T + tt], i2 = S.tri_v[2 * T + tt];
-      const float4 D = S.tri_D[tt];
-      f3 x0 = ld3(xnew, i0, N);
-      f3 e0 = ld3(xnew, i1, N) - x0, e1 = ld3(xnew, i2, N) - x0;
-      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
-      Polar P = polar3x2(f0, f1);
-      f3 g0 = (P.t0 - f0) * S.tri_w2[tt], g1 = (P.t1 - f1) * S.tri_w2[tt];
-      f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
-      f3 q0 = ld3c(yv, i0);
-      pacc[0] += dot(c1, ld3c(yv, i1) - q0) + dot(c2, ld3c(yv, i2) - q0);
-    }
-    const int e0i = (int) ((long long) E * part / K), e1i = (int) ((long long) E * (part + 1) / K);
-    for (int e = e0i + tid; e < e1i; e += THREADS) {
-      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
-      const float4 w = S.bend_w[e];
-      const float2 nw = S.bend_nw[e];
-      f3 x0 = ld3(xnew, i0, N);
-      f3 ev = (ld3(xnew, i1, N) - x0) * w.y + (ld3(xnew, i2, N) - x0) * w.z + (ld3(xnew, i3, N) - x0) * w.w;
-      f3 pp = mk(0, 0, 0);
-      if (nw.x > 1e-6f) pp = normalized(ev) * nw.x;
-      f3 q0 = ld3c(yv, i0);
-      f3 ey = (ld3c(yv, i1) - q0) * w.y + (ld3c(yv, i2) - q0) * w.z + (ld3c(yv, i3) - q0) * w.w;
-      pacc[1] += dot((pp - ev) * nw.y, ey);
-    }
-  }
-  float dmu_part[kMaxPrims];
-#pragma unroll
-  for (int k = 0; k < kMaxPrims; k++) dmu_part[k] = 0.f;
-  float *dxf = A.d_xfixed ? A.d_xfixed + (size_t) b * 3 * S.Af : nullptr;
-  const f3 grav = mk(S.gx, S.gy, S.gz);
-  for (int i = r0 + tid; i < r1; i += THREADS) {
-    f3 ui = ld3(u, i, N);
-    const float m = S.mass[i];
-    f3 w = ld3c(C.yb, i) - ui;
-    if (A.d_param) {
-      f3 yi = ui + w;
-      const int a = S.att_of_vertex[i];
-      if (a >= 0) pacc[2] += S.k_att * dot(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af) - ld3(C.xnew, i, N), yi);
-      const float ar = m / S.density;
-      f3 xp = ld3(A.x_prev + off, i, N), vp = ld3(A.v_prev + off, i, N);
-      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - ld3(C.xnew, i, N)) + h * dot(w, vp + grav * h));
-      pacc[4] += h2 * yi.x; pacc[5] += h2 * yi.y; pacc[6] += h2 * yi.z;
-    }
-    const int prim = C.rec_prim[i];
-    if (prim >= 0) {
-      f3 n = ld3(C.rec_n, i, N);
-      f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * m;
-      const int grp = S.prims[prim].group;
-      const float contrib = dot(dri_dmu(n, d, C.mu[grp]), ui) * h;
-#pragma unroll
-      for (int k = 0; k < kMaxPrims; k++) dmu_part[k] += (k == grp) ? contrib : 0.f;
-    }
-    f3 dx = ui * m - ld3(gv, i, N) * (1.0f / h);
-    f3 dv = (ui + w) * (h * m);
-    if (A.ix) dx = dx + ld3(A.ix + off, i, N);
-    if (A.iv) dv = dv + ld3(A.iv + off, i, N);
-    if (!A.is_start) dx = dx + dv * (1.0f / h);
-    st3(gx, i, N, dx);
-    st3(gv, i, N, dv);
-    const int a = S.att_of_vertex[i];
-    if (a >= 0 && dxf) st3(dxf, a, S.Af, (ui + w) * (h2 * S.k_att));   // A_t_dp_dxfixed (Simulation.cpp:3035-3048)
-  }
-  // sums over the parts, three values per exchange
-  if (A.d_mu) {
-    for (int k0 = 0; k0 < S.ngroups; k0 += 3) {
-      float val[3];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        val[c] = 0.f;
-#pragma unroll
-        for (int k = 0; k < kMaxPrims; k++) val[c] += (k == k0 + c) ? dmu_part[k] : 0.f;
+    if (fallback) {
+      // ---- fp64 BiCGSTAB on the same operator from (u, r): the reference's SparseLU always returns a solution ----
+      if constexpr (!BLK) {
+        for (int i = r0 + tid; i < r1; i += THREADS)
+          store_block_inverse(elastic_diag_block(S, C.xnew, i), S.mass[i], [&](f3 e) { return contact_JT_cl(S, C, i, e); }, minv, i, N);
       }
-      if (!xch_allsum<THREADS>(X, val[0], val[1], val[2], sums)) return;
-      if (tid == 0 && part == 0)
-        for (int c = 0; c < 3 && k0 + c < S.ngroups; c++) A.d_mu[(size_t) b * S.ngroups + k0 + c] += (float) sums[c];
+      __syncthreads();
+      double rr64 = rr_true;
+      for (int pass = 0; pass < 3 && status == 0; pass++) {
+        tm.X = X;
+        auto r64 = bicgstab64<THREADS>(S, C64, tm, W64, minv, stop, 20000, rr64, iters64);
+        tm = r64.tm; X = tm.X;
+        if (r64.res < 0) return;
+        iters64 = r64.iters;
+        auto rc = residual64<THREADS>(S, C64, tm, W64, gx, gscale);     // the recurrence drifts over thousands of iterations: check, go again
+        tm = rc.tm; X = tm.X;
+        if (rc.res < 0) return;
+        rr64 = rc.rr;
+        if (rr64 <= stop) status = 1;
+        else if (r64.res == 0) break;
+      }
+      rr_true = rr64;
     }
   }
-  if (A.d_param) {
-    float *dp = A.d_param + (size_t) b * 8;
-    const float scale[9] = {S.k_stretch > 0.f ? h2 / S.k_stretch : 0.f, S.k_bend > 0.f ? h2 / S.k_bend : 0.f,
-                            S.k_att > 0.f ? h2 / S.k_att : 0.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < 7; k0 += 3) {
-      if (!xch_allsum<THREADS>(X, pacc[k0], k0 + 1 < 7 ? pacc[min(k0 + 1, 6)] : 0.f, k0 + 2 < 7 ? pacc[min(k0 + 2, 6)] : 0.f, sums)) return;
-      if (tid == 0 && part == 0)
-        for (int c = 0; c < 3 && k0 + c < 7; c++) dp[k0 + c] = (float) (sums[c] * scale[k0 + c]);
-    }
+  udiff = sqrt(rr_true) / (gnorm > 0 ? gnorm : 1.0);     // relative residual: fp64-evaluated (mixed precision) or the fp32 recurrence's
+  __syncthreads();
+  // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650), in fp64 from u ----
+  {
+    tm.X = X;
+    auto rf = finish_gradients64<THREADS>(S, C64, tm, W64, A, W.vbest + off);
+    tm = rf.tm; X = tm.X;
+    if (rf.res < 0) return;
   }
   if (tid == 0 && part == 0) {
     dc_bwd_stats s;
     s.converged = status; s.adjoint_iters = iters; s.cg_iters = 0; s.clipped = clipped;
     s.used_direct = 1; s.last_udiff = (float) udiff;
-    s.refine_cycles = 0; s.fp64_iters = 0;
+    s.refine_cycles = cycles; s.fp64_iters = iters64;
     A.stats[b] = s;
   }
   (void) none;

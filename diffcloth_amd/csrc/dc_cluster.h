@@ -36,6 +36,8 @@ struct DevCluster {
   const float4 DC_G *wtri_D;
   const int4 DC_G *wbend_rec;
   const float4 DC_G *wbend_w;
+  const float4 DC_G *wtri_Dlo;
+  const float4 DC_G *wbend_lo;
   const int4 DC_G *winc;
   const int DC_C *winc_ptr;
   const int DC_C *winc_n;

@@ -80,6 +80,8 @@ struct DevSystem {
   const float4 DC_G *wtri_D;
   const int4 DC_G *wbend_rec;        // per window-flap: j0 | j1 << 16, j2 | j3 << 16, bits(rest norm), bits(w^2)
   const float4 DC_G *wbend_w;
+  const float4 DC_G *wtri_Dlo;       // low-order parts of wtri_D / of the cotan weights 1..3 and the rest norm (precise record pass)
+  const float4 DC_G *wbend_lo;
   const int4 DC_G *winc;             // vertex -> (result vector, coefficient) pair packets, wave-sliced by 64-vertex chunk
   const int DC_C *winc_ptr;
   const int DC_C *winc_n;
@@ -158,6 +160,7 @@ struct FwdArgs {
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
+  int precise_record;           // packet / split kernels: re-evaluate the record's f (and r, d) of a converged step with fp64 element math
   int cg_seed;                  // packet / split kernels: first search direction of a solve = the previous PD iteration's correction
   // several consecutive steps in one launch (packet kernel only): step s uses tape slot k + s
   int nsteps, inline_detect;    // inline_detect: run the self-collision detection of every step inside the kernel
@@ -180,6 +183,7 @@ struct BwdArgs {
   float *d_param;               // [B][8] per-step parameter gradients (dk_stretch, dk_bend, dk_att, ddensity, h^2 sum y) or nullptr
   const float *x_fixed;         // [B][3][Af] fixed-point targets used by the step that produced the record
   const float *x_prev, *v_prev; // slot k-1 state [B][3][N]
+  const float *v_new;           // slot k velocity [B][3][N]
   dc_bwd_stats *stats;          // [B]
   float bwd_tol, cg_tol, clip_thr, rel_tol;
   int mode;                     // 0: reference fixed-point iteration (+ direct fallback), 1: direct Krylov solve

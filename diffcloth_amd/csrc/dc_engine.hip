@@ -192,6 +192,8 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   static const bool seed_on = !(getenv("DC_CG_SEED") && getenv("DC_CG_SEED")[0] == '0');     // development switch
   A.cg_seed = seed_on ? 1 : 0;
+  static const bool precise_on = !(getenv("DC_PRECISE_RECORD") && getenv("DC_PRECISE_RECORD")[0] == '0');     // development switch
+  A.precise_record = precise_on ? 1 : 0;
   A.nsteps = 1; A.inline_detect = 0; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
   A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   return A;
@@ -214,7 +216,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.d_xfixed = c->DXF + (size_t) c->B * 3 * c->S.Af * slot; A.d_mu = c->DMU;
   A.d_param = c->DPAR + (size_t) c->B * 8 * slot;
   A.x_fixed = c->XF + (size_t) c->B * 3 * c->S.Af * slot;
-  A.x_prev = c->X + se * (slot - 1); A.v_prev = c->V + se * (slot - 1); A.stats = c->bstats + (size_t) c->B * slot;
+  A.x_prev = c->X + se * (slot - 1); A.v_prev = c->V + se * (slot - 1); A.v_new = c->V + se * slot; A.stats = c->bstats + (size_t) c->B * slot;
   A.bwd_tol = (float) c->params.backward_tol;
   A.cg_tol = (float) (c->params.cg_rel_tol > 0 ? c->params.cg_rel_tol : 1e-4);
   A.clip_thr = (float) c->params.gradient_clipping_threshold;
@@ -308,6 +310,10 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   D.wbend_rec = (const int4 *) ip;
   if ((rc = upload_cl<float>(c, &fp, HW.bend_w))) return rc;
   D.wbend_w = (const float4 *) fp;
+  if ((rc = upload_cl<float>(c, &fp, HW.tri_Dlo))) return rc;
+  D.wtri_Dlo = (const float4 *) fp;
+  if ((rc = upload_cl<float>(c, &fp, HW.bend_lo))) return rc;
+  D.wbend_lo = (const float4 *) fp;
   if ((rc = upload_cl<int>(c, &ip, HW.inc))) return rc;
   D.winc = (const int4 *) ip;
   if ((rc = upload_cl<int>(c, &D.winc_ptr, HW.inc_ptr))) return rc;
@@ -665,6 +671,10 @@ int dc_build(dc_ctx *c) {
       S.wbend_rec = (const int4 *) ip;
       if ((rc = upload<float>(c, &fp, HW.bend_w))) return rc;
       S.wbend_w = (const float4 *) fp;
+      if ((rc = upload<float>(c, &fp, HW.tri_Dlo))) return rc;
+      S.wtri_Dlo = (const float4 *) fp;
+      if ((rc = upload<float>(c, &fp, HW.bend_lo))) return rc;
+      S.wbend_lo = (const float4 *) fp;
       if ((rc = upload<int>(c, &ip, HW.inc))) return rc;
       S.winc = (const int4 *) ip;
       if ((rc = upload<int>(c, &S.winc_ptr, HW.inc_ptr))) return rc;

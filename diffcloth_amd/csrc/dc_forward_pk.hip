@@ -403,8 +403,49 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         if (i < N) { vbest[i] = vnow[i] - ap[k][0]; vbest[N + i] = vnow[N + i] - ap[k][1]; vbest[2 * N + i] = vnow[2 * N + i] - ap[k][2]; }
       }
     }
-    if (converged) break;
+    if (converged) {
+      // the record's f belongs to the iterate this last iteration STARTED from (Simulation.cpp:1248-1249, 1310-1314): v - delta,
+      // delta still in registers; kept for the precise record pass below
+      if (A.precise_record && S.win_ok) {
+        float *vpre = W.cg_p + off;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int i = tq + k * THREADS;
+          if (i < N) { vpre[i] = vnow[i] - ap[k][0]; vpre[N + i] = vnow[N + i] - ap[k][1]; vpre[2 * N + i] = vnow[2 * N + i] - ap[k][2]; }
+        }
+      }
+      break;
+    }
     if (++since_progress >= A.stall_window) { stalled = true; break; }   // fp32 floor, see dc_forward.hip
+  }
+  // ---- precise record (dc_winlib.h: PreciseTriOp): f, r and the self-contact vectors d of a converged step once more, with fp64
+  //      element math — what stepBackward differentiates (Simulation.cpp:881-919 reads d = f - m v_out of the record) ----
+  if (converged && A.precise_record && S.win_ok) {
+    __syncthreads();
+    const float *vpre = W.cg_p + off;
+    element_windows<THREADS, true>(S, lp, StagePlanar{xn, N}, vpre, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, [&](int i, f3 fint, f3) {
+      f3 f = ld3(g, i, N) + fint;
+      const int a = S.att_of_vertex[i];
+      if (a >= 0) {   // AttachmentSpring.cpp:25-29, the difference formed in fp64
+        const f3 xf = ld3(xfix, a, S.Af), x0 = ld3(xn, i, N), v = ld3(vpre, i, N);
+        const double hk = S.h64 * S.k_att64;
+        f = f + mk((float) ((((double) xf.x - (double) x0.x) - S.h64 * (double) v.x) * hk), (float) ((((double) xf.y - (double) x0.y) - S.h64 * (double) v.y) * hk),
+                   (float) ((((double) xf.z - (double) x0.z) - S.h64 * (double) v.z) * hk));
+      }
+      f3 r = mk(0, 0, 0);
+      const int prim = rec_prim[i];
+      if (prim >= 0) {
+        const f3 n = ld3(rec_n, i, N);
+        r = dry_friction(n, f - prim_vout(S.prims[prim], n) * S.mass[i], mu[S.prims[prim].group]);
+      }
+      st3(rec_f, i, N, f);
+      st3(rec_r, i, N, r);
+    });
+    if (nself > 0) {
+      __syncthreads();
+      if (!self_friction_layers_lds<THREADS>(S, srec, b, rec_f, rec_r, lp, 3 * NP)) self_friction_layers<THREADS>(S, srec, b, rec_f, rec_r);
+    }
+    __syncthreads();
   }
   // ---- write the new state (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
   float *xo = A.x_out + off + so, *vo = A.v_out + off + so;

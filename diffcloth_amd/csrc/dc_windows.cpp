@@ -137,6 +137,7 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
       const int r[4] = {j0 | (j1 << 16), j2, fbits((float) H.tri_w2[t]), t};
       tri_rec.insert(tri_rec.end(), r, r + 4);
       for (int q = 0; q < 4; q++) tri_D.push_back((float) H.tri_D[4 * t + q]);
+      for (int q = 0; q < 4; q++) tri_Dlo.push_back((float) (H.tri_D[4 * t + q] - (double) (float) H.tri_D[4 * t + q]));
     }
     for (int k = 0; k < nbend; k++) {
       const int e = s.bends[k];
@@ -146,6 +147,8 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
                         fbits((float) H.bend_w2[e])};
       bend_rec.insert(bend_rec.end(), r, r + 4);
       for (int c = 0; c < 4; c++) bend_w.push_back((float) H.bend_w[4 * e + c]);
+      for (int c = 1; c < 4; c++) bend_lo.push_back((float) (H.bend_w[4 * e + c] - (double) (float) H.bend_w[4 * e + c]));
+      bend_lo.push_back((float) (H.bend_n[e] - (double) (float) H.bend_n[e]));
     }
     // incidence pairs of the owned vertices, in the corner order of HostSystem::inc_idx
     for (int ch = v0 / 64; ch < (v1 + 63) / 64; ch++) {

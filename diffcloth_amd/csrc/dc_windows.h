@@ -32,6 +32,9 @@ struct HostWindows {
   std::vector<float> tri_D;       // 4 floats per window-triangle: inv_deltaUV
   std::vector<int> bend_rec;      // 4 ints per window-flap: j0 | j1 << 16, j2 | j3 << 16, bits(rest norm), bits(weight^2)
   std::vector<float> bend_w;      // 4 floats per window-flap: cotan weights
+  // low-order parts (value - fl32(value)) of the fp64 rest-shape data, for the precise record pass (dc_winlib.h: PreciseTriOp /
+  // PreciseBendOp): tri_Dlo = those of inv_deltaUV; bend_lo = those of the cotan weights 1..3 and of the rest norm
+  std::vector<float> tri_Dlo, bend_lo;
   // vertex -> (result vector, coefficient) pairs, wave-sliced by 64-vertex chunk: pair-packet (s, lane) at
   // inc[inc_ptr[c] + 64 s + lane] = {q0, bits(c0), q1, bits(c1)}; inc_n[c] packets per row (a multiple of 4)
   std::vector<int> inc;

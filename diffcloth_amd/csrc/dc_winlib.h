@@ -37,7 +37,9 @@ struct In2Plain {
   int N;
   __device__ __forceinline__ f3 operator()(int i) const { return mk(v[i], v[N + i], v[2 * N + i]); }
 };
-template <int THREADS, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
+// PRECISE: the element operators also receive the low-order parts of the element's rest data (wtri_Dlo / wbend_lo) — the record
+// pass of the forward step (PreciseTriOp / PreciseBendOp below); one element per thread and round, it runs once per time step.
+template <int THREADS, bool PRECISE = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, float *lds, Stage1 stage1,
                                                   In2 in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -102,6 +104,25 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         if (e < nb) stw(L.erxy, L.erz, 2 * nt + e, res);
       }
     };
+    if constexpr (PRECISE) {
+      for (int t = tid; t < nt; t += THREADS) {
+        const int4 r = S.wtri_rec[toff + t];
+        const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y;
+        f3 r0, r1;
+        tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1),
+               ldw(L.a2xy, L.a2z, j2), S.wtri_D[toff + t], S.wtri_Dlo[toff + t], __int_as_float(r.z), r0, r1);
+        stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1);
+      }
+      for (int e = tid; e < nb; e += THREADS) {
+        const int4 r = S.wbend_rec[boff + e];
+        const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y & 0xffff, j3 = (int) ((unsigned) r.y >> 16);
+        f3 res;
+        bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3), ldw(L.a2xy, L.a2z, j0),
+                ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), S.wbend_w[boff + e], S.wbend_lo[boff + e],
+                __int_as_float(r.z), __int_as_float(r.w), res);
+        stw(L.erxy, L.erz, 2 * nt + e, res);
+      }
+    } else {
     for (int q = 0, rounds = (nt + THREADS - 1) / THREADS; q < rounds;) {      // wave-uniform control flow
       const int left = rounds - q, t0 = q * THREADS + tid;
       if (left >= 4) { tri_batch(std::integral_constant<int, 4>(), t0); q += 4; }
@@ -113,6 +134,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
       if (left >= 4) { bend_batch(std::integral_constant<int, 4>(), e0); q += 4; }
       else if (left == 3) { bend_batch(std::integral_constant<int, 3>(), e0); q += 3; }
       else { bend_batch(std::integral_constant<int, 2>(), e0); q += 2; }
+    }
     }
     __syncthreads();
     // per-vertex phase. All packets of a vertex travel in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2
@@ -166,10 +188,10 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
   }
 }
 
-template <int THREADS, class Stage1, class TriOp, class BendOp, class VertOp>
+template <int THREADS, bool PRECISE = false, class Stage1, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, Stage1 stage1,
                                                 const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
-  element_windows_t<THREADS>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
+  element_windows_t<THREADS, PRECISE>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
 }
 
 // ---- forward local step: a = x_n, b = v (current iterate); x = x_n + h v, edges formed as differences first ----
@@ -199,6 +221,47 @@ struct FwdBendOp {  // TriangleBending::project (TriangleBending.cpp:138-151)
     f3 p = mk(0, 0, 0);
     if (n > 1e-6f) p = normalized_fast(ev) * n;
     res = (p - ev) * (h * w2);
+  }
+};
+
+// ---- the same two operators with fp64 element math, for the RECORD of a converged step (f, and with it the contact vectors d the
+// adjoint differentiates): T - F and p - e are differences of nearly equal quantities (strain 1e-3..1e-2), and the fp32 evaluation
+// above carries the 6e-8 roundings of the edges, of inv_deltaUV and of F into them — 2e-5 relative in f on the 10k-vertex cloth, the
+// dominant term of the GPU-vs-oracle gradient difference there (measured by substitution, tests/analyze_dump.py). Inputs: the exact
+// fp32 edge parts (x_n differences, velocity differences), rest data as fl32 value + low-order part. Runs once per time step.
+struct PreciseTriOp {
+  double h;
+  __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float4 Dl, float w2, f3 &r0, f3 &r1) const {
+    const f3 a0 = x1 - x0, a1 = x2 - x0, b0 = v1 - v0, b1 = v2 - v0;
+    const double e0x = (double) a0.x + h * (double) b0.x, e0y = (double) a0.y + h * (double) b0.y, e0z = (double) a0.z + h * (double) b0.z;
+    const double e1x = (double) a1.x + h * (double) b1.x, e1y = (double) a1.y + h * (double) b1.y, e1z = (double) a1.z + h * (double) b1.z;
+    const double Dx = (double) D.x + (double) Dl.x, Dy = (double) D.y + (double) Dl.y, Dz = (double) D.z + (double) Dl.z, Dw = (double) D.w + (double) Dl.w;
+    const double f0x = e0x * Dx + e1x * Dz, f0y = e0y * Dx + e1y * Dz, f0z = e0z * Dx + e1z * Dz;
+    const double f1x = e0x * Dy + e1x * Dw, f1y = e0y * Dy + e1y * Dw, f1z = e0z * Dy + e1z * Dw;
+    // closest isometry T = F S^-1 in closed form (polar3x2, dc_devlib.h), fp64
+    const double a = f0x * f0x + f0y * f0y + f0z * f0z, b = f0x * f1x + f0y * f1y + f0z * f1z, c = f1x * f1x + f1y * f1y + f1z * f1z;
+    const double s = sqrt(fmax(a * c - b * b, 1e-300)), t = sqrt(a + c + 2.0 * s), inv = 1.0 / (t * s);
+    const double i00 = (c + s) * inv, i01 = -b * inv, i11 = (a + s) * inv;
+    const double sc = h * (double) w2;
+    r0 = mk((float) ((f0x * i00 + f1x * i01 - f0x) * sc), (float) ((f0y * i00 + f1y * i01 - f0y) * sc), (float) ((f0z * i00 + f1z * i01 - f0z) * sc));
+    r1 = mk((float) ((f0x * i01 + f1x * i11 - f1x) * sc), (float) ((f0y * i01 + f1y * i11 - f1y) * sc), (float) ((f0z * i01 + f1z * i11 - f1z) * sc));
+  }
+};
+struct PreciseBendOp {   // wl = low-order parts of the cotan weights 1..3 and (.w) of the rest norm
+  double h;
+  __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 x3, f3 v0, f3 v1, f3 v2, f3 v3, float4 w, float4 wl, float n, float w2, f3 &res) const {
+    const double w1 = (double) w.y + (double) wl.x, w2d = (double) w.z + (double) wl.y, w3 = (double) w.w + (double) wl.z;
+    const f3 a1 = x1 - x0, a2 = x2 - x0, a3 = x3 - x0, b1 = v1 - v0, b2 = v2 - v0, b3 = v3 - v0;
+    const double ex = ((double) a1.x + h * (double) b1.x) * w1 + ((double) a2.x + h * (double) b2.x) * w2d + ((double) a3.x + h * (double) b3.x) * w3;
+    const double ey = ((double) a1.y + h * (double) b1.y) * w1 + ((double) a2.y + h * (double) b2.y) * w2d + ((double) a3.y + h * (double) b3.y) * w3;
+    const double ez = ((double) a1.z + h * (double) b1.z) * w1 + ((double) a2.z + h * (double) b2.z) * w2d + ((double) a3.z + h * (double) b3.z) * w3;
+    double fac = -1.0;                                    // p = 0: res = -e
+    if (n > 1e-6f) {
+      const double nn = (double) n + (double) wl.w, len = sqrt(ex * ex + ey * ey + ez * ez);
+      fac = len > 0.0 ? nn / len - 1.0 : 0.0;             // p - e = e (n / |e| - 1)
+    }
+    const double sc = fac * h * (double) w2;
+    res = mk((float) (ex * sc), (float) (ey * sc), (float) (ez * sc));
   }
 };
 

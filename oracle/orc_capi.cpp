@@ -230,3 +230,20 @@ extern "C" int orc_adjoint_matrix(void *s, int id, int *colptr, int *rowidx, dou
   std::memcpy(val, va.data(), sizeof(double) * va.size());
   return (int) ri.size();
 }
+
+// Diagnostic (tests/analyze_dump.py): overwrite x (x_new) and / or f of a stored record with values recorded elsewhere (the HIP
+// path's tape) and re-derive the contact vectors d and r from f exactly as Simulation::calculateDryFrictionVector does — to tell
+// which recorded quantity a gradient difference between two implementations comes from.
+extern "C" void orc_override_record(void *s, int id, const double *x, const double *f) {
+  Sim *S = (Sim *) s; Record &rec = S->records[id];
+  if (x) rec.x.assign(x, x + rec.x.size());
+  if (f) {
+    rec.f.assign(f, f + rec.f.size());
+    S->dryFrictionVector(rec.f, rec.prim, rec.layers, rec.r);
+  }
+}
+
+// Diagnostic: let the local projections see the deformation gradient (the weighted bending vector) rounded to fp32, as an fp32
+// evaluation of F = [x1 - x0, x2 - x0] inv_deltaUV delivers it — measures what that rounding alone does to a step and its gradient.
+namespace orc { extern bool g_emulate_fp32_F, g_emulate_fp32_v; }
+extern "C" void orc_emulate_fp32_F(int on) { orc::g_emulate_fp32_F = (on & 1) != 0; orc::g_emulate_fp32_v = (on & 2) != 0; }

@@ -262,6 +262,8 @@ void Sim::mulS(const std::vector<double> &val, const std::vector<double> &x, std
 // ------------------------------------------------------------------------------------------------
 // Local projections
 // ------------------------------------------------------------------------------------------------
+bool g_emulate_fp32_v = false;   // diagnostic switch: round the velocity iterate to fp32 after every global solve
+bool g_emulate_fp32_F = false;   // diagnostic switch (orc_emulate_fp32_F): round the deformation gradient / bending vector to fp32
 
 // Triangle::project -> projectToManifold (Triangle.cpp:310-351): F = [x1-x0, x2-x0] inv_deltaUV; Gram-Schmidt
 // frame Q from F's columns; R = U V^T of the 2x2 Q^T F; returns vec(Q R) (unweighted).
@@ -269,6 +271,13 @@ void Sim::triProject(const TriRest &t, const double *x, double out[6]) const {
   V3 x0 = seg3(x, t.v[0]), x1 = seg3(x, t.v[1]), x2 = seg3(x, t.v[2]);
   V3 e0 = x1 - x0, e1 = x2 - x0;
   V3 F0 = e0 * t.D[0] + e1 * t.D[2], F1 = e0 * t.D[1] + e1 * t.D[3];
+  V3 dF0, dF1;
+  if (g_emulate_fp32_F) {   // diagnostic (tests/analyze_dump.py): the deformation gradient as an fp32 evaluation delivers it; the
+    // step then sees T(F~) - (F~ - F), i.e. the elastic term h^2 A^T (T(F~) - F~) of an fp32 evaluation of T - F
+    V3 G0 = V3((float) F0.x, (float) F0.y, (float) F0.z), G1 = V3((float) F1.x, (float) F1.y, (float) F1.z);
+    dF0 = G0 - F0; dF1 = G1 - F1;
+    F0 = G0; F1 = G1;
+  }
   V3 q0 = F0.normalized();
   V3 q1 = (F1 - q0 * F1.dot(q0)).normalized();
   double F2[4] = {q0.dot(F0), q0.dot(F1), q1.dot(F0), q1.dot(F1)};
@@ -277,6 +286,7 @@ void Sim::triProject(const TriRest &t, const double *x, double out[6]) const {
   // R = U V^T
   double R[4] = {U[0] * V[0] + U[1] * V[1], U[0] * V[2] + U[1] * V[3], U[2] * V[0] + U[3] * V[1], U[2] * V[2] + U[3] * V[3]};
   V3 n0 = q0 * R[0] + q1 * R[2], n1 = q0 * R[1] + q1 * R[3];
+  n0 = n0 - dF0; n1 = n1 - dF1;
   out[0] = n0.x; out[1] = n0.y; out[2] = n0.z; out[3] = n1.x; out[4] = n1.y; out[5] = n1.z;
 }
 
@@ -337,7 +347,9 @@ void Sim::bendProject(const BendRest &b, const double *x, double out[3]) const {
   V3 e;
   if (b.n > 1e-6) {
     for (int i = 0; i < 4; i++) e += seg3(x, b.v[i]) * b.wv[i];
-    e = e.normalized() * b.n;
+    V3 de;
+    if (g_emulate_fp32_F) { V3 g = V3((float) e.x, (float) e.y, (float) e.z); de = g - e; e = g; }
+    e = e.normalized() * b.n - de;
   }
   out[0] = e.x; out[1] = e.y; out[2] = e.z;
 }
@@ -813,6 +825,7 @@ int Sim::step(const double *x_n_in, const double *v_n_in, const double *x_fixed_
     // global step (Sim.cpp:1267-1268)
     for (size_t k = 0; k < n3; k++) rhs[k] = b_tilde[k] + r[k];
     solveP(rhs, v_new);
+    if (g_emulate_fp32_v) for (double &q : v_new) q = (double) (float) q;    // diagnostic: the iterate held in fp32
     for (size_t k = 0; k < n3; k++) x_new[k] = v_new[k] * h + x_n[k];
     // convergence (Sim.cpp:1324-1373)
     double x_diff = 0;

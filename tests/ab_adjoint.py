@@ -23,6 +23,9 @@ import scenes                     # noqa: E402
 from diffcloth_amd import capi    # noqa: E402
 
 
+DUMP = None      # --dump DIR: write the HIP path's tape of the sampled rollouts (tests/analyze_dump.py reads them on a CPU box)
+
+
 def f32(a):
     return np.asarray(a, dtype=np.float32).astype(np.float64)
 
@@ -70,11 +73,16 @@ def run_c4(fp32_only, B=256, sample=(0, 101, 255), S=2, W=5):
     o.build()
     o.set_force_extras(None, field, 1.0)
     errs = []
+    recs = [e.get_record(W + s + 1) for s in range(S)] if DUMP else None
     for b in sample:
         o.set_mu(0, float(f32(MU[b, 0])))
         o.clear_records()
         for s in range(S):
             xs, vs = states[s]
+            if DUMP:
+                np.savez_compressed(os.path.join(DUMP, f"c4_b{b}_s{s}.npz"), x0=xs[b], v0=vs[b], x1=states[s + 1][0][b], v1=states[s + 1][1][b], f=recs[s][0][b],
+                                    r=recs[s][1][b], gin_x=carried[S - 1 - s][0][b], gin_v=carried[S - 1 - s][1][b], gout_x=carried[S - s][0][b],
+                                    gout_v=carried[S - s][1][b], mu=f32(MU[b, 0]))
             ref = o.step(xs[b], vs[b])
             fs, bs = stats[s]
             gin, gout = carried[S - 1 - s], carried[S - s]
@@ -125,6 +133,11 @@ def run_hat(fp32_only, B=64, sample=(0, 17, 63)):
     t1 = time.perf_counter() - t0
     print(f"[hat] B={B} backward wall {1e3 * t1:.1f} ms (incl. transfers); bicgstab32 mean {gb['adjoint_iters'].mean():.0f} cycles mean {gb['refine_cycles'].mean():.2f} "
           f"max {gb['refine_cycles'].max()} fp64 max {gb['fp64_iters'].max()} rel res max {gb['last_udiff'].max():.1e} converged {np.bincount(gb['converged'], minlength=3)}", flush=True)
+    if DUMP:
+        x1, v1 = e.get_state(1); fr = e.get_record(1)
+        for b in sample:
+            np.savez_compressed(os.path.join(DUMP, f"hat_b{b}.npz"), x0=X0[b], v0=V0[b], xf=XF[b], x1=x1[b], v1=v1[b], f=fr[0][b], r=fr[1][b], gin_x=gx[b], gin_v=gv[b],
+                                gout_x=gb["dL_dx"][b], gout_v=gb["dL_dv"][b], gout_xf=gb["dL_dxfixed"][b], mu=mus[b, 0])
     for b in sample:
         o.set_mu(0, float(mus[b, 0]))
         ref = o.step(X0[b], V0[b], XF[b])
@@ -165,6 +178,10 @@ def run_dress7k(fp32_only, mesh="dress7k"):
     e.sync(); t0 = time.perf_counter()
     gb = e.step_backward(1, gx, gv, is_start=False)
     t1 = time.perf_counter() - t0
+    if DUMP:
+        fr = e.get_record(1)
+        np.savez_compressed(os.path.join(DUMP, f"{mesh}.npz"), x0=x0[0], v0=v0[0], xf=xf[0], x1=x1[0], v1=v1[0], f=fr[0][0], r=fr[1][0], gin_x=gx[0], gin_v=gv[0],
+                            gout_x=gb["dL_dx"][0], gout_v=gb["dL_dv"][0], gout_xf=gb["dL_dxfixed"][0])
     rb = o.step_backward(ref["id"], gx[0], gv[0], is_start=False, direct=True)
     print(f"[{mesh}] backward wall {t1:.2f} s | {bstat(gb, 0)} | grad rel err dx {rel(gb['dL_dx'][0], rb['dL_dx']):.2e} dv {rel(gb['dL_dv'][0], rb['dL_dv']):.2e} "
           f"dxfixed {rel(gb['dL_dxfixed'][0], rb['dL_dxfixed']):.2e}", flush=True)
@@ -173,6 +190,10 @@ def run_dress7k(fp32_only, mesh="dress7k"):
 def main():
     what = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c4"]
     fp32_only = "--fp32-only" in sys.argv
+    global DUMP
+    if "--dump" in sys.argv:
+        DUMP = sys.argv[sys.argv.index("--dump") + 1]
+        os.makedirs(DUMP, exist_ok=True)
     print(f"lib {os.environ.get('DC_LIB', 'default')} fp32_only {fp32_only} DC_CLUSTER {os.environ.get('DC_CLUSTER')}", flush=True)
     for w in what:
         t0 = time.time()

@@ -214,6 +214,12 @@ class Oracle:
                     converged=bool(info[0]), iters=int(info[1]),
                     used_direct=bool(info[2]))
 
+    def override_record(self, rid, x=None, f=None):
+        """diagnostic: replace x_new and / or f of record `rid` (contact vectors d, r re-derived from f)"""
+        xx = None if x is None else f64(x).reshape(-1)
+        ff = None if f is None else f64(f).reshape(-1)
+        self.L.orc_override_record(self.h, C.c_int(rid), None if xx is None else _d(xx), None if ff is None else _d(ff))
+
     def adjoint_matrix(self, rid):
         """K = P - dP^T of the direct adjoint solve of record `rid` (3N x 3N, xyz-interleaved) as a scipy CSC matrix — diagnostic
         for the solver prototypes (tests/proto_adjoint.py)."""
