@@ -44,6 +44,7 @@ __device__ __forceinline__ void st3d(double *p, int i, int n, d3 v) { p[i] = v.x
 // fp64 work vectors of one rollout (planar [3][N] each)
 struct Work64 {
   double *u, *r, *y;                        // solution, true residual g - K u, y = (I + dr_df)^T z (crosses parts)
+  double *x;                                // x_new in fp64 (xnew64), filled once per backward step by prepare_x64 (crosses parts)
   double *rhat, *p, *v, *t, *ph, *sh;       // fall-back BiCGSTAB
 };
 
@@ -258,9 +259,9 @@ __device__ __forceinline__ bool form_y64(const DevSystem &S, const Adj64 &C, Tea
 
 // The element terms of vertex i: sum over its incident constraint corners of h^2 w^2 [(A - dp/dx)^T A y]_corner
 // (Triangle::projectToManifoldBackward Triangle.cpp:354-451 in closed form, TriangleBending::backwardGradient
-// TriangleBending.cpp:154-172), y read through the Team's access path, x_new from the fp32 tape.
+// TriangleBending.cpp:154-172), y and x_new (fp64, prepare_x64) read through the Team's access path.
 template <class YV>
-__device__ __forceinline__ d3 element_terms64(const DevSystem &S, const Adj64 &C, const YV &Y, int i) {
+__device__ __forceinline__ d3 element_terms64(const DevSystem &S, const YV &X, const YV &Y, int i) {
   const int N = S.N, T = S.T, E = S.E;
   const double h2 = S.h64 * S.h64;
   d3 acc = mkd(0, 0, 0);
@@ -271,8 +272,8 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const Adj64 &C
       const int corner = idx / T, t = idx - corner * T;
       const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
       const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
-      const d3 x0 = xnew64(S, C, i0);
-      const d3 e0 = xnew64(S, C, i1) - x0, e1 = xnew64(S, C, i2) - x0;
+      const d3 x0 = ld3y(X, i0, N);
+      const d3 e0 = ld3y(X, i1, N) - x0, e1 = ld3y(X, i2, N) - x0;
       const PolarD P = polar3x2d(e0 * Dx + e1 * Dz, e0 * Dy + e1 * Dw);
       const d3 q0 = ld3y(Y, i0, N);
       const d3 d0 = ld3y(Y, i1, N) - q0, d1 = ld3y(Y, i2, N) - q0;
@@ -294,8 +295,8 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const Adj64 &C
       const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
       d3 res = ey;
       if (nrest > 1e-6) {
-        const d3 x0 = xnew64(S, C, i0);
-        const d3 ev = (xnew64(S, C, i1) - x0) * w1 + (xnew64(S, C, i2) - x0) * w2 + (xnew64(S, C, i3) - x0) * w3;
+        const d3 x0 = ld3y(X, i0, N);
+        const d3 ev = (ld3y(X, i1, N) - x0) * w1 + (ld3y(X, i2, N) - x0) * w2 + (ld3y(X, i3, N) - x0) * w3;
         const double en = sqrt(dot(ev, ev));
         const d3 eh = ev * (1.0 / en);
         res = ey - (ey - eh * dot(eh, ey)) * (nrest / en);
@@ -307,17 +308,25 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const Adj64 &C
   return acc;
 }
 
+// x_new in fp64 on the Team's rows (once per backward step); ends with a Team barrier
+template <int THREADS, class Team>
+__device__ __forceinline__ bool prepare_x64(const DevSystem &S, const Adj64 &C, Team &tm, double *x) {
+  const auto X = tm.yv(x);
+  for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) st3y(X, i, S.N, xnew64(S, C, i));
+  return tm.barrier();
+}
+
 // out = K z on the Team's rows (fp64): K = M + h^2 (A - dp/dx)^T A (I + dr_df)^T. vert(i, K z at vertex i) is called for every own
 // row exactly once (store, accumulate dot products ...). Ends WITHOUT a barrier: the caller reduces next (which is also what
 // keeps a part from overwriting y while a neighbour still gathers from it).
 template <int THREADS, class Team, class VertOp>
-__device__ __forceinline__ bool apply_K64(const DevSystem &S, const Adj64 &C, Team &tm, const double *z, double *y, VertOp vert) {
+__device__ __forceinline__ bool apply_K64(const DevSystem &S, const Adj64 &C, Team &tm, const double *z, double *y, const double *x, VertOp vert) {
   if (!form_y64<THREADS>(S, C, tm, z, y)) return false;
   const int N = S.N;
-  const auto Y = tm.yv(y);
+  const auto Y = tm.yv(y), X = tm.yv((double *) x);
   const double hk = S.h64 * S.h64 * S.k_att64;
   for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) {
-    d3 o = ld3d(z, i, N) * S.mass64[i] + element_terms64(S, C, Y, i);
+    d3 o = ld3d(z, i, N) * S.mass64[i] + element_terms64(S, X, Y, i);
     if (S.att_of_vertex[i] >= 0) o = o + ld3y(Y, i, N) * hk;       // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
     vert(i, o);
   }
@@ -361,7 +370,7 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
     bool restart = false;
     // v = K M^-1 p ; alpha = rho / (rhat . v)
     double a1 = 0;
-    if (!apply_K64<THREADS>(S, C, tm, W.ph, W.y, [&](int i, d3 o) { st3d(W.v, i, N, o); a1 += dot(o, ld3d(W.rhat, i, N)); })) return ret(-1);
+    if (!apply_K64<THREADS>(S, C, tm, W.ph, W.y, W.x, [&](int i, d3 o) { st3d(W.v, i, N, o); a1 += dot(o, ld3d(W.rhat, i, N)); })) return ret(-1);
     if (!tm.sum3(a1, 0, 0, s3)) return ret(-1);
     const double rv = s3[0];
     double alpha = 0, omega = 0;
@@ -384,7 +393,7 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
       }
       // t = K M^-1 s ; omega = (t . s) / (t . t)
       double b1 = 0, b2 = 0;
-      if (!apply_K64<THREADS>(S, C, tm, W.sh, W.y, [&](int i, d3 o) { st3d(W.t, i, N, o); b1 += dot(o, ld3d(W.r, i, N)); b2 += dot(o, o); })) return ret(-1);
+      if (!apply_K64<THREADS>(S, C, tm, W.sh, W.y, W.x, [&](int i, d3 o) { st3d(W.t, i, N, o); b1 += dot(o, ld3d(W.r, i, N)); b2 += dot(o, o); })) return ret(-1);
       if (!tm.sum3(b1, b2, 0, s3)) return ret(-1);
       omega = s3[1] > 1e-300 ? s3[0] / s3[1] : 0.0;
       // u += alpha M^-1 p + omega M^-1 s ; r = s - omega t ; rho_new = rhat . r
@@ -427,7 +436,7 @@ template <int THREADS, class Team>
 __device__ DC_OUTLINED Ret64<Team> residual64(const DevSystem &S, Adj64 C, Team tm, Work64 W, const float *__restrict__ gx, float gscale) {
   const int N = S.N;
   double a = 0;
-  if (!apply_K64<THREADS>(S, C, tm, W.u, W.y, [&](int i, d3 o) {
+  if (!apply_K64<THREADS>(S, C, tm, W.u, W.y, W.x, [&](int i, d3 o) {
         const d3 q = tod(ld3(gx, i, N) * gscale) - o;
         st3d(W.r, i, N, q);
         a += dot(q, q);
@@ -451,7 +460,7 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
   float *gx = A.gx + off, *gv = A.gv + off;
   const double h = S.h64, h2 = h * h;
   if (!form_y64<THREADS>(S, C, tm, W.u, W.y)) return ret(-1);
-  const auto Y = tm.yv(W.y);
+  const auto Y = tm.yv(W.y), X = tm.yv(W.x);
   double pacc[7] = {0, 0, 0, 0, 0, 0, 0};
   if (A.d_param) {
     const int T = S.T, E = S.E, K = tm.parts(), part = tm.part();
@@ -459,8 +468,8 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
     for (int t = t0 + tid; t < t1; t += THREADS) {
       const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
       const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
-      const d3 x0 = xnew64(S, C, i0);
-      const d3 e0 = xnew64(S, C, i1) - x0, e1 = xnew64(S, C, i2) - x0;
+      const d3 x0 = ld3y(X, i0, N);
+      const d3 e0 = ld3y(X, i1, N) - x0, e1 = ld3y(X, i2, N) - x0;
       const d3 f0 = e0 * Dx + e1 * Dz, f1 = e0 * Dy + e1 * Dw;
       const PolarD P = polar3x2d(f0, f1);
       const double w2 = S.tri_w2_64[t];
@@ -474,8 +483,8 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
       const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
       const double w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
       const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
-      const d3 x0 = xnew64(S, C, i0);
-      const d3 ev = (xnew64(S, C, i1) - x0) * w1 + (xnew64(S, C, i2) - x0) * w2 + (xnew64(S, C, i3) - x0) * w3;
+      const d3 x0 = ld3y(X, i0, N);
+      const d3 ev = (ld3y(X, i1, N) - x0) * w1 + (ld3y(X, i2, N) - x0) * w2 + (ld3y(X, i3, N) - x0) * w3;
       d3 p = mkd(0, 0, 0);
       if (nrest > 1e-6) { const double n2 = dot(ev, ev); p = n2 > 0 ? ev * (nrest / sqrt(n2)) : ev * nrest; }
       const d3 q0 = ld3y(Y, i0, N);
@@ -493,10 +502,10 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
     const double m = S.mass64[i];
     if (A.d_param) {
       const int a = S.att_of_vertex[i];
-      if (a >= 0) pacc[2] += S.k_att64 * dot(tod(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af)) - xnew64(S, C, i), yi);
+      if (a >= 0) pacc[2] += S.k_att64 * dot(tod(ld3(A.x_fixed + (size_t) b * 3 * S.Af, a, S.Af)) - ld3y(X, i, N), yi);
       const double ar = m / S.density64;
       const d3 xp = tod(ld3(A.x_prev + off, i, N)), vp = tod(ld3(A.v_prev + off, i, N));
-      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - xnew64(S, C, i)) + h * dot(w, vp + grav * h));
+      pacc[3] += ar * (dot(ui, xp + vp * h + grav * h2 - ld3y(X, i, N)) + h * dot(w, vp + grav * h));
       pacc[4] += h2 * yi.x; pacc[5] += h2 * yi.y; pacc[6] += h2 * yi.z;
     }
     const int prim = C.rec_prim[i];

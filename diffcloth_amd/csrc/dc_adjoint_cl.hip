@@ -21,6 +21,7 @@ namespace dc {
 
 constexpr int kMaxRefine = 6;          // fp32 correction solves of the mixed-precision direct adjoint solve before the fp64 fall-back
 constexpr double kInnerFloor = 1e-3;   // (dc_adjoint.hip)
+constexpr double kFallbackGain = 1e-4;
 
 typedef int v2i __attribute__((ext_vector_type(2)));
 
@@ -36,7 +37,15 @@ struct TeamParts {
   __device__ __forceinline__ int part() const { return part_; }
   __device__ __forceinline__ int parts() const { return K_; }
   __device__ __forceinline__ bool barrier() { return xch_barrier<THREADS>(X); }
-  __device__ __forceinline__ bool sum3(double a, double b, double c, double (&s)[3]) { return xch_allsum<THREADS>(X, (float) a, (float) b, (float) c, s); }
+  // a and b travel as (hi, lo) float pairs, one exchange each (fp32 partial sums stall the fp64 BiCGSTAB of an ill-conditioned system:
+  // 1e-4 on the 7 742-vertex dress, measured r03c); c as fp32 with a
+  __device__ __forceinline__ bool sum3(double a, double b, double c, double (&s)[3]) {
+    double sa, sc, sb = 0, sd;
+    if (!xch_allsum_d<THREADS>(X, a, (float) c, sa, sc)) return false;
+    if (!xch_allsum_d<THREADS>(X, b, 0.f, sb, sd)) return false;
+    s[0] = sa; s[1] = sb; s[2] = sc;
+    return true;
+  }
   struct YV {
     __amdgpu_buffer_rsrc_t rs;
     bool same;
@@ -211,10 +220,13 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   C64.xnew = C.xnew; C64.rec_f = C.rec_f; C64.rec_n = C.rec_n; C64.mu = C.mu; C64.rec_prim = C.rec_prim;
   C64.self = C.self; C64.nself = C.nself; C64.b = b; C64.lds = dyn_lds; C64.lds_floats = hc_off;
   Work64 W64;
-  W64.u = W.u64 + off; W64.r = W.r64 + off; W64.y = W.y64 + off;
+  W64.u = W.u64 + off; W64.r = W.r64 + off; W64.y = W.y64 + off; W64.x = W.x64 + off;
   W64.rhat = W.k64[0] + off; W64.p = W.k64[1] + off; W64.v = W.k64[2] + off; W64.t = W.k64[3] + off; W64.ph = W.k64[4] + off; W64.sh = W.k64[5] + off;
   int cycles = 0, iters64 = 0;
   for (int i = r0 + tid; i < r1; i += THREADS) st3d(W64.u, i, N, mkd(0, 0, 0));
+  tm.X = X;
+  if (!prepare_x64<THREADS>(S, C64, tm, W64.x)) return;
+  X = tm.X;
   double rr_true = gnorm * gnorm;
   if (gnorm > 0) {
     // ---- direct solve of K u = g in mixed precision (see dc_adjoint.hip): fp32 BiCGSTAB for corrections of the fp64 residual ----
@@ -385,10 +397,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
           store_block_inverse(elastic_diag_block(S, C.xnew, i), S.mass[i], [&](f3 e) { return contact_JT_cl(S, C, i, e); }, minv, i, N);
       }
       __syncthreads();
+      const double stop_fb = fmax(stop * kFallbackGain * kFallbackGain, 1e-26 * gnorm * gnorm);     // (dc_adjoint.hip)
       double rr64 = rr_true;
-      for (int pass = 0; pass < 3 && status == 0; pass++) {
+      for (int pass = 0; pass < 3; pass++) {
         tm.X = X;
-        auto r64 = bicgstab64<THREADS>(S, C64, tm, W64, minv, stop, 20000, rr64, iters64);
+        auto r64 = bicgstab64<THREADS>(S, C64, tm, W64, minv, stop_fb, 20000, rr64, iters64);
         tm = r64.tm; X = tm.X;
         if (r64.res < 0) return;
         iters64 = r64.iters;
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
         if (rc.res < 0) return;
         rr64 = rc.rr;
         if (rr64 <= stop) status = 1;
-        else if (r64.res == 0) break;
+        if (rr64 <= stop_fb || r64.res == 0) break;
       }
       rr_true = rr64;
     }

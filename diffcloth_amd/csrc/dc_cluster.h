@@ -233,6 +233,47 @@ __device__ __forceinline__ bool xch_allsum(Xch &X, float a, float b, float c, do
   return xch_finish<THREADS, 1, false>(X, s, none);
 }
 
+// all-parts sum of one fp64 value (as hi + lo fp32 in the granule) and one fp32 value per thread: every wave reduces in fp64 and
+// publishes {hi, lo, c, tag}; wave 0 of the consumer adds the granules up in fp64. Same protocol and barrier count as xch_allsum.
+template <int THREADS>
+__device__ __forceinline__ bool xch_allsum_d(Xch &X, double a, float c, double &sa, double &sc) {
+  constexpr int NW = THREADS / 64;
+  xch_begin(X);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  c = xch_wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    const float hi = (float) a, lo = (float) (a - (double) hi);
+    v4i g = {__float_as_int(hi), __float_as_int(lo), __float_as_int(c), (int) X.seq};
+    xch_store(X, g, xch_off(X, X.part, (int) (threadIdx.x >> 6)));
+  }
+  bool ok = true;
+  double *slot = (double *) (X.lsum + 4 * (int) (X.seq & 1u));      // 16 bytes per parity: the fp64 total; the fp32 one goes after both
+  float *cslot = X.lsum + 10 + (int) (X.seq & 1u);
+  if (threadIdx.x < 64) {
+    double da = 0;
+    float fc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int j = threadIdx.x + 64 * q;
+      if (j < X.K * NW) {
+        v4i g;
+        ok = xch_poll(X, xch_off(X, j / NW, j % NW), g) && ok;
+        da += (double) __int_as_float(g.x) + (double) __int_as_float(g.y);
+        fc += __int_as_float(g.z);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) da += __shfl_down(da, o, 64);
+    fc = xch_wave_sum(fc);
+    if (threadIdx.x == 0) { slot[0] = da; *cslot = fc; }
+  }
+  if (!ok) *X.ldead = 1;
+  __syncthreads();
+  sa = slot[0]; sc = (double) *cslot;
+  return *X.ldead == 0;
+}
+
 // First exchange of a kernel (write-through stores): the parts tell each other which XCD they run on (HW_REG_XCC_ID). When all
 // K are on the same one, its L2 is their coherence point and the stores of every later exchange may stay there.
 template <int THREADS>

@@ -105,6 +105,8 @@ struct DevSystem {
   const double DC_G *bend_w64;       // [4][E] planar cotan weights
   const double DC_G *bend_nw64;      // [2][E] planar: rest norm, weight^2
   const double DC_G *mass64;         // [N]
+  const float4 DC_G *tri_Dlo;        // [T] low-order parts of inv_deltaUV (value - fl32(value)): fp64-strain element operators on the global tables
+  const float4 DC_G *bend_lo;        // [E] low-order parts of the cotan weights 1..3 and of the rest norm
   double h64, k_att64, k_stretch64, k_bend64, density64;
   double g64[3];
   DevPrim prims[kMaxPrims];
@@ -126,7 +128,7 @@ struct DevWork {
   float *minv;            // [B][9][N]
   // adjoint in mixed precision (dc_adjoint64.h): solution, true residual, y = (I + dr_df)^T z, and the six further vectors of the
   // fp64 fall-back BiCGSTAB; [B][3][N] doubles each
-  double *u64, *r64, *y64, *k64[6];
+  double *u64, *r64, *y64, *x64, *k64[6];
   // self-collision detection / layering scratch (k_self_detect)
   int *sd_cell, *sd_order;      // [B][N]
   float *sd_sx;                 // [B][3][N] positions in cell-sorted order
@@ -160,7 +162,7 @@ struct FwdArgs {
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
-  int precise_record;           // packet / split kernels: re-evaluate the record's f (and r, d) of a converged step with fp64 element math
+  int precise_all;              // element operators of the local step: 1 = fp64 strain (dc_winlib.h: HybridTriOp, the default), 0 = fp32, 2 = fp64
   int cg_seed;                  // packet / split kernels: first search direction of a solve = the previous PD iteration's correction
   // several consecutive steps in one launch (packet kernel only): step s uses tape slot k + s
   int nsteps, inline_detect;    // inline_detect: run the self-collision detection of every step inside the kernel

@@ -192,8 +192,7 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   static const bool seed_on = !(getenv("DC_CG_SEED") && getenv("DC_CG_SEED")[0] == '0');     // development switch
   A.cg_seed = seed_on ? 1 : 0;
-  static const bool precise_on = !(getenv("DC_PRECISE_RECORD") && getenv("DC_PRECISE_RECORD")[0] == '0');     // development switch
-  A.precise_record = precise_on ? 1 : 0;
+  { const char *envp = getenv("DC_PRECISE_ALL"); A.precise_all = envp ? atoi(envp) : 1; }     // (development switch: 0 fp32 element operators, 2 fp64)
   A.nsteps = 1; A.inline_detect = 0; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
   A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   return A;
@@ -610,6 +609,16 @@ int dc_build(dc_ctx *c) {
     if ((rc = upload<double>(c, &S.bend_w64, w4))) return rc;
     if ((rc = upload<double>(c, &S.bend_nw64, nw2))) return rc;
     if ((rc = upload<double>(c, &S.mass64, H.mass))) return rc;
+    std::vector<float> dlo(4 * (size_t) T), blo(4 * (size_t) E);
+    for (size_t k = 0; k < dlo.size(); k++) dlo[k] = (float) (H.tri_D[k] - (double) (float) H.tri_D[k]);
+    for (int e = 0; e < E; e++) {
+      for (int k = 1; k < 4; k++) blo[4 * (size_t) e + k - 1] = (float) (H.bend_w[4 * (size_t) e + k] - (double) (float) H.bend_w[4 * (size_t) e + k]);
+      blo[4 * (size_t) e + 3] = (float) (H.bend_n[e] - (double) (float) H.bend_n[e]);
+    }
+    if ((rc = upload<float>(c, &f4, dlo))) return rc;
+    S.tri_Dlo = (const float4 *) f4;
+    if ((rc = upload<float>(c, &f4, blo))) return rc;
+    S.bend_lo = (const float4 *) f4;
   }
   if ((rc = upload<int>(c, &S.P_ptr, H.P_ptr))) return rc;
   if ((rc = upload<int>(c, &S.P_col, H.P_col))) return rc;
@@ -837,6 +846,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->W.u64, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.r64, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.y64, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.x64, se))) return rc;
   for (int k = 0; k < 6; k++) if ((rc = dev_alloc(c, pool, &c->W.k64[k], se))) return rc;
   {
     const int cap = c->S.self_cap;

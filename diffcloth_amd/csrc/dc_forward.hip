@@ -14,6 +14,7 @@
 #include <cstdlib>
 #define DC_KERNEL_TU
 #include "dc_devlib.h"
+#include "dc_winlib.h"
 
 namespace dc {
 
@@ -71,14 +72,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
     for (int t = tid; t < T; t += THREADS) {
       const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
       const float4 D = S.tri_D[t];
-      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
-      // edges as (x_n differences) + h (v differences): exact fp32 differences, no cancellation error
-      f3 e0 = (ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h;
-      f3 e1 = (ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h;
-      f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
-      Polar P = polar3x2(f0, f1);
-      const float s = h * S.tri_w2[t];
-      f3 g0 = (P.t0 - f0) * s, g1 = (P.t1 - f1) * s;
+      // fp64-strain element operator (dc_winlib.h: the fp32 evaluation of T - F carries the 6e-8 roundings of F into a difference of
+      // nearly equal quantities)
+      f3 g0, g1;
+      HybridTriOp{S.h64}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N), D, S.tri_Dlo[t], S.tri_w2[t], g0, g1);
       f3 c1 = g0 * D.x + g1 * D.y, c2 = g0 * D.z + g1 * D.w;
       f3 c0 = mk(0, 0, 0) - c1 - c2;
       st3(corner, t, NC, c0); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
@@ -88,14 +85,9 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
       const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
       const float4 w = S.bend_w[e];
       const float2 nw = S.bend_nw[e];
-      f3 x0 = ld3(xn, i0, N), v0 = ld3(vnow, i0, N);
-      // sum_i w_i x_i with sum_i w_i = 0  ->  sum_{i>0} w_i (x_i - x_0)
-      f3 ev = ((ld3(xn, i1, N) - x0) + (ld3(vnow, i1, N) - v0) * h) * w.y;
-      ev = ev + ((ld3(xn, i2, N) - x0) + (ld3(vnow, i2, N) - v0) * h) * w.z;
-      ev = ev + ((ld3(xn, i3, N) - x0) + (ld3(vnow, i3, N) - v0) * h) * w.w;
-      f3 p = mk(0, 0, 0);
-      if (nw.x > 1e-6f) p = normalized(ev) * nw.x;
-      f3 d = (p - ev) * (h * nw.y);
+      f3 d;
+      HybridBendOp{S.h64}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(xn, i3, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N),
+                          ld3(vnow, i3, N), w, S.bend_lo[e], nw.x, nw.y, d);
       const int base = 3 * T;
       st3(corner, base + e, NC, d * w.x); st3(corner, base + E + e, NC, d * w.y);
       st3(corner, base + 2 * E + e, NC, d * w.z); st3(corner, base + 3 * E + e, NC, d * w.w);

@@ -155,11 +155,15 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     };
     // ---- local step + vertex pass through this part's element windows ----
     float psum = 0.f;
-    element_windows_t<THREADS>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, FwdTriOp{h}, FwdBendOp{h}, [&](int i, f3 sum, f3) {
+    auto vert = [&](int i, f3 sum, f3) {
       f3 rhs = vertex_body(i, sum);
       st3(scr, i, N, rhs);
       psum += dot(rhs, rhs);
-    });
+    };
+    // element operators: fp64 strain by default (dc_winlib.h: HybridTriOp), see dc_forward_pk.hip
+    if (A.precise_all == 1) element_windows_t<THREADS, true>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, HybridTriOp{S.h64}, HybridBendOp{S.h64}, vert);
+    else if (A.precise_all == 2) element_windows_t<THREADS, true>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, vert);
+    else element_windows_t<THREADS>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, FwdTriOp{h}, FwdBendOp{h}, vert);
     __syncthreads();
     CPH(0)
     X.site = 4;
@@ -452,53 +456,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         }
       }
     }
-    if (converged) {
-      // the record's f belongs to the iterate this last iteration STARTED from: v - delta (delta still in registers); kept for the
-      // precise record pass below (dc_forward_pk.hip has the same pass)
-      if (A.precise_record) {
-        const BufVec vpb = buf_vec(W.cg_p + off, N, X.same_xcd);
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int l = tq + k * THREADS, i = r0 + l;
-          if (l < R && i < N) { const f3 v = ld3c(vnb, i); st3c(vpb, i, mk(v.x - ap[k][0], v.y - ap[k][1], v.z - ap[k][2])); }
-        }
-      }
-      break;
-    }
+    if (converged) break;
     if (++since_progress >= A.stall_window) { stalled = true; break; }
-  }
-  // ---- precise record (dc_winlib.h: PreciseTriOp): f, r and the self-contact vectors d of a converged step once more, with fp64
-  //      element math (what stepBackward differentiates) ----
-  if (converged && A.precise_record) {
-    const BufVec vpb = buf_vec(W.cg_p + off, N, X.same_xcd);
-    X.site = 9;
-    if (!xch_barrier<THREADS>(X)) return;            // the neighbours' rows of v - delta are read by this part's windows
-    element_windows_t<THREADS, true>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vpb}, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, [&](int i, f3 fint, f3) {
-      f3 f = ld3(g, i, N) + fint;
-      const int a = S.att_of_vertex[i];
-      if (a >= 0) {   // AttachmentSpring.cpp:25-29, the difference formed in fp64
-        const f3 xf = ld3(xfix, a, S.Af), x0 = ld3c(xnb, i), v = ld3c(vpb, i);
-        const double hk = S.h64 * S.k_att64;
-        f = f + mk((float) ((((double) xf.x - (double) x0.x) - S.h64 * (double) v.x) * hk), (float) ((((double) xf.y - (double) x0.y) - S.h64 * (double) v.y) * hk),
-                   (float) ((((double) xf.z - (double) x0.z) - S.h64 * (double) v.z) * hk));
-      }
-      f3 r = mk(0, 0, 0);
-      const int prim = rec_prim[i];
-      if (prim >= 0) {
-        const f3 n = ld3(rec_n, i, N);
-        r = dry_friction(n, f - prim_vout(S.prims[prim], n) * S.mass[i], mu[S.prims[prim].group]);
-      }
-      st3c(rfb, i, f);
-      st3c(rrb, i, r);
-    });
-    __syncthreads();
-    if (nself > 0) {
-      if (!xch_barrier<THREADS>(X)) return;
-      if (part == 0) {
-        if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
-      }
-      if (!xch_barrier<THREADS>(X)) return;
-    }
   }
   // ---- write the new state of the own rows (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
   const BufVec xob = buf_vec(A.x_out + off + so, N, X.same_xcd), vob = buf_vec(A.v_out + off + so, N, X.same_xcd);

@@ -142,11 +142,16 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     if (S.win_ok) {
       // ---- local step + vertex pass, window by window inside LDS (dc_winlib.h) ----
       float *scr = W.cg_r + off;
-      element_windows<THREADS>(S, lp, StagePlanar{xn, N}, vnow, FwdTriOp{h}, FwdBendOp{h}, [&](int i, f3 sum, f3) {
+      auto vert = [&](int i, f3 sum, f3) {
         f3 rhs = vertex_body(i, sum);
         st3(scr, i, N, rhs);
         part += dot(rhs, rhs);
-      });
+      };
+      // element operators: fp64 strain by default (dc_winlib.h: HybridTriOp — +1 % on the 10k-vertex workload for 30 x smaller
+      // gradient differences against the fp64 reference, measured r03d); 0 = all-fp32, 2 = all-fp64 (A/B switches)
+      if (A.precise_all == 1) element_windows<THREADS, true>(S, lp, StagePlanar{xn, N}, vnow, HybridTriOp{S.h64}, HybridBendOp{S.h64}, vert);
+      else if (A.precise_all == 2) element_windows<THREADS, true>(S, lp, StagePlanar{xn, N}, vnow, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, vert);
+      else element_windows<THREADS>(S, lp, StagePlanar{xn, N}, vnow, FwdTriOp{h}, FwdBendOp{h}, vert);
       __syncthreads();
       PH(0)
       for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread (clamped index), then the LDS stores
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
         f3 r0, r1;
         const float4 D = S.tri_D[t];
-        FwdTriOp{h}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N), D, S.tri_w2[t], r0, r1);
+        HybridTriOp{S.h64}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N), D, S.tri_Dlo[t], S.tri_w2[t], r0, r1);
         f3 c1 = r0 * D.x + r1 * D.y, c2 = r0 * D.z + r1 * D.w;
         st3(corner, t, NC, mk(0, 0, 0) - c1 - c2); st3(corner, T + t, NC, c1); st3(corner, 2 * T + t, NC, c2);
       }
@@ -180,8 +185,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         const float4 w = S.bend_w[e];
         const float2 nw = S.bend_nw[e];
         f3 d;
-        FwdBendOp{h}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(xn, i3, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N),
-                     ld3(vnow, i3, N), w, nw.x, nw.y, d);
+        HybridBendOp{S.h64}(ld3(xn, i0, N), ld3(xn, i1, N), ld3(xn, i2, N), ld3(xn, i3, N), ld3(vnow, i0, N), ld3(vnow, i1, N), ld3(vnow, i2, N),
+                            ld3(vnow, i3, N), w, S.bend_lo[e], nw.x, nw.y, d);
         const int base = 3 * T;
         st3(corner, base + e, NC, d * w.x); st3(corner, base + E + e, NC, d * w.y);
         st3(corner, base + 2 * E + e, NC, d * w.z); st3(corner, base + 3 * E + e, NC, d * w.w);
@@ -403,49 +408,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         if (i < N) { vbest[i] = vnow[i] - ap[k][0]; vbest[N + i] = vnow[N + i] - ap[k][1]; vbest[2 * N + i] = vnow[2 * N + i] - ap[k][2]; }
       }
     }
-    if (converged) {
-      // the record's f belongs to the iterate this last iteration STARTED from (Simulation.cpp:1248-1249, 1310-1314): v - delta,
-      // delta still in registers; kept for the precise record pass below
-      if (A.precise_record && S.win_ok) {
-        float *vpre = W.cg_p + off;
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int i = tq + k * THREADS;
-          if (i < N) { vpre[i] = vnow[i] - ap[k][0]; vpre[N + i] = vnow[N + i] - ap[k][1]; vpre[2 * N + i] = vnow[2 * N + i] - ap[k][2]; }
-        }
-      }
-      break;
-    }
+    if (converged) break;
     if (++since_progress >= A.stall_window) { stalled = true; break; }   // fp32 floor, see dc_forward.hip
-  }
-  // ---- precise record (dc_winlib.h: PreciseTriOp): f, r and the self-contact vectors d of a converged step once more, with fp64
-  //      element math — what stepBackward differentiates (Simulation.cpp:881-919 reads d = f - m v_out of the record) ----
-  if (converged && A.precise_record && S.win_ok) {
-    __syncthreads();
-    const float *vpre = W.cg_p + off;
-    element_windows<THREADS, true>(S, lp, StagePlanar{xn, N}, vpre, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, [&](int i, f3 fint, f3) {
-      f3 f = ld3(g, i, N) + fint;
-      const int a = S.att_of_vertex[i];
-      if (a >= 0) {   // AttachmentSpring.cpp:25-29, the difference formed in fp64
-        const f3 xf = ld3(xfix, a, S.Af), x0 = ld3(xn, i, N), v = ld3(vpre, i, N);
-        const double hk = S.h64 * S.k_att64;
-        f = f + mk((float) ((((double) xf.x - (double) x0.x) - S.h64 * (double) v.x) * hk), (float) ((((double) xf.y - (double) x0.y) - S.h64 * (double) v.y) * hk),
-                   (float) ((((double) xf.z - (double) x0.z) - S.h64 * (double) v.z) * hk));
-      }
-      f3 r = mk(0, 0, 0);
-      const int prim = rec_prim[i];
-      if (prim >= 0) {
-        const f3 n = ld3(rec_n, i, N);
-        r = dry_friction(n, f - prim_vout(S.prims[prim], n) * S.mass[i], mu[S.prims[prim].group]);
-      }
-      st3(rec_f, i, N, f);
-      st3(rec_r, i, N, r);
-    });
-    if (nself > 0) {
-      __syncthreads();
-      if (!self_friction_layers_lds<THREADS>(S, srec, b, rec_f, rec_r, lp, 3 * NP)) self_friction_layers<THREADS>(S, srec, b, rec_f, rec_r);
-    }
-    __syncthreads();
   }
   // ---- write the new state (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
   float *xo = A.x_out + off + so, *vo = A.v_out + off + so;

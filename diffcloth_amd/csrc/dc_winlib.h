@@ -37,8 +37,8 @@ struct In2Plain {
   int N;
   __device__ __forceinline__ f3 operator()(int i) const { return mk(v[i], v[N + i], v[2 * N + i]); }
 };
-// PRECISE: the element operators also receive the low-order parts of the element's rest data (wtri_Dlo / wbend_lo) — the record
-// pass of the forward step (PreciseTriOp / PreciseBendOp below); one element per thread and round, it runs once per time step.
+// PRECISE: the element operators also receive the low-order parts of the element's rest data (wtri_Dlo / wbend_lo) — the
+// fp64-strain operators of the forward step (PreciseTriOp / PreciseBendOp, HybridTriOp / HybridBendOp below).
 template <int THREADS, bool PRECISE = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, float *lds, Stage1 stage1,
                                                   In2 in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
@@ -68,61 +68,53 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     auto tri_batch = [&](auto ebc, int t0) {
       constexpr int EB = decltype(ebc)::value;
       int4 r[EB];
-      float4 D[EB];
+      float4 D[EB], Dl[PRECISE ? EB : 1];
 #pragma unroll
       for (int j = 0; j < EB; j++) {
         const int t = min(t0 + j * THREADS, nt - 1);
         r[j] = S.wtri_rec[toff + t]; D[j] = S.wtri_D[toff + t];
+        if constexpr (PRECISE) Dl[j] = S.wtri_Dlo[toff + t];
       }
 #pragma unroll
       for (int j = 0; j < EB; j++) {
         const int t = t0 + j * THREADS;
         const int j0 = r[j].x & 0xffff, j1 = (int) ((unsigned) r[j].x >> 16), j2 = r[j].y;
         f3 r0, r1;
-        tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
-               ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D[j], __int_as_float(r[j].z), r0, r1);
+        if constexpr (PRECISE)
+          tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
+                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D[j], Dl[j], __int_as_float(r[j].z), r0, r1);
+        else
+          tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
+                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D[j], __int_as_float(r[j].z), r0, r1);
         if (t < nt) { stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1); }
       }
     };
     auto bend_batch = [&](auto ebc, int e0) {
       constexpr int EB = decltype(ebc)::value;
       int4 r[EB];
-      float4 wq[EB];
+      float4 wq[EB], wl[PRECISE ? EB : 1];
 #pragma unroll
       for (int j = 0; j < EB; j++) {
         const int e = min(e0 + j * THREADS, nb - 1);
         r[j] = S.wbend_rec[boff + e]; wq[j] = S.wbend_w[boff + e];
+        if constexpr (PRECISE) wl[j] = S.wbend_lo[boff + e];
       }
 #pragma unroll
       for (int j = 0; j < EB; j++) {
         const int e = e0 + j * THREADS;
         const int j0 = r[j].x & 0xffff, j1 = (int) ((unsigned) r[j].x >> 16), j2 = r[j].y & 0xffff, j3 = (int) ((unsigned) r[j].y >> 16);
         f3 res;
-        bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
-                ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq[j],
-                __int_as_float(r[j].z), __int_as_float(r[j].w), res);
+        if constexpr (PRECISE)
+          bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
+                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq[j], wl[j],
+                  __int_as_float(r[j].z), __int_as_float(r[j].w), res);
+        else
+          bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
+                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq[j],
+                  __int_as_float(r[j].z), __int_as_float(r[j].w), res);
         if (e < nb) stw(L.erxy, L.erz, 2 * nt + e, res);
       }
     };
-    if constexpr (PRECISE) {
-      for (int t = tid; t < nt; t += THREADS) {
-        const int4 r = S.wtri_rec[toff + t];
-        const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y;
-        f3 r0, r1;
-        tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1),
-               ldw(L.a2xy, L.a2z, j2), S.wtri_D[toff + t], S.wtri_Dlo[toff + t], __int_as_float(r.z), r0, r1);
-        stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1);
-      }
-      for (int e = tid; e < nb; e += THREADS) {
-        const int4 r = S.wbend_rec[boff + e];
-        const int j0 = r.x & 0xffff, j1 = (int) ((unsigned) r.x >> 16), j2 = r.y & 0xffff, j3 = (int) ((unsigned) r.y >> 16);
-        f3 res;
-        bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3), ldw(L.a2xy, L.a2z, j0),
-                ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), S.wbend_w[boff + e], S.wbend_lo[boff + e],
-                __int_as_float(r.z), __int_as_float(r.w), res);
-        stw(L.erxy, L.erz, 2 * nt + e, res);
-      }
-    } else {
     for (int q = 0, rounds = (nt + THREADS - 1) / THREADS; q < rounds;) {      // wave-uniform control flow
       const int left = rounds - q, t0 = q * THREADS + tid;
       if (left >= 4) { tri_batch(std::integral_constant<int, 4>(), t0); q += 4; }
@@ -134,7 +126,6 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
       if (left >= 4) { bend_batch(std::integral_constant<int, 4>(), e0); q += 4; }
       else if (left == 3) { bend_batch(std::integral_constant<int, 3>(), e0); q += 3; }
       else { bend_batch(std::integral_constant<int, 2>(), e0); q += 2; }
-    }
     }
     __syncthreads();
     // per-vertex phase. All packets of a vertex travel in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2
@@ -262,6 +253,55 @@ struct PreciseBendOp {   // wl = low-order parts of the cotan weights 1..3 and (
     }
     const double sc = fac * h * (double) w2;
     res = mk((float) (ex * sc), (float) (ey * sc), (float) (ez * sc));
+  }
+};
+
+// The same accuracy where it matters at a fraction of the fp64 work — for use in EVERY PD iteration: only the deformation gradient F
+// and the strain E = F^T F - I (bending: e and |e|^2 - n^2) are formed in fp64; everything after them is a function of the small
+// quantity E evaluated in fp32 without cancellation:
+//   C = I + E,  s = sqrt(det C),  t = sqrt(tr C + 2 s),  S = C^(1/2) = (C + s I) / t        (2 x 2 closed form)
+//   s - 1 = q / (sqrt(1 + q) + 1),  q = tr E + det E;   t - 2 = (tr E + 2 (s - 1)) / (t + 2);   S - I = (E + (s - 1 - (t - 2)) I) / t
+//   T - F = F (S^-1 - I) = -F (S - I) S^-1
+struct HybridTriOp {
+  double h;
+  __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float4 Dl, float w2, f3 &r0, f3 &r1) const {
+    const f3 a0 = x1 - x0, a1 = x2 - x0, b0 = v1 - v0, b1 = v2 - v0;
+    const double e0x = (double) a0.x + h * (double) b0.x, e0y = (double) a0.y + h * (double) b0.y, e0z = (double) a0.z + h * (double) b0.z;
+    const double e1x = (double) a1.x + h * (double) b1.x, e1y = (double) a1.y + h * (double) b1.y, e1z = (double) a1.z + h * (double) b1.z;
+    const double Dx = (double) D.x + (double) Dl.x, Dy = (double) D.y + (double) Dl.y, Dz = (double) D.z + (double) Dl.z, Dw = (double) D.w + (double) Dl.w;
+    const double f0x = e0x * Dx + e1x * Dz, f0y = e0y * Dx + e1y * Dz, f0z = e0z * Dx + e1z * Dz;
+    const double f1x = e0x * Dy + e1x * Dw, f1y = e0y * Dy + e1y * Dw, f1z = e0z * Dy + e1z * Dw;
+    const float e00 = (float) (f0x * f0x + f0y * f0y + f0z * f0z - 1.0), e01 = (float) (f0x * f1x + f0y * f1y + f0z * f1z),
+                e11 = (float) (f1x * f1x + f1y * f1y + f1z * f1z - 1.0);
+    const f3 f0 = mk((float) f0x, (float) f0y, (float) f0z), f1 = mk((float) f1x, (float) f1y, (float) f1z);
+    const float trE = e00 + e11, q = trE + (e00 * e11 - e01 * e01);
+    const float sm1 = q * fast_rcp(fast_sqrt(fmaxf(1.f + q, 1e-30f)) + 1.f);
+    const float t = fast_sqrt(fmaxf(4.f + trE + 2.f * sm1, 1e-30f));
+    const float tm2 = (trE + 2.f * sm1) * fast_rcp(t + 2.f);
+    const float c = sm1 - tm2, it = fast_rcp(t);
+    const float a = (e00 + c) * it, b = e01 * it, d = (e11 + c) * it;               // S - I
+    const float idet = fast_rcp((1.f + a) * (1.f + d) - b * b);
+    const float m00 = (a + (a * d - b * b)) * idet, m01 = b * idet, m11 = (d + (a * d - b * b)) * idet;   // (S - I) S^-1
+    const float sc = -(float) h * w2;
+    r0 = (f0 * m00 + f1 * m01) * sc; r1 = (f0 * m01 + f1 * m11) * sc;
+  }
+};
+struct HybridBendOp {
+  double h;
+  __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 x3, f3 v0, f3 v1, f3 v2, f3 v3, float4 w, float4 wl, float n, float w2, f3 &res) const {
+    const double w1 = (double) w.y + (double) wl.x, w2d = (double) w.z + (double) wl.y, w3 = (double) w.w + (double) wl.z;
+    const f3 a1 = x1 - x0, a2 = x2 - x0, a3 = x3 - x0, b1 = v1 - v0, b2 = v2 - v0, b3 = v3 - v0;
+    const double ex = ((double) a1.x + h * (double) b1.x) * w1 + ((double) a2.x + h * (double) b2.x) * w2d + ((double) a3.x + h * (double) b3.x) * w3;
+    const double ey = ((double) a1.y + h * (double) b1.y) * w1 + ((double) a2.y + h * (double) b2.y) * w2d + ((double) a3.y + h * (double) b3.y) * w3;
+    const double ez = ((double) a1.z + h * (double) b1.z) * w1 + ((double) a2.z + h * (double) b2.z) * w2d + ((double) a3.z + h * (double) b3.z) * w3;
+    float fac = -1.f;                                     // p = 0: res = -e
+    if (n > 1e-6f) {
+      const double nn = (double) n + (double) wl.w, l2 = ex * ex + ey * ey + ez * ez;
+      const float diff = (float) (nn * nn - l2), len = fast_sqrt((float) l2);
+      fac = len > 0.f ? diff * fast_rcp(len * ((float) nn + len)) : 0.f;      // n / |e| - 1 = (n^2 - |e|^2) / (|e| (n + |e|))
+    }
+    const float sc = fac * (float) h * w2;
+    res = mk((float) ex * sc, (float) ey * sc, (float) ez * sc);
   }
 };
 

@@ -1,12 +1,12 @@
 """Parity gate AT THE CONFIGURATION bench.py MEASURES: the C4 workload (100 x 100 grid, N = 10 000, 256 rollouts, flap folded
 back so that every step carries ~500 loaded self contacts), bench.py's own solver settings (forward_tol 1e-8, cg_rel_tol 1e-4,
 adjoint_mode 1 with adjoint_rel_tol 1e-6, gradient clipping on, self-collision on) and its own code path (dc_rollout_forward /
-dc_seed_gradient / dc_rollout_backward). Eight sampled rollouts over three consecutive time steps are compared, teacher-forced
+dc_seed_gradient / dc_rollout_backward). Sampled rollouts over three consecutive time steps are compared, teacher-forced
 (each step from the GPU's own previous state / carried gradient), against the fp64 oracle run with the direct adjoint solve:
-positions <= 4.5e-5 (1e-5 L); gradients against the oracle at the same settings: median over the samples <= 1.5e-4
-relative (BASELINE.json states 1e-4: measured median 0.7-1.0e-4, see the note at the assertion), upper quartile <= 2.5e-4, every sample <= 1e-3. For scale the test also prints how far
-the oracle at this forward tolerance is from the oracle's own step converged to 1e-13 (1e-2: the PD iteration stops on its update
-norm, ~100 x short of its fixed point) — the two implementations agree with each other 100 x better than either does with that.
+positions <= 4.5e-5 (1e-5 L), contact sets and PD iteration counts identical, and EVERY sampled gradient within
+BASELINE.json's 1e-4 relative of the oracle's (measured round 3: worst 1.2e-5, median 2.3e-6 — round 2 gated 1e-3 per sample
+here; what closed the gap: fp64-strain element operators in the forward step, the unrounded x_new and an fp64-refined solve in the
+adjoint).
 
 Plus the capacity case of VERDICT r01 #7: a 17k-vertex grid with a fold of more than 2048 contacts, pair set and layers
 identical to Simulation::collisionDetection / contactSorting (Simulation.cpp:281-352, 422-624) as restated by the oracle.
@@ -80,14 +80,7 @@ def test_bench_configuration_matches_oracle(B, sample):
     o.add_sphere(center, 2.0, 0.9)
     o.build()
     o.set_force_extras(None, field, 1.0)
-    # the same oracle converged to the fp64 fixed point of the step (forward tolerance 1e-13): the yardstick for what a forward
-    # tolerance of 1e-8 — on either side — leaves undetermined in the gradient
-    ot = orc.Oracle(V, F, h=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, fwd_tol=1e-13, bwd_tol=args.bwd_tol,
-                    selfcollision=True, gradient_clipping=True, threads=threads)
-    ot.add_sphere(center, 2.0, 0.9)
-    ot.build()
-    ot.set_force_extras(None, field, 1.0)
-    worst_x = worst_g = worst_t = worst_o = 0.0
+    worst_x = worst_g = 0.0
     errs = []
     for b in sample:
         o.set_mu(0, float(f32(MU[b, 0])))
@@ -102,34 +95,16 @@ def test_bench_configuration_matches_oracle(B, sample):
             gin, gout = carried[S - 1 - s], carried[S - s]
             rb = o.step_backward(ref["id"], gin[0][b], gin[1][b], is_start=False, direct=True)
             ex, ev = rel(gout[0][b], rb["dL_dx"]), rel(gout[1][b], rb["dL_dv"])
-            ot.set_mu(0, float(f32(MU[b, 0])))
-            ot.clear_records()
-            reft = ot.step(xs[b], vs[b])
-            rt = ot.step_backward(reft["id"], gin[0][b], gin[1][b], is_start=False, direct=True)
-            # error of the GPU and of the oracle-at-the-same-tolerance against the converged step
-            gt_x, ot_x = rel(gout[0][b], rt["dL_dx"]), rel(rb["dL_dx"], rt["dL_dx"])
-            gt_v, ot_v = rel(gout[1][b], rt["dL_dv"]), rel(rb["dL_dv"], rt["dL_dv"])
             print(f"\n[bench parity] rollout {b} step {W + s}: contacts prim {ref['nprim']} self {ref['nself']} ({ref['nlayers']} layers), PD iterations gpu "
-                  f"{fs['pd_iters'][b]} / oracle {ref['iters']}, BiCGSTAB {bs['adjoint_iters'][b]}, max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
-            print(f"    against the step converged to 1e-13: GPU dx {gt_x:.2e} dv {gt_v:.2e} | fp64 oracle at tolerance 1e-8 dx {ot_x:.2e} dv {ot_v:.2e} "
-                  f"(PD iterations {reft['iters']})")
+                  f"{fs['pd_iters'][b]} / oracle {ref['iters']}, BiCGSTAB {bs['adjoint_iters'][b]} in {bs['refine_cycles'][b]} fp32 solves, true residual "
+                  f"{bs['last_udiff'][b]:.1e}, max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
+            assert fs["pd_iters"][b] == ref["iters"], (b, s, fs["pd_iters"][b], ref["iters"])
+            assert bs["converged"][b] == 1 and bs["last_udiff"][b] <= 1.01 * args.adjoint_rel_tol and bs["fp64_iters"][b] == 0
             worst_x, worst_g = max(worst_x, dx), max(worst_g, ex, ev)
-            worst_t, worst_o = max(worst_t, gt_x, gt_v), max(worst_o, ot_x, ot_v)
             assert dx <= 4.5e-5
             errs.append(max(ex, ev))
-            assert ex <= 1e-3 and ev <= 1e-3, (b, s, ex, ev)       # a single (rollout, step): see the note on sliding contacts below
-    print(f"\n[bench parity] worst over {len(sample)} rollouts x {S} steps: max|dx| {worst_x:.2e}; gradient rel err GPU vs oracle at the same tolerance {worst_g:.2e}, "
-          f"GPU vs converged step {worst_t:.2e}, oracle at tolerance 1e-8 vs converged step {worst_o:.2e}; median GPU vs oracle {np.median(errs):.2e}")
-    # BASELINE.json's bound is 1e-4 relative against the CPU reference at the same settings. With ~500 loaded self contacts and
-    # 200-600 sliding sphere contacts per rollout the fp32 adjoint sits AT that bound, not below it: median 0.7-1.0e-4, upper
-    # quartile 1.4e-4 (measured r02i-r02m), single (rollout, step) samples up to 8.8e-4 carried by one vertex — a sliding contact
-    # whose tangential load is ~1e-4 of its normal load, so that the friction direction (and the local Jacobian) is decided by the
-    # last digits of f. The floor is eps_fp32 * cond(K) in the operator's COEFFICIENTS (rest-shape inverses, weights, masses are
-    # fp32 on the device): a tighter Krylov tolerance (1e-6 -> 2e-7) or a recomputed-residual restart leave the error unchanged to
-    # three digits, rounding the oracle's own tape to fp32 changes its gradient by 2e-6 only. For scale: the
-    # reference at this forward tolerance is 1e-2 away from its own converged step (printed above), 100 x more than the two
-    # implementations differ from each other.
-    assert np.median(errs) <= 1.5e-4 and np.percentile(errs, 75) <= 2.5e-4
+            assert ex <= 1e-4 and ev <= 1e-4, (b, s, ex, ev)       # BASELINE.json: gradients within 1e-4 rel-err of the CPU reference
+    print(f"\n[bench parity] worst over {len(sample)} rollouts x {S} steps: max|dx| {worst_x:.2e}; gradient rel err GPU vs oracle {worst_g:.2e}, median {np.median(errs):.2e}")
 
 
 def test_fold_with_more_than_2048_self_contacts_matches_contactSorting():

@@ -5,6 +5,8 @@ The meshes come from tests/golden/meshes.npz (raw OBJ data of the reference's as
 tests/golden/make_fixtures.py); their vertex numbering has bandwidth ~N, so these cases also exercise the engine's
 internal renumbering together with the packet-ELL forward kernel and the LDS element windows.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -46,11 +48,9 @@ def settle(o, x, v, xf, steps, tol=1e-6):
     return f32(x), f32(v)
 
 
-def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, truth=None):
-    """truth: the same oracle at a forward tolerance of 1e-13 (the step's fixed point). Where the PD iteration contracts slowly the
-    stopping rule |x_new - x_now| / N < tol leaves BOTH implementations well short of that fixed point, a few iterations apart
-    from each other; then the meaningful statement is not |gpu - oracle| but each side's distance from the fixed point, and the
-    gate becomes: the GPU is no further from it than 1.5 x the fp64 oracle run at the same tolerance (or within grad_tol)."""
+def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None):
+    """One forward + backward step of the batch; the sampled rollouts against their own fp64 oracle run: contact sets identical,
+    positions within pos_tol, every gradient output within grad_tol (BASELINE.json: 1e-4) of the oracle's direct adjoint."""
     B = len(X0)
     e.alloc_batch(B, 1)
     if mus is not None:
@@ -61,7 +61,7 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, t
     rng = np.random.default_rng(4)
     gx = f32(rng.standard_normal(X0.shape)); gv = f32(rng.standard_normal(X0.shape) * 0.01)
     gb = e.step_backward(1, gx, gv, is_start=False)
-    assert np.all(np.isin(st["converged"], (1, 2))) and np.all(np.isin(gb["converged"], (1, 2)))
+    assert np.all(st["converged"] == 1) and np.all(gb["converged"] == 1)
     worst = dict(dx=0.0, gx=0.0, gv=0.0, gf=0.0)
     for b in sample:
         if mus is not None:
@@ -72,24 +72,12 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, t
         assert st["prim_contacts"][b] == ref["nprim"] and st["self_contacts"][b] == ref["nself"]
         rb = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
         worst["dx"] = max(worst["dx"], np.abs(x1[b] - ref["x"]).max())
-        if truth is not None:
-            if mus is not None:
-                for g in range(mus.shape[1]):
-                    truth.set_mu(g, float(mus[b, g]))
-            rt_ = truth.step(X0[b], V0[b], None if XF is None else XF[b])
-            assert rt_["converged"]
-            tb = truth.step_backward(rt_["id"], gx[b], gv[b], is_start=False, direct=True)
-            for key in ("dL_dx", "dL_dv") + (("dL_dxfixed",) if XF is not None else ()):
-                eg, eo = rel(gb[key][b], tb[key]), rel(rb[key], tb[key])
-                print(f"\n[config] rollout {b} {key}: distance from the step converged to 1e-13 (PD iterations {rt_['iters']}): GPU {eg:.2e}, fp64 oracle at the "
-                      f"same tolerance {eo:.2e} (PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}); GPU vs oracle {rel(gb[key][b], rb[key]):.2e}; "
-                      f"|x - x*| GPU {np.abs(x1[b] - rt_['x']).max():.1e} oracle {np.abs(ref['x'] - rt_['x']).max():.1e}")
-                assert eg <= max(grad_tol, 1.5 * eo), (b, key, eg, eo)
-            continue
-        worst["gx"] = max(worst["gx"], rel(gb["dL_dx"][b], rb["dL_dx"]))
-        worst["gv"] = max(worst["gv"], rel(gb["dL_dv"][b], rb["dL_dv"]))
-        if XF is not None:
-            worst["gf"] = max(worst["gf"], rel(gb["dL_dxfixed"][b], rb["dL_dxfixed"]))
+        egx, egv = rel(gb["dL_dx"][b], rb["dL_dx"]), rel(gb["dL_dv"][b], rb["dL_dv"])
+        egf = rel(gb["dL_dxfixed"][b], rb["dL_dxfixed"]) if XF is not None else 0.0
+        print(f"\n[config] rollout {b}: PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}, contacts prim {ref['nprim']} self {ref['nself']}, "
+              f"BiCGSTAB {gb['adjoint_iters'][b]} in {gb['refine_cycles'][b]} fp32 solves (+ {gb['fp64_iters'][b]} fp64 iterations), true residual {gb['last_udiff'][b]:.1e}; "
+              f"gradient rel err dx {egx:.2e} dv {egv:.2e} dxfixed {egf:.2e}")
+        worst["gx"] = max(worst["gx"], egx); worst["gv"] = max(worst["gv"], egv); worst["gf"] = max(worst["gf"], egf)
     print(f"\n[config] B={B} sampled {list(sample)} pd iters {st['pd_iters'].min()}..{st['pd_iters'].max()} contacts prim "
           f"{st['prim_contacts'].min()}..{st['prim_contacts'].max()} self {st['self_contacts'].max()} | worst max|dx| {worst['dx']:.2e} "
           f"grad rel err dx {worst['gx']:.2e} dv {worst['gv']:.2e} dxfixed {worst['gf']:.2e}")
@@ -108,8 +96,9 @@ def test_c3_hat_batch_64():
     center = f32(scenes.hat_head_center(rmin, rmax, cfg["sphere_radius"]))
     att = cfg["attachments"]
     # forward threshold 1e-8 as hatController.py:83; this stiff scene (k_bend 120, k_att 1e4) contracts at ~0.995 per PD
-    # iteration, so the stopping rule leaves both sides short of the step's fixed point and a few iterations apart from each
-    # other; what is gated is each side's distance from that fixed point (see check_rollouts)
+    # iteration: a rounding of the iterate is amplified 200 x on its way to the stopping point (an fp32 velocity iterate alone
+    # accounts for 1e-6 in x_new and one or two PD iterations, emulated in the oracle: tests/analyze_dump.py).
+    # The gate is nevertheless the plain one: GPU against the oracle at the same tolerance, 1e-4 (measured 1.9e-5 ... 8.7e-5)
     o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-8,
                    bwd_tol=1e-9, attachments=att, selfcollision=False, gradient_clipping=False)
     o.add_sphere(center, cfg["sphere_radius"], cfg["sphere_mu"])
@@ -129,12 +118,7 @@ def test_c3_hat_batch_64():
     V0 = np.stack([f32(v + 0.01 * rng.standard_normal(x.size)) for _ in range(B)])
     XF = np.stack([f32(xf + np.tile([0.0, -0.05, -0.3], 2) + 0.02 * rng.standard_normal(6)) for _ in range(B)])
     mus = f32(rng.uniform(0.05, 0.6, (B, 1)))
-    # measure instead of assert — both sides against the step's fixed point (oracle at 1e-13)
-    ot = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-13,
-                    bwd_tol=1e-9, attachments=att, selfcollision=False, gradient_clipping=False, pd_iter_cap=40000)
-    ot.add_sphere(center, cfg["sphere_radius"], cfg["sphere_mu"])
-    ot.build()
-    check_rollouts(o, e, X0, V0, XF, sample=(0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus, truth=ot)
+    check_rollouts(o, e, X0, V0, XF, sample=(0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus)
 
 
 def test_c5_sock_batch_512():
@@ -202,23 +186,26 @@ def test_c4_dress_self_contact_batch(mesh="dress", B=8, sample=(0, 7)):
     X0 = np.stack([f32((X + 0.0005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
     V0 = np.stack([f32((vel + 0.005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
     XF = np.stack([f32(X[top].reshape(-1)) for _ in range(B)])
-    st = check_rollouts(o, e, X0, V0, XF, sample=sample, pos_tol=8e-5, grad_tol=2e-4)
+    st = check_rollouts(o, e, X0, V0, XF, sample=sample, pos_tol=8e-5, grad_tol=1e-4)
     assert st["self_contacts"].min() > 20
 
 
-def test_dress_7742_vertices_forward_step_and_honest_adjoint_status():
+def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
     """The reference's finer dress (src/assets/meshes/remeshed/dress-v7k-f14k.obj, 7 742 vertices) in the same squashed pose: 438 self
-    contacts, a very ill-conditioned step (434 PD iterations, ~290 PCG iterations each at 1e-6). The forward step reproduces the fp64
-    oracle (positions, contact set, PD iteration count). The adjoint system of this compressed fine mesh is beyond an fp32 Krylov
-    solve — the reference factorises it in fp64 (solveDirect, Simulation.cpp:1431-1440), BiCGSTAB stalls at a relative residual of
-    ~3e-2 — and the engine has to SAY so: converged = 0 in the statistics, finite output, no silent garbage."""
+    contacts in 287 layers, a very ill-conditioned step (434 PD iterations). The forward step reproduces the fp64 oracle (positions,
+    contact set, PD iteration count). Its adjoint system is beyond an fp32 Krylov solve (compressed fine sheets: cond(K) = 3e7, K
+    indefinite — the fp32 BiCGSTAB diverges; the reference factorises it in fp64, solveDirect, Simulation.cpp:1431-1440): the engine
+    must notice (no progress of the TRUE residual), switch to its fp64 BiCGSTAB on the same operator and return a CONVERGED solve
+    (round 2 returned converged = 0 here). What remains against the oracle's gradient sits in the ~20 vertices of the buckling
+    region where K is nearly singular (99 % of the difference; everywhere else <= 2e-3): there a 1e-9 difference of the forward
+    states moves the solution by percents, on either side."""
     V, F = scenes.load_mesh("dress7k")
     cfg = dict(h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
     P, rmin, rmax = scenes.normalise_model(V, "FRONT", 8.0)
     P = f32(P)
     top = np.argsort(-P[:, 1])[:6].tolist()
     o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-8,
-                   bwd_tol=1e-9, attachments=top, selfcollision=True, contact=True, gradient_clipping=False)
+                   bwd_tol=1e-9, attachments=top, selfcollision=True, contact=True, gradient_clipping=False, threads=min(os.cpu_count() or 1, 32))
     o.build()
     e = engine_for(P, F, cfg, [], top, True, 1e-8)
     lay = e.layout()
@@ -245,8 +232,18 @@ def test_dress_7742_vertices_forward_step_and_honest_adjoint_status():
     assert dx <= 8e-5
     gx = f32(rng.standard_normal(x0.shape)); gv = f32(0.01 * rng.standard_normal(x0.shape))
     gb = e.step_backward(1, gx, gv, is_start=False)
-    print(f"[dress 7742] adjoint: converged {gb['converged'][0]}, BiCGSTAB iterations {gb['adjoint_iters'][0]}, relative residual {gb['last_udiff'][0]:.2e}")
+    rb = o.step_backward(ref["id"], gx[0], gv[0], is_start=False, direct=True)
+    N = P.shape[0]
+    d = (gb["dL_dx"][0] - rb["dL_dx"]).reshape(N, 3)
+    per_vertex = np.sqrt((d ** 2).sum(axis=1))
+    order = np.argsort(-per_vertex)
+    share = (per_vertex[order[:30]] ** 2).sum() / max((per_vertex ** 2).sum(), 1e-300)
+    rest = np.ones(N, dtype=bool); rest[order[:30]] = False
+    err_rest = np.linalg.norm(d[rest]) / np.linalg.norm(rb["dL_dx"].reshape(N, 3)[rest])
+    print(f"[dress 7742] adjoint: converged {gb['converged'][0]}, fp32 BiCGSTAB {gb['adjoint_iters'][0]} iterations in {gb['refine_cycles'][0]} solve(s), fp64 fall-back "
+          f"{gb['fp64_iters'][0]} iterations, true relative residual {gb['last_udiff'][0]:.1e}; gradient rel err dx {rel(gb['dL_dx'][0], rb['dL_dx']):.2e} dv "
+          f"{rel(gb['dL_dv'][0], rb['dL_dv']):.2e}; share of the difference in its 30 largest vertices {share:.3f}, rel err outside them {err_rest:.2e}")
+    assert gb["converged"][0] == 1 and gb["fp64_iters"][0] > 0          # solved — by the fp64 fall-back
+    assert gb["last_udiff"][0] <= 1e-7                                   # the caller's tolerance (engine_for), on the residual evaluated in fp64
     assert np.isfinite(gb["dL_dx"]).all() and np.isfinite(gb["dL_dv"]).all()
-    assert not (gb["converged"][0] == 1 and gb["last_udiff"][0] > 1e-6)      # "converged" is only ever claimed for a solved system
-    if gb["converged"][0] == 0:
-        assert gb["last_udiff"][0] > 1e-7                                      # gave up (cap or breakdown) and reports the residual it stopped at
+    assert rel(gb["dL_dx"][0], rb["dL_dx"]) <= 6e-2 and share >= 0.95 and err_rest <= 5e-3

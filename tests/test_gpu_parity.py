@@ -332,9 +332,9 @@ def test_parameter_gradients_match_oracle(mu):
     ew = np.linalg.norm(dwind - rb["dL_dwind"]) / np.linalg.norm(rb["dL_dwind"])
     print(f"\n[param grads mu={mu}] dL_dk gpu {pg['dL_dk'][0]} ref {rb['dL_dk']} rel {ek}; ddensity gpu {pg['dL_ddensity'][0]:.6e} ref {rb['dL_ddensity']:.6e}"
           f" rel {ed:.2e}; dwind rel {ew:.2e}")
-    # sums of signed per-element terms: fp32 rounding of the residual A^T(p - A x) (a small difference of O(1)
-    # quantities near equilibrium) bounds these at ~1e-3 relative
-    assert np.all(ek <= 5e-3) and ed <= 1e-3 and ew <= 1e-4
+    # BASELINE.json's 1e-4 on every output (round 2 gated 5e-3 / 1e-3 here: the sums are now accumulated in fp64 from the fp64
+    # rest-shape tables, Simulation.cpp:1672-1699)
+    assert np.all(ek <= 1e-4) and ed <= 1e-4 and ew <= 1e-4
 
 
 def test_capped_runs_return_the_best_iterate_like_the_reference():
