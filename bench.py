@@ -288,62 +288,89 @@ def main():
         rank_ms = [float(v) for v in tr.tolist()]
 
     kt = e.kernel_times()
-    # iteration statistics of the timed steps (needed for the algorithmic-byte count)
-    pd = cg_f = adj = cg_b = selfc = 0.0
+    # iteration statistics of the timed steps (needed for the byte / cycle models)
+    pd = cg_f = adj = cg_b = selfc = cyc = it64 = 0.0
     conv = 0
     for s in range(W + 1, W + K + 1):
         fs, bs = e.get_stats(s)
         pd += fs["pd_iters"].sum(); cg_f += fs["cg_iters"].sum(); conv += int((fs["converged"] > 0).sum())
         selfc += fs["self_contacts"].sum()
-        adj += bs["adjoint_iters"].sum(); cg_b += bs["cg_iters"].sum()
-    N = e.N
-    # ALGORITHMIC bytes (fp32, per rollout; SURVEY.md §8d, DESIGN.md "Roofline model"): what ONE streaming pass per vector sweep
-    # would move if nothing stayed on chip.
-    #   forward  (108 * I_pd + 132 * I_cg) * N
-    #   backward, mode 0 (reference iteration)  72 N + (24 * I_adj + 132 * I_cg) * N
-    #   backward, mode 1 (BiCGSTAB on K)        72 N + 388 * I_adj * N   (2 operator applications x 108 B + 172 B of vector updates)
-    bytes_fwd = (108.0 * pd + 132.0 * cg_f) * N
-    if args.adjoint_mode == 1:
-        bytes_bwd = (72.0 * B * K + 388.0 * adj) * N
-    else:
-        bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b) * N
+        adj += bs["adjoint_iters"].sum(); cg_b += bs["cg_iters"].sum(); cyc += bs["refine_cycles"].sum(); it64 += bs["fp64_iters"].sum()
+    N, T, E = e.N, e.T, e.E
     cl = e.cluster() if hasattr(e, "cluster") else 1
+    # ---- roofline models (DESIGN.md "Roofline model"), per launch = the K timed steps of the rank's B rollouts ----
+    # Forward kernel: the PCG vectors live in LDS / registers, so what the design HAS to move through HBM is the PD-level state only:
+    #   compulsory bytes  108 * I_pd * N  (x_n, v, g, f, r, contact record per PD iteration) + 64 * N per step of tape
+    # and the resource its inner loop loads is the LDS array. LDS-array cycles per CU (MI355X_MICROARCH.md LDS table: ds_read_b32 / b64
+    # 2 cycles per wave-instruction, ds_write_b32 / b64 2 / 4):
+    #   per CG iteration   rows/64 * (12 neighbours * (2 + 2) + 14 for reading / rewriting p and the LDS part of x)
+    #   per PD iteration   staging 12 * 1.15 N/64 + triangles (6 * 4 + 12) * T/64 + flaps (8 * 4 + 6) * E/64 + vertex gather 24 * 4 * N/64
+    # The streaming model of SURVEY.md section 8d ((108 I_pd + 132 I_cg) N: every CG vector through HBM) is kept as a number for reference;
+    # it is what the resident design AVOIDS, not a roof for it.
+    # Adjoint kernel: its Krylov vectors do stream through HBM — 72 N per step + 388 N per BiCGSTAB iteration (2 operator applications
+    # x 108 B + 172 B of vector updates) + 96 N per fp64 residual evaluation + 100 N per step of fp64 gradient assembly.
+    rows64 = (N + 63) // 64
+    bytes_fwd = (108.0 * pd + 64.0 * B * K) * N
+    bytes_fwd_stream = (108.0 * pd + 132.0 * cg_f) * N
+    lds_cycles_fwd = (cg_f * rows64 * (12 * 4 + 14) + pd * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 96.0 * rows64)) / max(B * cl, 1)
+    if args.adjoint_mode == 1:
+        bytes_bwd = (72.0 * B * K + 388.0 * adj + 96.0 * cyc + 100.0 * B * K) * N
+    else:
+        bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b + 100.0 * B * K) * N
+    lds_cycles_bwd = (2.0 * adj + cyc) * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 96.0 * rows64) / max(B * cl, 1)
+    try:
+        clock_hz = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
+    except Exception:
+        clock_hz = 2.4e9
     key = config_key(args, B, K, W, N)
-    profiles = load_profiles() if world == 1 else []
+    profiles = load_profiles()
 
-    def kernel_entry(name, nbytes, ms, launches):
-        # one launch = the K timed steps of (a chunk of) the B rollouts (dc_rollout_* runs a rollout's steps inside one launch).
-        # `frac` is the fraction of the HBM peak the kernel's MEASURED fabric traffic amounts to (<= 1 by construction):
-        # calibrated FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc passes in profiles/ — of this very configuration when the
-        # profile was taken with it, otherwise the profiled traffic-per-algorithmic-byte ratio applied to this run's algorithmic
-        # bytes. The streaming model (`algorithmic_*`) is reported next to it: for a kernel that keeps its inner solver on chip
-        # it exceeds what HBM could deliver, which is the point of keeping it on chip, not a fraction of anything.
+    def kernel_entry(name, nbytes, lds_cycles, ms, launches, extra):
+        """Contract fields: achieved = algorithmic bytes of the launch / its duration (HIP events on the context's stream,
+        dc_kernel_times), frac = achieved / HBM peak. Next to them the LDS side (modelled LDS-array cycles per CU / kernel cycles)
+        and, when profiles/ holds a rocprofv3 --pmc profile, the MEASURED quantities: fabric traffic (calibrated FETCH_SIZE +
+        WRITE_SIZE; of this very configuration, else that profile's traffic per algorithmic byte applied to this run and said so),
+        LDS-array / VALU busy fractions, share of wave cycles spent waiting. Every fraction is <= 1 by construction."""
         sec = max(ms * 1e-3, 1e-12)
         ent = {"kernel": name, "avg_launch_ms": ms / max(launches, 1), "launches": launches, "steps_per_launch": K / max(launches, 1),
-               "ms_per_step": ms / K, "algorithmic_bytes": nbytes, "algorithmic_rate_gbs": nbytes / sec / 1e9,
-               "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "achieved": None, "frac": None, "traffic_source": None,
-               "lds_frac": None, "valu_frac": None, "wait_frac": None}
+               "ms_per_step": ms / K, "algorithmic_bytes": nbytes, "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS,
+               "lds_model_cycles_per_cu": lds_cycles, "lds_frac_model": lds_cycles / (sec * clock_hz), "clock_hz": clock_hz,
+               "traffic": None, "traffic_frac": None, "traffic_source": None, "lds_frac": None, "lds_conflict_share": None,
+               "valu_frac": None, "wait_frac": None, "scratch_write_bytes": None}
+        ent.update(extra)
         prof, exact = profile_for(profiles, key, name)
         if prof:
             pk = prof["kernels"][name]
-            # a profile of this configuration taken with other kernels (its launch time is off by > 10 %) only lends its traffic per
-            # algorithmic byte, like a profile of another configuration
-            if exact and abs(pk["launch_ms_total"] - ms) > 0.1 * ms:
+            if exact and abs(pk["launch_ms_total"] - ms) > 0.1 * ms:       # same configuration, other kernels: lends ratios only
                 exact = False
+            pa = max(pk.get("algorithmic_bytes", 0.0), 1.0)
             if exact:
                 traffic, src = pk["hbm_bytes"], f"{prof['file']} (this configuration)"
             else:
-                traffic = nbytes * pk["hbm_bytes"] / max(pk["algorithmic_bytes"], 1.0)
+                traffic = nbytes * pk["hbm_bytes"] / pa
                 src = f"{prof['file']} (profiled at {prof.get('config_key')}: its traffic per algorithmic byte applied to this run)"
-            ent.update(traffic=traffic / max(launches, 1), achieved=traffic / sec / 1e9, frac=traffic / sec / 1e9 / HBM_PEAK_GBS,
-                       traffic_source=src, lds_frac=pk.get("lds_frac"), valu_frac=pk.get("valu_frac"), wait_frac=pk.get("wait_frac"))
+            ent.update(traffic=traffic / max(launches, 1), traffic_frac=min(traffic / sec / 1e9 / HBM_PEAK_GBS, 1.0), traffic_source=src,
+                       lds_frac=pk.get("lds_frac"), lds_conflict_share=pk.get("lds_conflict_share"), valu_frac=pk.get("valu_frac"),
+                       wait_frac=pk.get("wait_frac"))
+            if pk.get("scratch_write_bytes") is not None:
+                ent["scratch_write_bytes"] = pk["scratch_write_bytes"] * (1.0 if exact else nbytes / pa) / max(launches, 1)
+        # the binding resource: the largest of the fractions known for this kernel (measured ones where there are any)
+        cand = {"hbm": ent["traffic_frac"] if ent["traffic_frac"] is not None else ent["frac"],
+                "lds": ent["lds_frac"] if ent["lds_frac"] is not None else ent["lds_frac_model"]}
+        if ent["valu_frac"] is not None:
+            cand["valu"] = ent["valu_frac"]
+        ent["bound"] = max(cand, key=cand.get)
+        ent["bound_frac"] = cand[ent["bound"]]
         return ent
-    k_fwd = kernel_entry("k_pd_step_cl" if cl > 1 else "k_pd_step_pk", bytes_fwd, kt["fwd_ms"], kt["fwd_launches"])
-    k_bwd = kernel_entry("k_adjoint_step_cl" if cl > 1 else "k_adjoint_step", bytes_bwd, kt["bwd_ms"], kt["bwd_launches"])
+    k_fwd = kernel_entry("k_pd_step_cl" if cl > 1 else "k_pd_step_pk", bytes_fwd, lds_cycles_fwd, kt["fwd_ms"], kt["fwd_launches"],
+                         {"streaming_model_bytes": bytes_fwd_stream, "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
+                          "model": "compulsory HBM bytes of the resident design: (108 I_pd + 64 per step) N; CG vectors never leave the CU"})
+    k_bwd = kernel_entry("k_adjoint_step_cl" if cl > 1 else "k_adjoint_step", bytes_bwd, lds_cycles_bwd, kt["bwd_ms"], kt["bwd_launches"],
+                         {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + 48.0 * cyc + 60.0 * B * K) * N,
+                          "model": "Krylov vectors stream through HBM: (72 + 100) N per step + 388 N per BiCGSTAB iteration + 96 N per fp64 residual"})
     dom = dict(k_fwd if kt["fwd_ms"] >= kt["bwd_ms"] else k_bwd)
-    fr = {"hbm": dom["frac"], "lds": dom["lds_frac"], "valu": dom["valu_frac"]}
-    known = {k: v for k, v in fr.items() if v is not None}
-    bound = max(known, key=known.get) if known else "hbm"
+    bound = dom["bound"]
     dx, dv, dmu = e.get_gradient()
     finite = bool(np.isfinite(dx).all() and np.isfinite(dv).all())
 
@@ -364,7 +391,9 @@ def main():
                        "adjoint_rel_tol": args.adjoint_rel_tol, "adjoint_block_precond": args.block_precond, "selfcollision": bool(args.selfcollision),
                        "mean_self_contacts_per_step": selfc / (B * K),
                        "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
-                       "mean_adjoint_iters_per_step": adj / (B * K), "converged_fraction": conv / (B * K),
+                       "mean_adjoint_iters_per_step": adj / (B * K), "mean_fp32_solves_per_adjoint": cyc / (B * K),
+                       "fp64_fallback_iters": it64, "adjoint_precision": "mixed: fp32 BiCGSTAB corrections of the fp64 residual",
+                       "converged_fraction": conv / (B * K),
                        "batch_steps_per_s": K / dt, "gradients_finite": finite,
                        "dL_dmu_sum_over_job": float(np.asarray(dmu_total).sum()),
                        "per_rank_sweep_ms": rank_ms, "allreduce_ms": t_reduce * 1e3,
@@ -373,7 +402,7 @@ def main():
             "roofline": {"bound": bound, **dom, "kernels": [k_fwd, k_bwd]},
         }
         ncpu = K if args.cpu_steps < 0 else args.cpu_steps
-        if world == 1 and ncpu > 0:
+        if ncpu > 0:      # rank 0, at every N: the same rollout 0 of the job
             xw, vw = e.get_state(W)
             out["cpu_baseline"] = cpu_baseline(args, V, F, center, field, xw[0], vw[0], MU[0, 0], ncpu, gscale)
         if world == 1 and args.tshirt:

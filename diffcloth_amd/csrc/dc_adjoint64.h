@@ -96,6 +96,21 @@ struct TeamOne {
 template <class YV> __device__ __forceinline__ d3 ld3y(const YV &a, int i, int n) { return mkd(a.ld(i), a.ld(n + i), a.ld(2 * n + i)); }
 template <class YV> __device__ __forceinline__ void st3y(const YV &a, int i, int n, d3 v) { a.st(i, v.x); a.st(n + i, v.y); a.st(2 * n + i, v.z); }
 
+// 1 / sqrt(x) and 1 / x in fp64 from the hardware estimates (v_rsq_f64, v_rcp_f64) + two Newton steps (relative error < 1e-15 for
+// normal x): the IEEE expansions of sqrt() and '/' cost ~40 instructions each, and the fp64 operator needs three per triangle.
+__device__ __forceinline__ double rsqrt_d(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(y * fma(0.375, e, 0.5), e, y);
+  e = fma(-x * y, y, 1.0);
+  return fma(0.5 * y, e, y);
+}
+__device__ __forceinline__ double rcp_d(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+
 // ---- closed forms in fp64 (same formulas as dc_devlib.h / dc_winlib.h) ----
 struct PolarD {
   d3 t0, t1;
@@ -104,7 +119,7 @@ struct PolarD {
 __device__ __forceinline__ PolarD polar3x2d(d3 f0, d3 f1) {
   const double a = dot(f0, f0), b = dot(f0, f1), c = dot(f1, f1);
   const double det = fmax(a * c - b * b, 1e-300);
-  const double s = sqrt(det), t = sqrt(a + c + 2.0 * s), inv = 1.0 / (t * s);
+  const double s = det * rsqrt_d(det), tt = a + c + 2.0 * s, t = tt * rsqrt_d(tt), inv = rcp_d(t * s);
   PolarD P;
   P.i00 = (c + s) * inv; P.i01 = -b * inv; P.i11 = (a + s) * inv; P.trS = t;
   P.t0 = f0 * P.i00 + f1 * P.i01;
@@ -269,7 +284,7 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const YV &X, c
   for (int k = S.inc_ptr[i]; k < k1; k++) {
     const int idx = S.inc_idx[k];
     if (idx < 3 * T) {
-      const int corner = idx / T, t = idx - corner * T;
+      const int corner = (idx >= T) + (idx >= 2 * T), t = idx - corner * T;       // (no integer division in the gather)
       const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
       const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
       const d3 x0 = ld3y(X, i0, N);
@@ -278,7 +293,7 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const YV &X, c
       const d3 q0 = ld3y(Y, i0, N);
       const d3 d0 = ld3y(Y, i1, N) - q0, d1 = ld3y(Y, i2, N) - q0;
       const d3 y0 = d0 * Dx + d1 * Dz, y1 = d0 * Dy + d1 * Dw;
-      const double c = (dot(P.t1, y0) - dot(P.t0, y1)) / P.trS;
+      const double c = (dot(P.t1, y0) - dot(P.t0, y1)) * rcp_d(P.trS);
       d3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
       z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
       z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
@@ -287,7 +302,7 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const YV &X, c
       const d3 c1 = r0 * Dx + r1 * Dy, c2 = r0 * Dz + r1 * Dw;
       acc = acc + (corner == 1 ? c1 : (corner == 2 ? c2 : mkd(0, 0, 0) - c1 - c2));
     } else {
-      const int q = idx - 3 * T, corner = q / E, e = q - corner * E;
+      const int q = idx - 3 * T, corner = (q >= E) + (q >= 2 * E) + (q >= 3 * E), e = q - corner * E;
       const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
       const double w0 = S.bend_w64[e], w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
       const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
@@ -297,9 +312,9 @@ __device__ __forceinline__ d3 element_terms64(const DevSystem &S, const YV &X, c
       if (nrest > 1e-6) {
         const d3 x0 = ld3y(X, i0, N);
         const d3 ev = (ld3y(X, i1, N) - x0) * w1 + (ld3y(X, i2, N) - x0) * w2 + (ld3y(X, i3, N) - x0) * w3;
-        const double en = sqrt(dot(ev, ev));
-        const d3 eh = ev * (1.0 / en);
-        res = ey - (ey - eh * dot(eh, ey)) * (nrest / en);
+        const double ien = rsqrt_d(dot(ev, ev));
+        const d3 eh = ev * ien;
+        res = ey - (ey - eh * dot(eh, ey)) * (nrest * ien);
       }
       res = res * (h2 * wsq);
       acc = acc + res * (corner == 0 ? w0 : (corner == 1 ? w1 : (corner == 2 ? w2 : w3)));
@@ -486,7 +501,7 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
       const d3 x0 = ld3y(X, i0, N);
       const d3 ev = (ld3y(X, i1, N) - x0) * w1 + (ld3y(X, i2, N) - x0) * w2 + (ld3y(X, i3, N) - x0) * w3;
       d3 p = mkd(0, 0, 0);
-      if (nrest > 1e-6) { const double n2 = dot(ev, ev); p = n2 > 0 ? ev * (nrest / sqrt(n2)) : ev * nrest; }
+      if (nrest > 1e-6) { const double n2 = dot(ev, ev); p = n2 > 0 ? ev * (nrest * rsqrt_d(n2)) : ev * nrest; }
       const d3 q0 = ld3y(Y, i0, N);
       const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
       pacc[1] += dot((p - ev) * wsq, ey);

@@ -162,7 +162,6 @@ struct FwdArgs {
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
-  int precise_all;              // element operators of the local step: 1 = fp64 strain (dc_winlib.h: HybridTriOp, the default), 0 = fp32, 2 = fp64
   int cg_seed;                  // packet / split kernels: first search direction of a solve = the previous PD iteration's correction
   // several consecutive steps in one launch (packet kernel only): step s uses tape slot k + s
   int nsteps, inline_detect;    // inline_detect: run the self-collision detection of every step inside the kernel

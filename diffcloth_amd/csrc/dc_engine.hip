@@ -192,7 +192,6 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   static const bool seed_on = !(getenv("DC_CG_SEED") && getenv("DC_CG_SEED")[0] == '0');     // development switch
   A.cg_seed = seed_on ? 1 : 0;
-  { const char *envp = getenv("DC_PRECISE_ALL"); A.precise_all = envp ? atoi(envp) : 1; }     // (development switch: 0 fp32 element operators, 2 fp64)
   A.nsteps = 1; A.inline_detect = 0; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
   A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   return A;

@@ -160,10 +160,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       st3(scr, i, N, rhs);
       psum += dot(rhs, rhs);
     };
-    // element operators: fp64 strain by default (dc_winlib.h: HybridTriOp), see dc_forward_pk.hip
-    if (A.precise_all == 1) element_windows_t<THREADS, true>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, HybridTriOp{S.h64}, HybridBendOp{S.h64}, vert);
-    else if (A.precise_all == 2) element_windows_t<THREADS, true>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, vert);
-    else element_windows_t<THREADS>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, FwdTriOp{h}, FwdBendOp{h}, vert);
+    element_windows_t<THREADS, kFwdOpsPrecise>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
     __syncthreads();
     CPH(0)
     X.site = 4;

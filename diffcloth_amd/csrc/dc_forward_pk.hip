@@ -147,11 +147,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         st3(scr, i, N, rhs);
         part += dot(rhs, rhs);
       };
-      // element operators: fp64 strain by default (dc_winlib.h: HybridTriOp — +1 % on the 10k-vertex workload for 30 x smaller
-      // gradient differences against the fp64 reference, measured r03d); 0 = all-fp32, 2 = all-fp64 (A/B switches)
-      if (A.precise_all == 1) element_windows<THREADS, true>(S, lp, StagePlanar{xn, N}, vnow, HybridTriOp{S.h64}, HybridBendOp{S.h64}, vert);
-      else if (A.precise_all == 2) element_windows<THREADS, true>(S, lp, StagePlanar{xn, N}, vnow, PreciseTriOp{S.h64}, PreciseBendOp{S.h64}, vert);
-      else element_windows<THREADS>(S, lp, StagePlanar{xn, N}, vnow, FwdTriOp{h}, FwdBendOp{h}, vert);
+      element_windows<THREADS, kFwdOpsPrecise>(S, lp, StagePlanar{xn, N}, vnow, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
       __syncthreads();
       PH(0)
       for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread (clamped index), then the LDS stores

@@ -305,6 +305,26 @@ struct HybridBendOp {
   }
 };
 
+// The element operators of the forward local step, chosen at COMPILE time (a run-time choice inside the PD loop cost 1.5 ms of 23 on
+// the 10k-vertex workload through the register allocation of the loop, measured r03d / r03e): fp64 strain by default, -DDC_ELEMENT_OPS=0
+// the all-fp32 operators of rounds 1-2, =2 the all-fp64 ones (A/B builds).
+#ifndef DC_ELEMENT_OPS
+#define DC_ELEMENT_OPS 1
+#endif
+#if DC_ELEMENT_OPS == 0
+constexpr bool kFwdOpsPrecise = false;
+__device__ __forceinline__ FwdTriOp fwd_tri_op(float h, double) { return FwdTriOp{h}; }
+__device__ __forceinline__ FwdBendOp fwd_bend_op(float h, double) { return FwdBendOp{h}; }
+#elif DC_ELEMENT_OPS == 2
+constexpr bool kFwdOpsPrecise = true;
+__device__ __forceinline__ PreciseTriOp fwd_tri_op(float, double h) { return PreciseTriOp{h}; }
+__device__ __forceinline__ PreciseBendOp fwd_bend_op(float, double h) { return PreciseBendOp{h}; }
+#else
+constexpr bool kFwdOpsPrecise = true;
+__device__ __forceinline__ HybridTriOp fwd_tri_op(float, double h) { return HybridTriOp{h}; }
+__device__ __forceinline__ HybridBendOp fwd_bend_op(float, double h) { return HybridBendOp{h}; }
+#endif
+
 // ---- adjoint: a = y, b = x_new; h^2 w^2 (A - dp/dx)^T A y per element ----
 struct AdjTriOp {   // Triangle::projectToManifoldBackward (Triangle.cpp:354-451) in closed form
   float h2;

@@ -66,7 +66,9 @@ def main(out, tag):
              "algorithmic_bytes": ent["algorithmic_bytes"], "launch_ms_total": ent["avg_launch_ms"] * n,
              "hbm_frac": hbm / (ent["avg_launch_ms"] * n * 1e-3) / 8e12 if hbm else None,
              "lds_frac": lds / (32.0 * g1) if g1 else None, "lds_conflict_share": conf / lds if lds else None,
-             "valu_frac": 4.0 * valu / (128.0 * g2) if g2 else None, "wait_frac": wany / wcyc_c if wcyc_c else None}
+             "valu_frac": 4.0 * valu / (128.0 * g2) if g2 else None, "wait_frac": wany / wcyc_c if wcyc_c else None,
+             # what the kernel writes beyond the stores its algorithm needs (bench.py: compulsory_write_bytes): register spills to scratch
+             "scratch_write_bytes": max(wr * 1024.0 / w4 - ent["compulsory_write_bytes"], 0.0) if "compulsory_write_bytes" in ent else None}
         res["kernels"][name] = k
         print(name, json.dumps(k))
     path = os.path.join(out, f"{tag}_roofline.json")
