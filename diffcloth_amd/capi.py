@@ -53,6 +53,7 @@ EXPORTED_SYMBOLS = [
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
     "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout", "dc_comm_unique_id", "dc_comm_init", "dc_allreduce_sum", "dc_comm_destroy",
+    "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
 ]
 
 _lib = None
@@ -262,6 +263,44 @@ class Engine:
         out = dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:, :3 * self.Af], dL_dmu=dmu)
         out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters"]))
         return out
+
+    # ---- device-pointer boundary (torch tensors on this GPU: no host copies, no synchronisation) ----
+    @staticmethod
+    def _tp(t, per):
+        """(device pointer, is_f32) of a contiguous CUDA tensor of B * per elements, fp32 or fp64"""
+        import torch
+        if t is None:
+            return None, 1
+        if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64) or t.numel() != per:
+            raise ValueError(f"expected a contiguous CUDA float32 / float64 tensor of {per} elements, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        return C.c_void_p(t.data_ptr()), int(t.dtype == torch.float32)
+
+    def use_stream(self, stream=None):
+        """run the context on a torch.cuda.Stream (None: back to its own stream)"""
+        self._chk(self.lib.dc_use_stream(self.h, C.c_void_p(stream.cuda_stream) if stream is not None else None))
+
+    def set_state_dev(self, slot, x, v):
+        px, f = self._tp(x, self.B * 3 * self.N); pv, f2 = self._tp(v, self.B * 3 * self.N)
+        assert f == f2, "x and v must have one dtype"
+        self._chk(self.lib.dc_set_state_dev(self.h, C.c_int(slot), px, pv, C.c_int(f)))
+
+    def get_state_dev(self, slot, x, v):
+        px, f = self._tp(x, self.B * 3 * self.N); pv, f2 = self._tp(v, self.B * 3 * self.N)
+        assert f == f2, "x and v must have one dtype"
+        self._chk(self.lib.dc_get_state_dev(self.h, C.c_int(slot), px, pv, C.c_int(f)))
+
+    def step_forward_dev(self, slot, fixed_pts=None):
+        p, f = self._tp(fixed_pts, self.B * 3 * self.Af)
+        self._chk(self.lib.dc_step_forward_dev(self.h, C.c_int(slot), p, C.c_int(f)))
+
+    def step_backward_dev(self, slot, gx, gv, dx, dv, dxfixed=None, dmu=None, ix=None, iv=None, is_start=False):
+        n = self.B * 3 * self.N
+        pgx, f = self._tp(gx, n); pgv, _ = self._tp(gv, n); pdx, f3_ = self._tp(dx, n); pdv, _ = self._tp(dv, n)
+        pix, _ = self._tp(ix, n); piv, _ = self._tp(iv, n)
+        pxf, _ = self._tp(dxfixed, self.B * 3 * self.Af); pmu, _ = self._tp(dmu, self.B * self.ngroups)
+        for t in (gv, dx, dv, ix, iv, dxfixed, dmu):
+            assert t is None or t.dtype == gx.dtype, "all tensors of a call must have one dtype"
+        self._chk(self.lib.dc_step_backward_dev(self.h, C.c_int(slot), pgx, pgv, pix, piv, C.c_int(int(is_start)), pdx, pdv, pxf, pmu, C.c_int(f)))
 
     # ---- device-resident rollouts ----
     def rollout_forward(self, slot, nsteps):

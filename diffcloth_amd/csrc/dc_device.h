@@ -206,6 +206,9 @@ void launch_self_detect(const DevSystem &S, const DevWork &W, const FwdArgs &A, 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);
 void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, const int *user_of, hipStream_t st);
 void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, const int *user_of, hipStream_t st);
+void launch_dev_to_planar(const void *src, int is_f32, float *dst, int B, int n, const int *user_of, hipStream_t st);
+void launch_planar_to_dev(const float *src, void *dst, int is_f32, int B, int n, const int *user_of, hipStream_t st);
+void launch_copy_cast(const float *src, void *dst, int is_f32, long total, hipStream_t st);
 void launch_seed_gradient(const float *x, const float *target, float *gx, float *gv, int B, int N, float scale, hipStream_t st);
 
 }  // namespace dc

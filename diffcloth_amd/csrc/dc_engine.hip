@@ -1,7 +1,16 @@
 // C-ABI layer of libdiffcloth_hip.so: context, device memory, tape, and the calls that enqueue the
 // persistent step kernels. See include/diffcloth_hip.h for the contract of every entry point.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>      // types only: the library is bound with dlopen in dc_comm_* (no link-time dependency)
+// RCCL is bound with dlopen in dc_comm_* (no link-time and no header dependency): the handful of types and constants of its C API
+// (rccl.h / nccl.h) the four entry points used here need, restated
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat64 = 8 } ncclDataType_t;      // ncclDouble
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+}
 #include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
@@ -36,6 +45,7 @@ struct dc_ctx {
   int device = 0;
   bool host_only = false;   // dc_create(-1): table building / inspection only, every compute call fails
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr; // the stream dc_create made (dc_use_stream may point `stream` at the caller's)
   std::string err;
   HostSystem host;
   dc_params params;
@@ -252,6 +262,12 @@ int upload_cl(dc_ctx *c, const T **out, const std::vector<U> &src) {
   return DC_OK;
 }
 
+// Rollouts one launch of the split kernels can hold with EVERY workgroup resident (the exchange spins on its peers: a part that is not
+// scheduled until another rollout has finished its whole sweep would let them run into the spin limit). A launch is padded to a
+// multiple of 8 rollouts and the parts of rollout j all run on XCD j mod 8 (cluster_map, dc_cluster.h), so what bounds it is one XCD:
+// ceil(nb / 8) * K workgroups on cus / 8 CUs, one workgroup (160 KB of LDS, up to 1024 threads) per CU.
+static int cluster_capacity(int cus, int K) { return std::max(1, 8 * ((cus / 8) / std::max(K, 1))); }
+
 // Tables for K parts per rollout; returns DC_OK with c->cl.ok = false when K does not fit this mesh (the caller tries K - 1).
 int build_cluster(dc_ctx *c, int K, bool forced) {
   free_cluster(c);
@@ -324,7 +340,7 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   if ((rc = upload_cl<float>(c, &D.sq_dinv, HP.sq_dinv))) return rc;
   cl.K = K;
   {   // rollouts per launch: all of them when they fit, else equal chunks (never a last launch with a handful of rollouts)
-    const int nbmax = std::max(1, c->cus / K), nchunks = (c->B + nbmax - 1) / nbmax;
+    const int nbmax = cluster_capacity(c->cus, K), nchunks = (c->B + nbmax - 1) / nbmax;
     cl.nb = std::max(1, (c->B + nchunks - 1) / nchunks);
   }
   D.nb = cl.nb;
@@ -355,11 +371,11 @@ int choose_cluster(dc_ctx *c) {
   const int kmin = (!c->S.pk_ok || !c->S.win_ok) ? std::max(2, std::min(8, (c->host.N + 6143) / 6144)) : 1;
   int K = 1;
   if (forced >= 2) K = std::min(forced, 8);
-  else if ((long long) c->B * std::max(kmin, 2) <= c->cus) { K = std::max(kmin, 2); while ((K + 1) * c->B <= c->cus && K + 1 <= 8) K++; }
+  else if (c->B <= cluster_capacity(c->cus, std::max(kmin, 2))) { K = std::max(kmin, 2); while (K + 1 <= 8 && c->B <= cluster_capacity(c->cus, K + 1)) K++; }
   else if (kmin > 1) {
     double best = -1;
     for (int k = kmin; k <= 8; k++) {
-      const int nbmax = std::max(1, c->cus / k), nchunks = (c->B + nbmax - 1) / nbmax, nb = (c->B + nchunks - 1) / nchunks;
+      const int nbmax = cluster_capacity(c->cus, k), nchunks = (c->B + nbmax - 1) / nbmax, nb = (c->B + nchunks - 1) / nchunks;
       const double score = (double) nb * k / c->cus * eff[k];
       if (score > best + 1e-9) { best = score; K = k; }
     }
@@ -373,14 +389,15 @@ int choose_cluster(dc_ctx *c) {
   return DC_OK;
 }
 
-int cluster_begin(dc_ctx *c) {       // start of an API call that launches split kernels: clear the sticky error word
-  if (c->cl.ok) HIPCHK(c, hipMemsetAsync(c->cl.D.err, 0, 16, c->stream));
-  return DC_OK;
-}
+// The error word of the split kernels is sticky on the device: it is zero until an exchange times out and is cleared only AFTER that
+// has been reported — an asynchronous call (dc_step_forward without statistics, dc_step_backward ...) can therefore not lose a
+// time-out to the next call: whichever synchronising call comes first (statistics, dc_get_state / gradient / record, dc_sync) reports it.
+int cluster_begin(dc_ctx *) { return DC_OK; }
 int cluster_check(dc_ctx *c) {       // after a synchronisation
   if (!c->cl.ok) return DC_OK;
   unsigned e[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpy(e, c->cl.D.err, sizeof(e), hipMemcpyDeviceToHost));
+  if (e[0]) HIPCHK(c, hipMemset(c->cl.D.err, 0, 16));
   if (e[0]) return fail(c, DC_ERR_HIP, "split kernels: an inter-workgroup exchange timed out (waiting for sequence " + std::to_string(e[1]) + ", saw tag " +
                         std::to_string(e[2]) + ", site " + std::to_string(e[3] & 255u) + ", part " + std::to_string((e[3] >> 8) & 15u) + ", granule " +
                         std::to_string(e[3] >> 12) + "; set DC_CLUSTER=1 to run one workgroup per rollout)");
@@ -446,6 +463,7 @@ int dc_create(int device_id, dc_ctx **out) {
   std::memset(&c->S, 0, sizeof(c->S));
   std::memset(&c->W, 0, sizeof(c->W));
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return DC_ERR_HIP; }
+  c->own_stream = c->stream;
   if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || c->cus <= 0) c->cus = 256;
   if (hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess || hipEventCreate(&c->ev_t0) != hipSuccess ||
       hipEventCreate(&c->ev_t1) != hipSuccess) { delete c; return DC_ERR_HIP; }
@@ -464,7 +482,7 @@ int dc_destroy(dc_ctx *c) {
   free_pool(c->batch_allocs);
   (void) hipEventDestroy(c->ev_a); (void) hipEventDestroy(c->ev_b);
   (void) hipEventDestroy(c->ev_t0); (void) hipEventDestroy(c->ev_t1);
-  (void) hipStreamDestroy(c->stream);
+  (void) hipStreamDestroy(c->own_stream);
   delete c;
   return DC_OK;
 }
@@ -967,7 +985,7 @@ int dc_get_state(dc_ctx *c, int slot, double *x, double *v) {
   if (x && (rc = d2h_planar(c, c->X + se * slot, x, c->host.N, 0, true))) return rc;
   if (v && (rc = d2h_planar(c, c->V + se * slot, v, c->host.N, 1, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return DC_OK;
+  return cluster_check(c);          // a state written by split kernels whose exchange timed out is not a state
 }
 
 int dc_step_forward(dc_ctx *c, int slot, const double *fixed_pts, dc_step_stats *stats) {
@@ -1002,7 +1020,7 @@ int dc_get_record(dc_ctx *c, int slot, double *f, double *r) {
   if (f && (rc = d2h_planar(c, c->F + se * slot, f, c->host.N, 0, true))) return rc;
   if (r && (rc = d2h_planar(c, c->R + se * slot, r, c->host.N, 1, true))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return DC_OK;
+  return cluster_check(c);
 }
 
 int dc_get_contacts(dc_ctx *c, int slot, int *prim_group, double *normal) {
@@ -1086,6 +1104,87 @@ int dc_step_backward(dc_ctx *c, int slot, const double *dL_dxnew, const double *
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((rc = cluster_check(c))) return rc;
   if (dL_dmu) for (size_t k = 0; k < dmu.size(); k++) dL_dmu[k] = dmu[k];
+  return DC_OK;
+}
+
+// ---- device-pointer boundary: the per-step calls for callers whose tensors live on this GPU
+//      (the RL / controller-training loop: functional.py:20-102, hatController.py:78-105 run one stepNN + stepBackwardNN per step).
+//      Buffers are DEVICE pointers in the caller's layout — xyz interleaved, B rollouts concatenated, fp32 (is_f32 = 1, torch's default)
+//      or fp64 — converted on the device; nothing crosses PCIe and nothing synchronises: every call is enqueued on the context's stream.
+int dc_use_stream(dc_ctx *c, void *hip_stream) {
+  if (!c || c->host_only) return fail(c, DC_ERR_STATE, "dc_use_stream: no device context");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t) hip_stream : c->own_stream;
+  return DC_OK;
+}
+
+int dc_set_state_dev(dc_ctx *c, int slot, const void *d_x, const void *d_v, int is_f32) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (!d_x || !d_v) return fail(c, DC_ERR_INVALID, "dc_set_state_dev: null state");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c);
+  launch_dev_to_planar(d_x, is_f32, c->X + se * slot, c->B, c->host.N, c->d_user_of, c->stream);
+  launch_dev_to_planar(d_v, is_f32, c->V + se * slot, c->B, c->host.N, c->d_user_of, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return DC_OK;
+}
+
+int dc_get_state_dev(dc_ctx *c, int slot, void *d_x, void *d_v, int is_f32) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c);
+  if (d_x) launch_planar_to_dev(c->X + se * slot, d_x, is_f32, c->B, c->host.N, c->d_user_of, c->stream);
+  if (d_v) launch_planar_to_dev(c->V + se * slot, d_v, is_f32, c->B, c->host.N, c->d_user_of, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return DC_OK;
+}
+
+int dc_step_forward_dev(dc_ctx *c, int slot, const void *d_fixed_pts, int is_f32) {
+  int rc = check_batch(c, slot, slot + 1);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int Af = c->S.Af;
+  if (d_fixed_pts && Af > 0) {
+    launch_dev_to_planar(d_fixed_pts, is_f32, c->xf_cur, c->B, Af, nullptr, c->stream);
+    c->sched_xf[slot + 1] = 0;
+  }
+  if (Af > 0 && !c->sched_xf[slot + 1]) HIPCHK(c, hipMemcpyAsync(c->XF + (size_t) c->B * 3 * Af * (slot + 1), c->xf_cur, sizeof(float) * c->B * 3 * Af, hipMemcpyDeviceToDevice, c->stream));
+  if (c->S.contact_enabled && c->S.self_enabled) launch_self_detect(c->S, c->W, fwd_args(c, slot), c->B, c->stream);
+  if ((rc = cluster_begin(c))) return rc;
+  return enqueue_pd_step(c, fwd_args(c, slot));
+}
+
+int dc_step_backward_dev(dc_ctx *c, int slot, const void *d_dL_dxnew, const void *d_dL_dvnew, const void *d_dL_dxinit, const void *d_dL_dvinit,
+                         int is_start, void *d_dL_dx, void *d_dL_dv, void *d_dL_dxfixed, void *d_dL_dmu, int is_f32) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_step_backward_dev: slot 0 has no record");
+  if (!d_dL_dxnew || !d_dL_dvnew || !d_dL_dx || !d_dL_dv) return fail(c, DC_ERR_INVALID, "dc_step_backward_dev: null gradient");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->host.N, Af = c->S.Af, G = c->S.ngroups;
+  launch_dev_to_planar(d_dL_dxnew, is_f32, c->GX, c->B, N, c->d_user_of, c->stream);
+  launch_dev_to_planar(d_dL_dvnew, is_f32, c->GV, c->B, N, c->d_user_of, c->stream);
+  const bool with_init = d_dL_dxinit && d_dL_dvinit;
+  if (with_init) {
+    launch_dev_to_planar(d_dL_dxinit, is_f32, c->IX, c->B, N, c->d_user_of, c->stream);
+    launch_dev_to_planar(d_dL_dvinit, is_f32, c->IV, c->B, N, c->d_user_of, c->stream);
+  }
+  HIPCHK(c, hipMemsetAsync(c->DMU, 0, sizeof(float) * c->B * G, c->stream));
+  if (Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF + (size_t) c->B * 3 * Af * slot, 0, sizeof(float) * c->B * 3 * Af, c->stream));
+  if ((rc = cluster_begin(c))) return rc;
+  {
+    BwdArgs BA = bwd_args(c, slot, is_start != 0, with_init);
+    if (!with_init) { BA.ix = nullptr; BA.iv = nullptr; BA.slot_ix = 0; }
+    if ((rc = enqueue_adjoint_step(c, BA))) return rc;
+  }
+  launch_planar_to_dev(c->GX, d_dL_dx, is_f32, c->B, N, c->d_user_of, c->stream);
+  launch_planar_to_dev(c->GV, d_dL_dv, is_f32, c->B, N, c->d_user_of, c->stream);
+  if (d_dL_dxfixed && Af > 0) launch_planar_to_dev(c->DXF + (size_t) c->B * 3 * Af * slot, d_dL_dxfixed, is_f32, c->B, Af, nullptr, c->stream);
+  if (d_dL_dmu) launch_copy_cast(c->DMU, d_dL_dmu, is_f32, (long) c->B * G, c->stream);
+  HIPCHK(c, hipGetLastError());
   return DC_OK;
 }
 
@@ -1364,7 +1463,11 @@ RcclApi &rccl() {
     api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     if (api.lib) break;
   }
-  if (!api.lib) { api.error = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return api; }
+  if (!api.lib) {
+    const char *why = dlerror();      // (one call: dlerror() clears the message it returns)
+    api.error = std::string("RCCL not found (dlopen librccl.so.1): ") + (why ? why : "");
+    return api;
+  }
   api.GetUniqueId = (decltype(api.GetUniqueId)) dlsym(api.lib, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank)) dlsym(api.lib, "ncclCommInitRank");
   api.AllReduce = (decltype(api.AllReduce)) dlsym(api.lib, "ncclAllReduce");

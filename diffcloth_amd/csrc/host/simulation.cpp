@@ -778,6 +778,8 @@ bool Simulation::rolloutOnDevice(int nsteps) {
     rec.splines = controlPointSplines;
     forwardRecords.push_back(std::move(rec));
   }
+  // from here on a failing device call (capacity overflow, exchange time-out ...) must not leave half-made records behind
+  try {
   check(ctx, dc_clear_schedules(ctx), "dc_clear_schedules");
   if (fallOff || field) {
     VecXd fv(n3, 0.0);
@@ -805,6 +807,10 @@ bool Simulation::rolloutOnDevice(int nsteps) {
     rec.totalConverged = prev.totalConverged + (rec.converged ? 1 : 0);
     rec.cumulateIter = prev.cumulateIter + st.pd_iters;
     rec.totalRuntime = prev.totalRuntime + us / nsteps;
+  }
+  } catch (...) {
+    forwardRecords.resize(first);
+    throw;
   }
   return true;
 }

@@ -10,7 +10,10 @@ step; here `x`, `v`, `a` carry a leading batch dimension and the step runs throu
     dL_dxinit / dL_dvinit (functional.py:66-75) — for that step the adjoint is the identity;
   * the gradient w.r.t. the action (fixed-point targets) is rescaled to a norm within [0.05, 4 * dim] per rollout
     (functional.py:88-97).
-Tensors cross the boundary as float64 host arrays, as in the reference (numpy <-> Eigen by copy there).
+CUDA tensors (fp32 or fp64) never leave the GPU: states, actions and gradients cross the boundary as device pointers
+(dc_*_dev of include/diffcloth_hip.h), the step is enqueued on torch's current stream and nothing synchronises — the
+reference copies every tensor through numpy on the host (functional.py:30-34, 60-64), which for B = 256 rollouts of 10 000
+vertices is 246 MB over PCIe per step. CPU tensors still take the host path (float64 arrays, as in the reference).
 """
 import numpy as np
 import torch
@@ -26,6 +29,14 @@ class BatchedSim:
         self.engine = engine
         self.step_num = int(step_num)
         self.step_idx = 0
+        self._stream = None
+
+    def on_current_stream(self):
+        """order the engine's work with torch's current CUDA stream (once per stream change)"""
+        st = torch.cuda.current_stream()
+        if self._stream is None or self._stream.cuda_stream != st.cuda_stream:
+            self.engine.use_stream(st)
+            self._stream = st
 
     def reset(self, x0, v0=None):
         """Start a new episode from the given states ([B, 3N]); returns them as float32 tensors like getStateInfo()."""
@@ -43,12 +54,20 @@ class BatchedSimFunction(torch.autograd.Function):
         slot = sim.step_idx
         if slot >= e.tape:
             raise RuntimeError("BatchedSimFunction: tape exhausted, call BatchedSim.reset()")
-        e.set_state(slot, np.float64(x.contiguous().detach().cpu().numpy()), np.float64(v.contiguous().detach().cpu().numpy()))
-        act = None if e.Af == 0 else np.float64(a.contiguous().detach().cpu().numpy())
-        e.step_forward(slot, fixed_pts=act, want_stats=False)
-        sim.step_idx = slot + 1
         ctx.sim = sim
         ctx.slot = slot + 1
+        sim.step_idx = slot + 1
+        if x.is_cuda:           # device path: pointers in, pointers out, torch's stream
+            sim.on_current_stream()
+            xd, vd = x.detach().contiguous(), v.detach().to(x.dtype).contiguous()
+            e.set_state_dev(slot, xd, vd)
+            e.step_forward_dev(slot, None if e.Af == 0 else a.detach().to(x.dtype).contiguous())
+            xn, vn = torch.empty_like(xd), torch.empty_like(vd)
+            e.get_state_dev(slot + 1, xn, vn)
+            return xn, vn
+        e.set_state(slot, np.float64(x.contiguous().detach().numpy()), np.float64(v.contiguous().detach().numpy()))
+        act = None if e.Af == 0 else np.float64(a.contiguous().detach().numpy())
+        e.step_forward(slot, fixed_pts=act, want_stats=False)
         xn, vn = e.get_state(slot + 1)
         return torch.as_tensor(xn).to(x.dtype), torch.as_tensor(vn).to(v.dtype)
 
@@ -56,9 +75,25 @@ class BatchedSimFunction(torch.autograd.Function):
     def backward(ctx, dL_dx_next, dL_dv_next):
         sim, slot = ctx.sim, ctx.slot
         e = sim.engine
-        gx = np.float64(dL_dx_next.contiguous().detach().cpu().numpy())
-        gv = np.float64(dL_dv_next.contiguous().detach().cpu().numpy())
-        if slot == sim.step_num:            # functional.py:66-75
+        last = slot == sim.step_num            # functional.py:66-75
+        if dL_dx_next.is_cuda:
+            sim.on_current_stream()
+            gx = dL_dx_next.detach().contiguous(); gv = dL_dv_next.detach().to(gx.dtype).contiguous()
+            dx, dv = torch.empty_like(gx), torch.empty_like(gx)
+            da = torch.zeros((e.B, max(3 * e.Af, 1)), dtype=gx.dtype, device=gx.device)[:, :3 * e.Af].contiguous()
+            zero = torch.zeros_like(gx) if last else None
+            if last:
+                e.step_backward_dev(slot, zero, zero, dx, dv, dxfixed=da if e.Af else None, ix=gx, iv=gv, is_start=(slot == 1))
+            else:
+                e.step_backward_dev(slot, gx, gv, dx, dv, dxfixed=da if e.Af else None, is_start=(slot == 1))
+            if e.Af:                           # functional.py:88-97, per rollout, on the device
+                n = da.norm(dim=1, keepdim=True)
+                scale = torch.where(n > 1e-7, n.clamp(min=0.05, max=4.0 * da.shape[1]) / n.clamp(min=1e-30), torch.ones_like(n))
+                da = da * scale
+            return dx, dv, da, None
+        gx = np.float64(dL_dx_next.contiguous().detach().numpy())
+        gv = np.float64(dL_dv_next.contiguous().detach().numpy())
+        if last:
             out = e.step_backward(slot, np.zeros_like(gx), np.zeros_like(gv), dL_dxinit=gx, dL_dvinit=gv, is_start=(slot == 1))
         else:
             out = e.step_backward(slot, gx, gv, is_start=(slot == 1))
@@ -72,5 +107,6 @@ class BatchedSimFunction(torch.autograd.Function):
 
 
 def sim_step(sim, x, v, a):
-    """One differentiable time step of all rollouts: (x', v') = step(x, v; a). x, v: [B, 3N]; a: [B, 3 Af] clip targets."""
+    """One differentiable time step of all rollouts: (x', v') = step(x, v; a). x, v: [B, 3N]; a: [B, 3 Af] clip targets.
+    CUDA tensors stay on the GPU (device-pointer boundary); CPU tensors go through the host path."""
     return BatchedSimFunction.apply(x, v, a, sim)

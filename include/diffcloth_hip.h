@@ -11,7 +11,9 @@
  *    dc_last_error() returns a message for the last failing call on that context.
  *  - host vectors are float64, xyz-interleaved, length 3N (or 3*Af) PER ROLLOUT, rollouts concatenated:
  *    exactly the reference's VecXd layout (Simulation.h: ForwardInformation::x etc.), batched.
- *  - the device computes in fp32; device layout is component-planar [B][3][N].
+ *  - the device state is fp32, component-planar [B][3][N]; the step computes in fp32 with fp64 where a difference
+ *    of nearly equal quantities decides the result: element strains in the forward step, residual / fall-back solve / gradient
+ *    sums in the adjoint (dc_params::adjoint_fp32_only).
  *  - a context owns one HIP stream; calls are enqueued in order; calls that return host data synchronise.
  *  - "slot" k of the tape holds the state after k steps; slot 0 is the initial state.
  */
@@ -199,6 +201,21 @@ int dc_get_param_gradients(dc_ctx *ctx, int slot, double *out /*B*8*/);
  * (dot with (wind * windNorm) (.) windFallOff) and the fall-off variants of dL_dfext / dL_dwind are formed.            */
 int dc_get_force_gradient(dc_ctx *ctx, double *dL_df /*B*3N*/);
 
+/* ---- device-pointer boundary: the per-step calls for callers whose tensors already live on this GPU (torch-ROCm: the controller /
+ * RL training loops, reference src/python_code/pySim/functional.py:20-102 and hatController.py:78-105, call stepNN + stepBackwardNN
+ * once per time step). Same semantics as dc_set_state / dc_get_state / dc_step_forward / dc_step_backward, but every buffer is a
+ * DEVICE pointer in the caller's layout — xyz interleaved, B rollouts concatenated, fp32 (is_f32 = 1, torch's default dtype) or
+ * fp64 (0) — converted to / from the planar device layout by a kernel: no host copy, no synchronisation; the calls are enqueued on
+ * the context's stream and return at once. dc_use_stream makes that stream the caller's (e.g. torch.cuda.current_stream()), so that
+ * the calls are ordered with the caller's own kernels; NULL returns to the context's own stream. Statistics of such steps: dc_get_stats. */
+int dc_use_stream(dc_ctx *ctx, void *hip_stream);
+int dc_set_state_dev(dc_ctx *ctx, int slot, const void *d_x /*B*3N*/, const void *d_v /*B*3N*/, int is_f32);
+int dc_get_state_dev(dc_ctx *ctx, int slot, void *d_x /*B*3N or NULL*/, void *d_v /*B*3N or NULL*/, int is_f32);
+int dc_step_forward_dev(dc_ctx *ctx, int slot, const void *d_fixed_pts /*B*3Af or NULL*/, int is_f32);
+int dc_step_backward_dev(dc_ctx *ctx, int slot, const void *d_dL_dxnew, const void *d_dL_dvnew, const void *d_dL_dxinit /*or NULL*/,
+                         const void *d_dL_dvinit /*or NULL*/, int is_start, void *d_dL_dx, void *d_dL_dv, void *d_dL_dxfixed /*B*3Af or NULL*/,
+                         void *d_dL_dmu /*B*num_groups or NULL*/, int is_f32);
+
 /* ---- device-resident rollouts (no host copies inside; used by bench.py and batched callers) --------- */
 /* nsteps forward steps slot -> slot+nsteps; fixed points held at their current values. Returns when the sweep has finished on the
  * device (its kernel time and the split kernels' error word are read back; a self-contact overflow of a step is reported by
@@ -211,8 +228,8 @@ int dc_rollout_forward(dc_ctx *ctx, int slot, int nsteps);
 int dc_seed_gradient(dc_ctx *ctx, int slot, const double *target /*3N or NULL*/, double scale_x);
 /* nsteps backward steps from record `slot` down to slot-nsteps+1, carrying (dL_dx, dL_dv) on the device
  * exactly as Simulation::runBackwardTask does (Simulation.cpp:3938-3952), all steps in one launch. dL_dmu accumulates
- * over the steps, the per-step parameter gradients stay readable per slot (dc_get_param_gradients); dL_dx_fixed of the
- * individual steps is only available through dc_step_backward. Returns when the sweep has finished on the device.    */
+ * over the steps; the per-step parameter gradients (dc_get_param_gradients) and dL_dx_fixed of every step (dc_get_dxfixed) stay
+ * readable per slot. Returns when the sweep has finished on the device.                                              */
 int dc_rollout_backward(dc_ctx *ctx, int slot, int nsteps);
 int dc_get_gradient(dc_ctx *ctx, double *dL_dx, double *dL_dv, double *dL_dmu /*B*num_groups or NULL*/);
 /* Carried gradient of the backward sweep set from the host (the loss gradient w.r.t. the last state, Simulation.cpp:3925-3936);

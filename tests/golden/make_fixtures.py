@@ -42,6 +42,14 @@ def freeze_reference_callers():
     for f in ("__init__.py", "functional.py", "pySim.py"):
         shutil.copyfile(os.path.join(REF, "src/python_code/pySim", f), os.path.join(dst, f))
     print("froze", dst)
+    # the controller-training script the north star names (hatController.py:78-105 is the loop) with the modules it imports, and the
+    # target shape file its OptimizeHelper reads: run unmodified for one epoch by tests/test_gpu_reference_callers.py
+    top = os.path.join(OUT, "reference_callers")
+    os.makedirs(os.path.join(top, "clothNN"), exist_ok=True)
+    for f in ("hatController.py", "common.py", "utils.py", "clothNN/__init__.py", "clothNN/controller.py"):
+        shutil.copyfile(os.path.join(REF, "src/python_code", f), os.path.join(top, f))
+    shutil.copyfile(os.path.join(REF, "src/assets/meshes/remeshed/Hat/hat_target.txt"), os.path.join(top, "hat_target.txt"))
+    print("froze hatController.py, common.py, utils.py, clothNN/, hat_target.txt")
 
 
 def main():

@@ -70,19 +70,7 @@ def check_against_oracle(o, e, step, sample, MU, gx, gv, st, gb, pos_tol, grad_t
         print(f"\n[full size] rollout {b}: contacts {ref['nprim']}, PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}, "
               f"max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
         assert dx <= pos_tol
-        if not (ex <= grad_tol and ev <= grad_tol):
-            # A contact sitting on a friction-state boundary (d.n ~ 0 or |d_T| ~ mu |d_N|) can land on different sides in two
-            # fp32 evaluations that differ in summation order only; its local Jacobian then differs by O(1) and a handful of
-            # vertices carry a 1e-3-level error (seen once in r02: K = 8 at vertex 8641, while K = 1 and K = 4 give 3.5e-5 on
-            # the same input). Accept that case — the error is confined to <= 8 vertices — and nothing else.
-            def without_worst(a, b, k=8):
-                d = (a - b).reshape(-1, 3)
-                nv = np.linalg.norm(d, axis=1)
-                keep = np.ones(len(nv), bool); keep[np.argsort(-nv)[:k]] = False
-                return np.linalg.norm(d[keep]) / np.linalg.norm(b)
-            rx, rv = without_worst(gb["dL_dx"][b], rb["dL_dx"]), without_worst(gb["dL_dv"][b], rb["dL_dv"])
-            print(f"[full size] rollout {b}: error confined to a few vertices; without the 8 worst: dx {rx:.2e} dv {rv:.2e}")
-            assert rx <= grad_tol and rv <= grad_tol and ex <= 5e-3 and ev <= 5e-3
+        assert ex <= grad_tol and ev <= grad_tol, (b, ex, ev)      # plain gate (round 2 excused the 8 worst vertices up to 5e-3 here)
 
 
 def test_c4_10k_vertices_batch_256():

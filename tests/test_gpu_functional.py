@@ -127,3 +127,49 @@ def test_last_step_of_an_episode_is_an_identity_in_the_adjoint():
     h = cfg["h"]
     np.testing.assert_allclose(g1x.numpy(), (gx + gv / h).numpy(), rtol=1e-6, atol=2e-6)     # Simulation.cpp:1534-1540 with u* = 0
     np.testing.assert_allclose(g1v.numpy(), gv.numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_device_pointer_path_equals_the_host_path():
+    """CUDA tensors go through the device-pointer boundary (dc_*_dev: no host copy, torch's stream); the same episode with CPU
+    tensors goes through the host path. Same kernels, same fp32 device state: states and every gradient must agree to the last bit
+    of the fp64 tensors handed back; an fp32 CUDA episode must agree to fp32 rounding."""
+    V, F = scenes.load_mesh("hat")
+    cfg = scenes.HAT
+    P, rmin, rmax = scenes.normalise_model(V, cfg["orientation"], cfg["cloth_dim"])
+    P = P.astype(np.float32).astype(np.float64)
+    att = cfg["attachments"]
+    K, B = 3, 4
+
+    def run(device, dtype):
+        e = capi.Engine(0)
+        e.set_mesh(P, F); e.set_attachments(att)
+        e.set_params(time_step=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], forward_tol=1e-7,
+                     gradient_clipping=0, selfcollision_enabled=0, adjoint_mode=1, adjoint_rel_tol=1e-7)
+        e.set_primitives([])
+        e.build()
+        e.alloc_batch(B, K)
+        bs = BatchedSim(e, 400)
+        rng = np.random.default_rng(3)
+        X0 = np.stack([(P + 0.002 * rng.standard_normal(P.shape)).reshape(-1) for _ in range(B)]).astype(np.float32).astype(np.float64)
+        A = np.stack([[P[att].reshape(-1) + (k + 1) * np.tile([0.0, -0.04, -0.2], len(att)) for k in range(K)] for _ in range(B)]).astype(np.float32)
+        W = torch.tensor(rng.standard_normal(P.size), dtype=dtype, device=device)
+        x = torch.tensor(X0, dtype=dtype, device=device, requires_grad=True)
+        v = torch.zeros_like(x, requires_grad=True)
+        acts = [torch.tensor(A[:, k], dtype=dtype, device=device, requires_grad=True) for k in range(K)]
+        bs.reset(X0)
+        xs, xk, vk = [], x, v
+        for k in range(K):
+            xk, vk = sim_step(bs, xk, vk, acts[k])
+            xs.append(xk)
+        loss = sum((k + 1) * (xs[k] * W).sum() for k in range(K)) * 1e-3 + (vk ** 2).sum() * 1e-4
+        loss.backward()
+        return [t.detach().cpu().double().numpy() for t in xs] + [x.grad.cpu().double().numpy(), v.grad.cpu().double().numpy()] + [a.grad.cpu().double().numpy() for a in acts]
+
+    host = run("cpu", torch.float64)
+    dev64 = run("cuda", torch.float64)
+    dev32 = run("cuda", torch.float32)
+    for h, d in zip(host, dev64):
+        np.testing.assert_array_equal(h, d)
+    for h, d in zip(host, dev32):
+        np.testing.assert_allclose(d, h, rtol=2e-5, atol=2e-6 * max(np.abs(h).max(), 1e-12))
+    assert np.abs(host[-1]).max() > 0
