@@ -45,6 +45,7 @@ __device__ __forceinline__ void st3d(double *p, int i, int n, d3 v) { p[i] = v.x
 struct Work64 {
   double *u, *r, *y;                        // solution, true residual g - K u, y = (I + dr_df)^T z (crosses parts)
   double *x;                                // x_new in fp64 (xnew64), filled once per backward step by prepare_x64 (crosses parts)
+  double *corner;                           // [3][NC] per-constraint-corner results of the element pass (crosses parts)
   double *rhat, *p, *v, *t, *ph, *sh;       // fall-back BiCGSTAB
 };
 
@@ -91,6 +92,7 @@ struct TeamOne {
     __device__ __forceinline__ void st(int idx, double v) const { p[idx] = v; }
   };
   __device__ __forceinline__ YV yv(double *y) const { return YV{y}; }
+  __device__ __forceinline__ YV yv(double *y, int) const { return YV{y}; }      // (n = entries per plane; the split Team sizes its buffer resource with it)
 };
 
 template <class YV> __device__ __forceinline__ d3 ld3y(const YV &a, int i, int n) { return mkd(a.ld(i), a.ld(n + i), a.ld(2 * n + i)); }
@@ -272,57 +274,6 @@ __device__ __forceinline__ bool form_y64(const DevSystem &S, const Adj64 &C, Tea
   return tm.barrier();
 }
 
-// The element terms of vertex i: sum over its incident constraint corners of h^2 w^2 [(A - dp/dx)^T A y]_corner
-// (Triangle::projectToManifoldBackward Triangle.cpp:354-451 in closed form, TriangleBending::backwardGradient
-// TriangleBending.cpp:154-172), y and x_new (fp64, prepare_x64) read through the Team's access path.
-template <class YV>
-__device__ __forceinline__ d3 element_terms64(const DevSystem &S, const YV &X, const YV &Y, int i) {
-  const int N = S.N, T = S.T, E = S.E;
-  const double h2 = S.h64 * S.h64;
-  d3 acc = mkd(0, 0, 0);
-  const int k1 = S.inc_ptr[i + 1];
-  for (int k = S.inc_ptr[i]; k < k1; k++) {
-    const int idx = S.inc_idx[k];
-    if (idx < 3 * T) {
-      const int corner = (idx >= T) + (idx >= 2 * T), t = idx - corner * T;       // (no integer division in the gather)
-      const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
-      const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
-      const d3 x0 = ld3y(X, i0, N);
-      const d3 e0 = ld3y(X, i1, N) - x0, e1 = ld3y(X, i2, N) - x0;
-      const PolarD P = polar3x2d(e0 * Dx + e1 * Dz, e0 * Dy + e1 * Dw);
-      const d3 q0 = ld3y(Y, i0, N);
-      const d3 d0 = ld3y(Y, i1, N) - q0, d1 = ld3y(Y, i2, N) - q0;
-      const d3 y0 = d0 * Dx + d1 * Dz, y1 = d0 * Dy + d1 * Dw;
-      const double c = (dot(P.t1, y0) - dot(P.t0, y1)) * rcp_d(P.trS);
-      d3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
-      z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
-      z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
-      const double s = h2 * S.tri_w2_64[t];
-      const d3 r0 = (y0 - (P.t1 * c + z0)) * s, r1 = (y1 - (z1 - P.t0 * c)) * s;
-      const d3 c1 = r0 * Dx + r1 * Dy, c2 = r0 * Dz + r1 * Dw;
-      acc = acc + (corner == 1 ? c1 : (corner == 2 ? c2 : mkd(0, 0, 0) - c1 - c2));
-    } else {
-      const int q = idx - 3 * T, corner = (q >= E) + (q >= 2 * E) + (q >= 3 * E), e = q - corner * E;
-      const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
-      const double w0 = S.bend_w64[e], w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
-      const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
-      const d3 q0 = ld3y(Y, i0, N);
-      const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
-      d3 res = ey;
-      if (nrest > 1e-6) {
-        const d3 x0 = ld3y(X, i0, N);
-        const d3 ev = (ld3y(X, i1, N) - x0) * w1 + (ld3y(X, i2, N) - x0) * w2 + (ld3y(X, i3, N) - x0) * w3;
-        const double ien = rsqrt_d(dot(ev, ev));
-        const d3 eh = ev * ien;
-        res = ey - (ey - eh * dot(eh, ey)) * (nrest * ien);
-      }
-      res = res * (h2 * wsq);
-      acc = acc + res * (corner == 0 ? w0 : (corner == 1 ? w1 : (corner == 2 ? w2 : w3)));
-    }
-  }
-  return acc;
-}
-
 // x_new in fp64 on the Team's rows (once per backward step); ends with a Team barrier
 template <int THREADS, class Team>
 __device__ __forceinline__ bool prepare_x64(const DevSystem &S, const Adj64 &C, Team &tm, double *x) {
@@ -331,17 +282,70 @@ __device__ __forceinline__ bool prepare_x64(const DevSystem &S, const Adj64 &C, 
   return tm.barrier();
 }
 
-// out = K z on the Team's rows (fp64): K = M + h^2 (A - dp/dx)^T A (I + dr_df)^T. vert(i, K z at vertex i) is called for every own
-// row exactly once (store, accumulate dot products ...). Ends WITHOUT a barrier: the caller reduces next (which is also what
-// keeps a part from overwriting y while a neighbour still gathers from it).
+// Element pass of the fp64 operator: h^2 w^2 [(A - dp/dx)^T A y] of every element of [t0, t1) x [e0, e1), one thread per element, written
+// per constraint corner (Triangle::projectToManifoldBackward Triangle.cpp:354-451 in closed form, TriangleBending::backwardGradient
+// TriangleBending.cpp:154-172); y and x_new (fp64, prepare_x64) are read, the corners written through the Team's access path.
+// (Element-centred with a corner array: the vertex-centred gather that re-evaluated every element at each of its 3 - 4 vertices
+// was bound by the fp64 rate — 2.1 M cycles per application at N = 10 000, measured with the in-kernel phase timers, r03h.)
+template <int THREADS, class YV>
+__device__ __forceinline__ void element_pass64(const DevSystem &S, const YV &X, const YV &Y, const YV &CV, int t0, int t1, int e0, int e1) {
+  const int N = S.N, T = S.T, E = S.E, NC = S.NC;
+  const double h2 = S.h64 * S.h64;
+  for (int t = t0 + threadIdx.x; t < t1; t += THREADS) {
+    const int i0 = S.tri_v[t], i1 = S.tri_v[T + t], i2 = S.tri_v[2 * T + t];
+    const double Dx = S.tri_D64[t], Dy = S.tri_D64[T + t], Dz = S.tri_D64[2 * T + t], Dw = S.tri_D64[3 * T + t];
+    const d3 x0 = ld3y(X, i0, N);
+    const d3 a0 = ld3y(X, i1, N) - x0, a1 = ld3y(X, i2, N) - x0;
+    const PolarD P = polar3x2d(a0 * Dx + a1 * Dz, a0 * Dy + a1 * Dw);
+    const d3 q0 = ld3y(Y, i0, N);
+    const d3 d0 = ld3y(Y, i1, N) - q0, d1 = ld3y(Y, i2, N) - q0;
+    const d3 y0 = d0 * Dx + d1 * Dz, y1 = d0 * Dy + d1 * Dw;
+    const double c = (dot(P.t1, y0) - dot(P.t0, y1)) * rcp_d(P.trS);
+    d3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
+    z0 = z0 - P.t0 * dot(P.t0, z0) - P.t1 * dot(P.t1, z0);
+    z1 = z1 - P.t0 * dot(P.t0, z1) - P.t1 * dot(P.t1, z1);
+    const double s = h2 * S.tri_w2_64[t];
+    const d3 r0 = (y0 - (P.t1 * c + z0)) * s, r1 = (y1 - (z1 - P.t0 * c)) * s;
+    const d3 c1 = r0 * Dx + r1 * Dy, c2 = r0 * Dz + r1 * Dw;
+    st3y(CV, t, NC, mkd(0, 0, 0) - c1 - c2); st3y(CV, T + t, NC, c1); st3y(CV, 2 * T + t, NC, c2);
+  }
+  for (int e = e0 + threadIdx.x; e < e1; e += THREADS) {
+    const int i0 = S.bend_v[e], i1 = S.bend_v[E + e], i2 = S.bend_v[2 * E + e], i3 = S.bend_v[3 * E + e];
+    const double w0 = S.bend_w64[e], w1 = S.bend_w64[E + e], w2 = S.bend_w64[2 * E + e], w3 = S.bend_w64[3 * E + e];
+    const double nrest = S.bend_nw64[e], wsq = S.bend_nw64[E + e];
+    const d3 q0 = ld3y(Y, i0, N);
+    const d3 ey = (ld3y(Y, i1, N) - q0) * w1 + (ld3y(Y, i2, N) - q0) * w2 + (ld3y(Y, i3, N) - q0) * w3;
+    d3 res = ey;
+    if (nrest > 1e-6) {
+      const d3 x0 = ld3y(X, i0, N);
+      const d3 ev = (ld3y(X, i1, N) - x0) * w1 + (ld3y(X, i2, N) - x0) * w2 + (ld3y(X, i3, N) - x0) * w3;
+      const double ien = rsqrt_d(dot(ev, ev));
+      const d3 eh = ev * ien;
+      res = ey - (ey - eh * dot(eh, ey)) * (nrest * ien);
+    }
+    res = res * (h2 * wsq);
+    const int base = 3 * T;
+    st3y(CV, base + e, NC, res * w0); st3y(CV, base + E + e, NC, res * w1); st3y(CV, base + 2 * E + e, NC, res * w2); st3y(CV, base + 3 * E + e, NC, res * w3);
+  }
+}
+
+// out = K z on the Team's rows (fp64): K = M + h^2 (A - dp/dx)^T A (I + dr_df)^T. The elements are dealt to the Team's parts in contiguous
+// ranges, then every own row sums its corners in the fixed order of the incidence list (deterministic, no atomics). vert(i, K z at
+// vertex i) is called for every own row exactly once (store, accumulate dot products ...). Ends WITHOUT a barrier: the caller reduces
+// next (which is also what keeps a part from overwriting y / the corners while another part still reads them).
 template <int THREADS, class Team, class VertOp>
-__device__ __forceinline__ bool apply_K64(const DevSystem &S, const Adj64 &C, Team &tm, const double *z, double *y, const double *x, VertOp vert) {
-  if (!form_y64<THREADS>(S, C, tm, z, y)) return false;
-  const int N = S.N;
-  const auto Y = tm.yv(y), X = tm.yv((double *) x);
+__device__ __forceinline__ bool apply_K64(const DevSystem &S, const Adj64 &C, Team &tm, const double *z, const Work64 &W, VertOp vert) {
+  if (!form_y64<THREADS>(S, C, tm, z, W.y)) return false;
+  const int N = S.N, NC = S.NC, K = tm.parts(), part = tm.part();
+  const auto Y = tm.yv(W.y), X = tm.yv(W.x), CV = tm.yv(W.corner, NC);
+  element_pass64<THREADS>(S, X, Y, CV, (int) ((long long) S.T * part / K), (int) ((long long) S.T * (part + 1) / K),
+                          (int) ((long long) S.E * part / K), (int) ((long long) S.E * (part + 1) / K));
+  if (!tm.barrier()) return false;
   const double hk = S.h64 * S.h64 * S.k_att64;
   for (int i = tm.r0() + threadIdx.x; i < tm.r1(); i += THREADS) {
-    d3 o = ld3d(z, i, N) * S.mass64[i] + element_terms64(S, X, Y, i);
+    d3 o = ld3d(z, i, N) * S.mass64[i];
+    const int k1 = S.inc_ptr[i + 1];
+    for (int k = S.inc_ptr[i]; k < k1; k++) o = o + ld3y(CV, S.inc_idx[k], NC);
     if (S.att_of_vertex[i] >= 0) o = o + ld3y(Y, i, N) * hk;       // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
     vert(i, o);
   }
@@ -385,7 +389,7 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
     bool restart = false;
     // v = K M^-1 p ; alpha = rho / (rhat . v)
     double a1 = 0;
-    if (!apply_K64<THREADS>(S, C, tm, W.ph, W.y, W.x, [&](int i, d3 o) { st3d(W.v, i, N, o); a1 += dot(o, ld3d(W.rhat, i, N)); })) return ret(-1);
+    if (!apply_K64<THREADS>(S, C, tm, W.ph, W, [&](int i, d3 o) { st3d(W.v, i, N, o); a1 += dot(o, ld3d(W.rhat, i, N)); })) return ret(-1);
     if (!tm.sum3(a1, 0, 0, s3)) return ret(-1);
     const double rv = s3[0];
     double alpha = 0, omega = 0;
@@ -408,7 +412,7 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
       }
       // t = K M^-1 s ; omega = (t . s) / (t . t)
       double b1 = 0, b2 = 0;
-      if (!apply_K64<THREADS>(S, C, tm, W.sh, W.y, W.x, [&](int i, d3 o) { st3d(W.t, i, N, o); b1 += dot(o, ld3d(W.r, i, N)); b2 += dot(o, o); })) return ret(-1);
+      if (!apply_K64<THREADS>(S, C, tm, W.sh, W, [&](int i, d3 o) { st3d(W.t, i, N, o); b1 += dot(o, ld3d(W.r, i, N)); b2 += dot(o, o); })) return ret(-1);
       if (!tm.sum3(b1, b2, 0, s3)) return ret(-1);
       omega = s3[1] > 1e-300 ? s3[0] / s3[1] : 0.0;
       // u += alpha M^-1 p + omega M^-1 s ; r = s - omega t ; rho_new = rhat . r
@@ -451,7 +455,7 @@ template <int THREADS, class Team>
 __device__ DC_OUTLINED Ret64<Team> residual64(const DevSystem &S, Adj64 C, Team tm, Work64 W, const float *__restrict__ gx, float gscale) {
   const int N = S.N;
   double a = 0;
-  if (!apply_K64<THREADS>(S, C, tm, W.u, W.y, W.x, [&](int i, d3 o) {
+  if (!apply_K64<THREADS>(S, C, tm, W.u, W, [&](int i, d3 o) {
         const d3 q = tod(ld3(gx, i, N) * gscale) - o;
         st3d(W.r, i, N, q);
         a += dot(q, q);

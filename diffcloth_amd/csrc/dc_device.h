@@ -129,6 +129,7 @@ struct DevWork {
   // adjoint in mixed precision (dc_adjoint64.h): solution, true residual, y = (I + dr_df)^T z, and the six further vectors of the
   // fp64 fall-back BiCGSTAB; [B][3][N] doubles each
   double *u64, *r64, *y64, *x64, *k64[6];
+  double *c64;            // [B][3][NC] per-constraint-corner results of the fp64 element pass
   // self-collision detection / layering scratch (k_self_detect)
   int *sd_cell, *sd_order;      // [B][N]
   float *sd_sx;                 // [B][3][N] positions in cell-sorted order

@@ -864,6 +864,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->W.r64, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.y64, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->W.x64, se))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->W.c64, (size_t) B * 3 * NC))) return rc;
   for (int k = 0; k < 6; k++) if ((rc = dev_alloc(c, pool, &c->W.k64[k], se))) return rc;
   {
     const int cap = c->S.self_cap;

@@ -37,6 +37,21 @@ struct In2Plain {
   int N;
   __device__ __forceinline__ f3 operator()(int i) const { return mk(v[i], v[N + i], v[2 * N + i]); }
 };
+// Elements a thread keeps in flight in the per-element phase: the largest batch (-DDC_WIN_EB, A/B builds) and the dispatch of a batch
+// size to its unrolled variant: `left` rounds remain, the batch takes min(left, MAXB) of them, at least 2 (one masked).
+#ifndef DC_WIN_EB
+#define DC_WIN_EB 4
+#endif
+constexpr int kWinMaxBatch = DC_WIN_EB;
+template <int MAXB, class F>
+__device__ __forceinline__ int batch_dispatch(int left, F f) {
+  if constexpr (MAXB <= 2) { f(std::integral_constant<int, 2>()); return 2; }
+  else {
+    if (left >= MAXB) { f(std::integral_constant<int, MAXB>()); return MAXB; }
+    return batch_dispatch<MAXB - 1>(left, f);
+  }
+}
+
 // PRECISE: the element operators also receive the low-order parts of the element's rest data (wtri_Dlo / wbend_lo) — the
 // fp64-strain operators of the forward step (PreciseTriOp / PreciseBendOp, HybridTriOp / HybridBendOp below).
 template <int THREADS, bool PRECISE = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
@@ -117,15 +132,11 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     };
     for (int q = 0, rounds = (nt + THREADS - 1) / THREADS; q < rounds;) {      // wave-uniform control flow
       const int left = rounds - q, t0 = q * THREADS + tid;
-      if (left >= 4) { tri_batch(std::integral_constant<int, 4>(), t0); q += 4; }
-      else if (left == 3) { tri_batch(std::integral_constant<int, 3>(), t0); q += 3; }
-      else { tri_batch(std::integral_constant<int, 2>(), t0); q += 2; }
+      q += batch_dispatch<kWinMaxBatch>(left, [&](auto ebc) { tri_batch(ebc, t0); });
     }
     for (int q = 0, rounds = (nb + THREADS - 1) / THREADS; q < rounds;) {
       const int left = rounds - q, e0 = q * THREADS + tid;
-      if (left >= 4) { bend_batch(std::integral_constant<int, 4>(), e0); q += 4; }
-      else if (left == 3) { bend_batch(std::integral_constant<int, 3>(), e0); q += 3; }
-      else { bend_batch(std::integral_constant<int, 2>(), e0); q += 2; }
+      q += batch_dispatch<kWinMaxBatch>(left, [&](auto ebc) { bend_batch(ebc, e0); });
     }
     __syncthreads();
     // per-vertex phase. All packets of a vertex travel in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2
