@@ -86,9 +86,11 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None):
     return st
 
 
-def test_c3_hat_batch_64():
+@pytest.mark.parametrize("lowering_steps", [12, 23], ids=["first-touch", "pressed-onto-the-head"])
+def test_c3_hat_batch_64(lowering_steps):
     """wear_hat (OptimizationTaskConfigurations.cpp hat scene): 579 vertices, two clips, head sphere mu 0.1; 64 rollouts
-    with their own clip targets and states."""
+    with their own clip targets and states. After 12 lowering steps the hat just touches the head (2 contacts); after 23 it is
+    pressed onto it: ~75 primitive contacts per rollout, about 50 of them sliding (friction must be exercised)."""
     cfg = scenes.HAT
     V, F = scenes.load_mesh("hat")
     P, rmin, rmax = scenes.normalise_model(V, cfg["orientation"], cfg["cloth_dim"])
@@ -111,14 +113,18 @@ def test_c3_hat_batch_64():
     base_xf = P[att].reshape(-1)
     x, v = f32(P.reshape(-1)), np.zeros(P.size)
     xf = base_xf.copy()
-    for s in range(12):
+    for s in range(lowering_steps):
         xf = xf + np.tile([0.0, -0.05, -0.3], 2)
         out = o.step(x, v, f32(xf)); x, v = out["x"], out["v"]
+    if lowering_steps > 20:
+        assert out["nprim"] >= 50, "the pressed-on case must carry friction contacts"
     X0 = np.stack([f32(x + 0.002 * rng.standard_normal(x.size)) for _ in range(B)])
     V0 = np.stack([f32(v + 0.01 * rng.standard_normal(x.size)) for _ in range(B)])
     XF = np.stack([f32(xf + np.tile([0.0, -0.05, -0.3], 2) + 0.02 * rng.standard_normal(6)) for _ in range(B)])
     mus = f32(rng.uniform(0.05, 0.6, (B, 1)))
-    check_rollouts(o, e, X0, V0, XF, sample=(0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus)
+    st = check_rollouts(o, e, X0, V0, XF, sample=(0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus)
+    if lowering_steps > 20:
+        assert st["prim_contacts"].min() >= 40
 
 
 def test_c5_sock_batch_512():
@@ -164,9 +170,11 @@ def test_c5_sock_batch_512():
     assert st["prim_contacts"].min() > 0
 
 
-def test_c4_dress_self_contact_batch(mesh="dress", B=8, sample=(0, 7)):
+@pytest.mark.parametrize("B,sample", [(8, (0, 7)), (256, (0, 131, 255))], ids=["8-rollouts-split", "256-rollouts"])
+def test_c4_dress_self_contact_batch(B, sample, mesh="dress"):
     """dress mesh (3634 vertices: the dress_twirl demo's) hanging from its top rim and folded so that sheets touch: self-collision
-    detection, layering, layered friction and its adjoint on a real garment (the batch of 256 is the bench's job; a few rollouts here)."""
+    detection, layering, layered friction and its adjoint on a real garment — at 8 rollouts (each split over workgroups) and at
+    BASELINE.json's batch of 256 (one workgroup per rollout)."""
     V, F = scenes.load_mesh(mesh)
     cfg = dict(h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
     P, rmin, rmax = scenes.normalise_model(V, "FRONT", 8.0)
