@@ -236,6 +236,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   { const char *envp = getenv("DC_BLOCK_PRE"); A.block_pre = envp ? (envp[0] != '0') : (c->params.adjoint_block_precond != 0); }   // (development switch)
   { const char *envp = getenv("DC_ADJ_FP32"); A.fp32_only = envp ? (envp[0] == '1') : (c->params.adjoint_fp32_only != 0); }     // (development switch)
+  { const char *envp = getenv("DC_ADJ_VERIFY"); A.verify_all = envp ? (envp[0] == '1') : 0; }     // (development switch)
   A.nsteps = 1; A.slot = slot;
   A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   A.slot_param = (size_t) c->B * 8; A.slot_xf = (size_t) c->B * 3 * c->S.Af; A.slot_stats = (size_t) c->B;

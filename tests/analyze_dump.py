@@ -3,7 +3,7 @@
 Reads the HIP path's tape of sampled rollouts (tests/ab_adjoint.py --dump DIR), repeats the step with the fp64 oracle and
 differentiates it four times: with its own record, with the GPU's x_new, with the GPU's f (contact vectors d, r re-derived), with
 both. If "both" reproduces the GPU's gradient, the adjoint SOLVE is exact and what differs is the forward record.
-  python tests/analyze_dump.py DIR c4|hat|dress7k
+  python tests/analyze_dump.py DIR c4|hat|hat6|dress7k [file pattern]
 """
 import glob
 import os
@@ -39,13 +39,13 @@ def oracle_c4():
     return o
 
 
-def oracle_hat():
+def oracle_hat(fwd_tol=1e-8):
     cfg = scenes.HAT
     V, F = scenes.load_mesh("hat")
     P, rmin, rmax = scenes.normalise_model(V, cfg["orientation"], cfg["cloth_dim"])
     P = f32(P)
     center = f32(scenes.hat_head_center(rmin, rmax, cfg["sphere_radius"]))
-    o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-8,
+    o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=fwd_tol,
                    bwd_tol=1e-9, attachments=cfg["attachments"], selfcollision=False, gradient_clipping=False)
     o.add_sphere(center, cfg["sphere_radius"], cfg["sphere_mu"])
     o.build()
@@ -65,8 +65,9 @@ def oracle_dress(mesh):
 
 def main():
     d, which = sys.argv[1], sys.argv[2]
-    o = {"c4": oracle_c4, "hat": oracle_hat, "dress7k": lambda: oracle_dress("dress7k")}[which]()
-    for fn in sorted(glob.glob(os.path.join(d, which + "*.npz"))):
+    o = {"c4": oracle_c4, "hat": oracle_hat, "hat6": lambda: oracle_hat(1e-6), "dress7k": lambda: oracle_dress("dress7k")}[which]()
+    pattern = sys.argv[3] if len(sys.argv) > 3 else which + "*.npz"      # e.g. "cfg_B64_N579_*.npz": the DC_DUMP_DIR files of tests/test_gpu_configs.py
+    for fn in sorted(glob.glob(os.path.join(d, pattern))):
         z = np.load(fn)
         if "mu" in z.files:
             o.set_mu(0, float(z["mu"]))
