@@ -31,11 +31,18 @@ constexpr double kInnerFloor = 1e-3;   // an fp32 correction solve never aims be
 #ifdef DC_PROFILE_PHASES
 #define PH_DECL long long ph_t = clock64(); long long ph_acc[4] = {0, 0, 0, 0};
 #define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
-#define PH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[phases adj] iters %d | per iter: operator(x2) %lld vector-ops %lld | setup %lld final %lld cycles\n", iters, ph_acc[1] / max(iters, 1), ph_acc[2] / max(iters, 1), ph_acc[0], ph_acc[3]);
+#define PH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) { printf("[phases adj] iters %d | per step: fp64 residuals %lld fp32 solves %lld setup %lld final %lld cycles | per iter: contact^T x2 %lld windows x2 (stage %lld tri %lld bend %lld vertex %lld) s-update %lld d,r-update %lld p-update %lld\n", iters, ph_acc[1], ph_acc[2], ph_acc[0], ph_acc[3], g_adj_ph[0] / max(iters, 1), g_win_ph[0] / max(iters, 1), g_win_ph[1] / max(iters, 1), g_win_ph[2] / max(iters, 1), g_win_ph[3] / max(iters, 1), g_adj_ph[1] / max(iters, 1), g_adj_ph[2] / max(iters, 1), g_adj_ph[3] / max(iters, 1)); for (int q_ = 0; q_ < 4; q_++) g_adj_ph[q_] = g_win_ph[q_] = 0; }
+static __device__ long long g_adj_ph[4];
+#define APH_DECL long long aph_t = clock64();
+#define APH(k) { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); g_adj_ph[k] += n_ - aph_t; aph_t = n_; } }
+#define APH_SKIP { aph_t = clock64(); }
 #else
 #define PH_DECL
 #define PH(k)
 #define PH_PRINT
+#define APH_DECL
+#define APH(k)
+#define APH_SKIP
 #endif
 
 namespace {
@@ -62,6 +69,10 @@ struct AdjCtx {
   int lds_floats;               // size of the dynamic LDS region (0 without element windows)
   SelfRec self;
   int nself, b;
+  // contact vertices of this step (k_adjoint_step builds them once per step): y differs from z only there
+  int *mark;                    // [N] bit 0 = in the working set of the self contacts, bit 1 = in contact with a primitive
+  const int *plist;             // [nplist] the vertices in contact with a primitive
+  int nplist;
 };
 
 // w = dr_df^T z for the (block-diagonal) primitive contacts: Simulation::calculatedr_df (Simulation.cpp:700-711)
@@ -193,6 +204,15 @@ __device__ __forceinline__ void adjoint_operator_global(const DevSystem &S, cons
   }
 }
 
+// z (optionally scaled by D^-1) in, y out — at the working-set vertices of the self contacts only (self_JT_layers_lds_v)
+struct SelfInOut {
+  const float *zin, *dinv;
+  float *y;
+  int N;
+  __device__ __forceinline__ float ld(int idx) const { const int v = idx >= 2 * N ? idx - 2 * N : (idx >= N ? idx - N : idx); return dinv ? zin[idx] * dinv[v] : zin[idx]; }
+  __device__ __forceinline__ void st(int idx, float val) const { y[idx] = val; }
+};
+
 // Same operator with the element pass inside LDS (element windows, dc_winlib.h): no corner array, no atomics.
 template <int THREADS, bool WIN>
 __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
@@ -210,17 +230,36 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
     if (d1) a1 += dot(o, ld3(d1, i, N));
     a2 += dot(o, o);
   };
-  if (C.nself > 0) {
-    // layered self contacts couple vertices: y = (I + dr_df)^T z is formed in global memory first
-    contact_transpose<THREADS>(S, C, zin, precond, C.y);     // ends with a barrier
-    element_windows<THREADS>(S, C.lds, StagePlanar{C.y, N}, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
-  } else {
-    // primitive contacts only: dr_df is block diagonal, y_i is formed per vertex while the window is staged
-    element_windows<THREADS>(S, C.lds, [&](int i) {
+  // y = (I + dr_df)^T z differs from z only at the contact vertices: the layered self contacts couple the ~2 x nself vertices of
+  // their working set (the layers run on those alone, in LDS, before the windows use it), the primitive contacts are block diagonal
+  // (one pass over the list of their vertices); both leave y in global memory, every other vertex is staged as z itself. (Before:
+  // two passes over all N vertices per operator application, 49 k of its 290 k cycles on the 10 000-vertex cloth with 500 self and
+  // 400 primitive contacts; forming y_i inside the staging instead costs three dependent loads per span vertex, halo included.)
+  APH_DECL
+  bool sparse = C.mark != nullptr;
+  if (sparse && C.nself > 0) sparse = self_JT_layers_lds_v<THREADS>(S, C.self, C.b, SelfInOut{zin, precond ? S.dinv : nullptr, C.y, N}, C.lds, C.lds_floats);   // ends with a barrier
+  if (sparse) {
+    const int *mark = C.mark;
+    for (int q = threadIdx.x; q < C.nplist; q += THREADS) {
+      const int i = C.plist[q];
+      f3 z;
+      if (mark[i] & 1) z = ld3(C.y, i, N);
+      else { z = ld3(zin, i, N); if (precond) z = z * S.dinv[i]; }
+      st3(C.y, i, N, z + contact_JT(S, C, i, z));
+    }
+    __syncthreads();
+    APH(0)
+    element_windows<THREADS>(S, C.lds, [&](int i) {      // (both candidates loaded, then selected: one memory round trip, not two)
+      const int m = mark[i];
+      const f3 yi = ld3(C.y, i, N);
       f3 z = ld3(zin, i, N);
       if (precond) z = z * S.dinv[i];
-      return z + contact_JT(S, C, i, z);
+      return mk(m ? yi.x : z.x, m ? yi.y : z.y, m ? yi.z : z.z);
     }, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
+  } else {
+    // (self-contact working set beyond the LDS: y = (I + dr_df)^T z is formed in global memory first)
+    contact_transpose<THREADS>(S, C, zin, precond, C.y);     // ends with a barrier
+    element_windows<THREADS>(S, C.lds, StagePlanar{C.y, N}, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
   }
   dot1 = a1; dot2 = a2;
 }
@@ -271,6 +310,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
       double rv = block_sum<THREADS>((double) d1, red);
       if (!(fabs(rv) > 1e-300)) { in_status = 2; break; }
       const float alpha = (float) (rho / rv);
+      APH_DECL
       // s = r - alpha v  (in place)
       // (vector updates: VB vertices of a thread per round, all loads issued before the first store)
       part = 0.f;
@@ -286,6 +326,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
         }
       }
       double ss = block_sum<THREADS>((double) part, red);
+      APH(1)
       iters++;
       if (ss <= in_stop) {
         for (int i = tid; i < N; i += THREADS) st3(u, i, N, ld3(u, i, N) + (BLK ? ld3(ph, i, N) * alpha : ld3(p, i, N) * (alpha * S.dinv[i])));
@@ -298,6 +339,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
       block_sum2<THREADS>(ts, tt, red);
       if (!(tt > 1e-300)) { in_status = 2; break; }
       const float omega = (float) (ts / tt);
+      APH_SKIP
       // d += alpha M^-1 p + omega M^-1 s ;  r = s - omega t ;  rho_new = rhat . r
       float pa = 0.f, pb = 0.f;
       for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
@@ -324,6 +366,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
       double rho_new = (double) pa;
       rr = (double) pb;
       block_sum2<THREADS>(rho_new, rr, red);
+      APH(2)
       if (rr <= in_stop) { in_status = 1; break; }
       if (rr < best_rr) { best_rr = rr; since_progress = 0; }
       else if (++since_progress >= stall_window) { in_status = 2; break; }
@@ -342,6 +385,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
         }
       }
       __syncthreads();
+      APH(3)
     }
   __syncthreads();
   return Ret32{in_status, kdone, iters, rr};
@@ -380,6 +424,28 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   C.y = W.vbest + off; C.corner = W.corner + (size_t) b * 3 * S.NC;
   C.self = A.self; C.b = b;
   C.nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;
+  // the contact vertices of this step (the detection's cell / order arrays are free during the backward sweep)
+  C.mark = A.dense_y ? nullptr : W.sd_cell + (size_t) b * N;
+  C.plist = nullptr; C.nplist = 0;
+  if (C.mark) {
+    int *plist = W.sd_order + (size_t) b * N;
+    __shared__ int nplist;
+    if (tid == 0) nplist = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += THREADS) {
+      const bool pc = C.rec_prim[i] >= 0;
+      C.mark[i] = pc ? 2 : 0;
+      if (pc) plist[atomicAdd(&nplist, 1)] = i;        // (order free: the vertices are independent)
+    }
+    __syncthreads();
+    if (C.nself > 0) {
+      const int M = A.self.meta[(size_t) b * kMetaStride + kMetaStride - 1];
+      const int *verts = A.self.verts + (size_t) b * 2 * S.self_cap;
+      for (int q = tid; q < M; q += THREADS) C.mark[verts[q]] |= 1;
+    }
+    C.plist = plist; C.nplist = nplist;
+    __syncthreads();
+  }
   float *gx = A.gx + off;
   float *gin = W.g + off, *u = W.vnow + off;
   float *cg_r = W.cg_r + off, *cg_p = W.cg_p + off, *cg_ap = W.cg_ap + off, *cg_x = W.cg_x + off;

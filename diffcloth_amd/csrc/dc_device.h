@@ -163,6 +163,7 @@ struct FwdArgs {
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;
   int pd_cap, cg_max, stall_window;
+  int self_full;                // 1 = rebuild the right-hand side of all vertices after the self-contact layers (development switch DC_FWD_SELFFULL)
   int cg_seed;                  // packet / split kernels: first search direction of a solve = the previous PD iteration's correction
   // several consecutive steps in one launch (packet kernel only): step s uses tape slot k + s
   int nsteps, inline_detect;    // inline_detect: run the self-collision detection of every step inside the kernel
@@ -192,6 +193,7 @@ struct BwdArgs {
   int it_cap, cg_max, is_start, clip, stall_window;
   int block_pre;                // direct solve: 1 = block-Jacobi from K's own diagonal blocks (dc_adjprecond.h), 0 = Jacobi from diag(P)
   int fp32_only;                // direct solve: 1 = the fp32 Krylov solve alone (no fp64 residual, no refinement, no fp64 fall-back)
+  int dense_y;                  // 1 = form y = (I + dr_df)^T z over all vertices in every operator application (development switch DC_ADJ_DENSEY)
   int verify_all;               // direct solve: 1 = evaluate the fp64 residual after EVERY correction solve (development switch DC_ADJ_VERIFY)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;

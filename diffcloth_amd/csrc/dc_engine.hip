@@ -202,6 +202,7 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   static const bool seed_on = !(getenv("DC_CG_SEED") && getenv("DC_CG_SEED")[0] == '0');     // development switch
   A.cg_seed = seed_on ? 1 : 0;
+  { const char *envp = getenv("DC_FWD_SELFFULL"); A.self_full = envp ? (envp[0] == '1') : 0; }
   A.nsteps = 1; A.inline_detect = 0; A.slot_state = se; A.slot_prim = sp; A.slot_stats = (size_t) c->B;
   A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   return A;
@@ -236,6 +237,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
   { const char *envp = getenv("DC_BLOCK_PRE"); A.block_pre = envp ? (envp[0] != '0') : (c->params.adjoint_block_precond != 0); }   // (development switch)
   { const char *envp = getenv("DC_ADJ_FP32"); A.fp32_only = envp ? (envp[0] == '1') : (c->params.adjoint_fp32_only != 0); }     // (development switch)
+  { const char *envp = getenv("DC_ADJ_DENSEY"); A.dense_y = envp ? (envp[0] == '1') : 0; }
   { const char *envp = getenv("DC_ADJ_VERIFY"); A.verify_all = envp ? (envp[0] == '1') : 0; }     // (development switch)
   A.nsteps = 1; A.slot = slot;
   A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;

@@ -29,10 +29,15 @@
 
 namespace dc {
 
+#ifndef DC_WIN_PF
+#define DC_WIN_PF 0
+#endif
+constexpr bool kWinPrefetchFwd = DC_WIN_PF != 0;     // software-pipelined table loads in the element windows (dc_winlib.h)
+
 #ifdef DC_PROFILE_PHASES
-#define PH_DECL long long ph_t = clock64(); long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PH_DECL long long ph_t = clock64(); long long ph_acc[6] = {0, 0, 0, 0, 0, 0}; if (blockIdx.x == 0 && threadIdx.x == 0) { g_win_ph[0] = g_win_ph[1] = g_win_ph[2] = g_win_ph[3] = 0; }
 #define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
-#define PH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[phases pk] pd %d cg %d | per PD iter: local %lld vertex %lld pd-update %lld | per CG iter: spmv %lld pAp-red %lld upd+red %lld cycles\n", iters, cg_total, ph_acc[0] / iters, ph_acc[1] / iters, ph_acc[5] / iters, ph_acc[2] / max(cg_total, 1), ph_acc[3] / max(cg_total, 1), ph_acc[4] / max(cg_total, 1));
+#define PH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[phases pk] pd %d cg %d | per PD iter: local %lld vertex %lld pd-update %lld | per CG iter: spmv %lld pAp-red %lld upd+red %lld cycles | windows per PD iter: stage %lld tri %lld bend %lld vertex %lld\n", iters, cg_total, ph_acc[0] / iters, ph_acc[1] / iters, ph_acc[5] / iters, ph_acc[2] / max(cg_total, 1), ph_acc[3] / max(cg_total, 1), ph_acc[4] / max(cg_total, 1), g_win_ph[0] / iters, g_win_ph[1] / iters, g_win_ph[2] / iters, g_win_ph[3] / iters);
 #else
 #define PH_DECL
 #define PH(k)
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       return (f + r - v * m) * S.sq_dinv[i];       // scaled residual D^-1/2 rhs
     };
     part = 0.f;
+    bool self_done = false;
     if (S.win_ok) {
       // ---- local step + vertex pass, window by window inside LDS (dc_winlib.h) ----
       float *scr = W.cg_r + off;
@@ -147,9 +153,25 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         st3(scr, i, N, rhs);
         part += dot(rhs, rhs);
       };
-      element_windows<THREADS, kFwdOpsPrecise>(S, lp, StagePlanar{xn, N}, vnow, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
+      element_windows<THREADS, kFwdOpsPrecise, kWinPrefetchFwd>(S, lp, StagePlanar{xn, N}, vnow, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
       __syncthreads();
       PH(0)
+      if (nself > 0 && !A.self_full) {
+        // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678) over the working set of the contacts, in the LDS the windows
+        // have just left; then the right-hand side of those ~2 x nself vertices alone is formed again (all N before: a quarter
+        // of the per-vertex phase on the 10 000-vertex cloth with 500 contacts)
+        if (self_friction_layers_lds<THREADS>(S, srec, b, rec_f, rec_r, lp, 3 * NP)) {     // ends with a barrier
+          const int M = srec.meta[(size_t) b * kMetaStride + kMetaStride - 1];
+          const int *verts = srec.verts + (size_t) b * 2 * S.self_cap;
+          for (int q = tid; q < M; q += THREADS) {
+            const int i = verts[q];
+            st3(scr, i, N, (ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i]) * S.sq_dinv[i]);
+          }
+          __syncthreads();
+          self_done = true;
+          part = 0.f;
+        }
+      }
       for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread (clamped index), then the LDS stores
         float t[4][3];
 #pragma unroll
@@ -163,6 +185,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           if (k0 + j < VPT) {
             const int i = tq + (k0 + j) * THREADS;
             ((float2 *) lp)[i] = make_float2(t[j][0], t[j][1]); lp[2 * NP + i] = t[j][2];
+            if (self_done) part += dot(mk(t[j][0], t[j][1], t[j][2]), mk(t[j][0], t[j][1], t[j][2]));
           }
         }
       }
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
       }
     }
-    if (nself > 0) {   // self contacts: layered Gauss-Seidel on r (Simulation.cpp:655-678), then rebuild the right-hand side
+    if (nself > 0 && !self_done) {   // (working set beyond the LDS, or no element windows) the same through global memory, then rebuild the right-hand side
       __syncthreads();
       // (the LDS version uses the search-direction planes as scratch: they are rebuilt, padding rows included, below)
       if (!self_friction_layers_lds<THREADS>(S, srec, b, rec_f, rec_r, lp, 3 * NP)) self_friction_layers<THREADS>(S, srec, b, rec_f, rec_r);
@@ -459,6 +482,15 @@ static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, in
 // 512 threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).
 bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   if (!S.pk_ok) return false;
+#ifdef DC_PK_ONLY20      // development builds: only the 10 000-vertex variant (compile time)
+  if (S.pk_vpt != 20) return false;
+#ifdef DC_PK_1024
+  launch_pk<1024, 10, DC_PK_1024>(S, W, A, B, st);
+#else
+  launch_pk<512, 20, 6>(S, W, A, B, st);
+#endif
+  return true;
+#else
   switch (S.pk_vpt) {
     case 1: launch_pk<512, 1, 0>(S, W, A, B, st); break;
     case 2: launch_pk<512, 2, 0>(S, W, A, B, st); break;
@@ -473,6 +505,7 @@ bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &
     default: return false;
   }
   return true;
+#endif
 }
 
 }  // namespace dc

@@ -1,5 +1,6 @@
 #include "dc_windows.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace dc {
@@ -34,6 +35,41 @@ void scan_window(const HostSystem &H, int v0, int v1, WinScan &s) {
       for (int k = 0; k < 4; k++) { s.lo = std::min(s.lo, q[k]); s.hi = std::max(s.hi, q[k] + 1); }
     }
   }
+}
+
+// Order of the elements inside a window. Their result vectors sit in LDS at the element's position, and in the per-vertex phase lane
+// l (vertex v0 + l) reads, in its slot j, the result of its j-th incident element: with the elements in mesh order a regular mesh
+// turns that into a strided access (the two triangles of a quad cell alternate: slot j of consecutive vertices is 2 elements
+// = 4 result vectors apart, a 4-way LDS bank conflict on every read of the phase). Placing the elements in the order in which a
+// slot-major sweep over the owned vertices first meets them makes slot j of consecutive vertices consecutive positions wherever
+// the mesh is regular, and costs nothing where it is not. (Only positions change: the sums keep their order, results are bit-identical.)
+void order_by_first_use(const HostSystem &H, int v0, int v1, bool bends, std::vector<int> &list) {
+  const int T = H.T, E = H.E;
+  std::vector<char> placed(bends ? E : T, 0), member(bends ? E : T, 0);
+  for (int id : list) member[id] = 1;
+  std::vector<int> out;
+  out.reserve(list.size());
+  std::vector<std::vector<int>> inc(v1 - v0);
+  size_t depth = 0;
+  for (int v = v0; v < v1; v++) {
+    for (int k = H.inc_ptr[v]; k < H.inc_ptr[v + 1]; k++) {
+      const int idx = H.inc_idx[k];
+      const bool is_bend = idx >= 3 * T;
+      if (is_bend != bends) continue;
+      const int id = is_bend ? (idx - 3 * T) % E : idx % T;
+      if (member[id]) inc[v - v0].push_back(id);
+    }
+    depth = std::max(depth, inc[v - v0].size());
+  }
+  for (size_t j = 0; j < depth; j++)
+    for (int v = v0; v < v1; v++)
+      if (j < inc[v - v0].size()) {
+        const int id = inc[v - v0][j];
+        if (!placed[id]) { placed[id] = 1; out.push_back(id); }
+      }
+  for (int id : list)
+    if (!placed[id]) out.push_back(id);
+  list.swap(out);
 }
 
 // sizing pass for one window size
@@ -126,6 +162,11 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
   for (int w = 0; w < nwin; w++) {
     const int v0 = w * own, v1 = std::min(N, v0 + own);
     scan_window(H, v0, v1, s);
+    static const bool reorder = !(getenv("DC_WIN_ORDER") && getenv("DC_WIN_ORDER")[0] == '0');     // development switch
+    if (reorder) {
+      order_by_first_use(H, v0, v1, false, s.tris);
+      order_by_first_use(H, v0, v1, true, s.bends);
+    }
     const int ntri = (int) s.tris.size(), nbend = (int) s.bends.size();
     const int tri_off = (int) (tri_rec.size() / 4), bend_off = (int) (bend_rec.size() / 4);
     const int d[8] = {v0, v1, s.lo, s.hi - s.lo, tri_off, ntri, bend_off, nbend};
@@ -167,8 +208,8 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
             if (corner == 1) { a = Dx; b = Dy; }
             else if (corner == 2) { a = Dz; b = Dw; }
             else { a = -(Dx + Dz); b = -(Dy + Dw); }
-            rows[l].push_back({2 * tri_local[t], a});
-            rows[l].push_back({2 * tri_local[t] + 1, b});
+            rows[l].push_back({tri_local[t], a});               // result planes: first columns [0, ntri), second [ntri, 2 ntri), bending
+            rows[l].push_back({ntri + tri_local[t], b});
           } else {
             const int corner = (idx - 3 * T) / E, e = (idx - 3 * T) % E;
             rows[l].push_back({2 * ntri + bend_local[e], (float) H.bend_w[4 * e + corner]});

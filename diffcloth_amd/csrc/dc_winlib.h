@@ -43,6 +43,9 @@ struct In2Plain {
 #define DC_WIN_EB 4
 #endif
 constexpr int kWinMaxBatch = DC_WIN_EB;
+#ifndef DC_WIN_PFP
+#define DC_WIN_PFP 1
+#endif
 template <int MAXB, class F>
 __device__ __forceinline__ int batch_dispatch(int left, F f) {
   if constexpr (MAXB <= 2) { f(std::integral_constant<int, 2>()); return 2; }
@@ -52,16 +55,62 @@ __device__ __forceinline__ int batch_dispatch(int left, F f) {
   }
 }
 
+// Sub-phase timing of the window passes (-DDC_PROFILE_PHASES): thread 0 of workgroup 0 accumulates shader-clock totals of the
+// staging, triangle, bending and per-vertex parts; the step kernels print them with their own phase totals.
+#ifdef DC_PROFILE_PHASES
+static __device__ long long g_win_ph[4];
+#define WPH_DECL long long wph_t = clock64();
+#define WPH(k) { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); g_win_ph[k] += n_ - wph_t; wph_t = n_; } }
+#else
+#define WPH_DECL
+#define WPH(k)
+#endif
+
 // PRECISE: the element operators also receive the low-order parts of the element's rest data (wtri_Dlo / wbend_lo) — the
 // fp64-strain operators of the forward step (PreciseTriOp / PreciseBendOp, HybridTriOp / HybridBendOp below).
-template <int THREADS, bool PRECISE = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
+// PF (software pipelining): the table records of a batch are loaded one batch ahead — the first triangle batch before the window is
+// staged, the next batch (or the first bending batch, or the first coefficient packets of the per-vertex phase) before the current
+// one is computed — so that an L2 round trip (1.5-2 k cycles, and both waves of a SIMD sit in the same phase) is no longer exposed
+// at every batch. Costs the registers of one more batch (48) and, across the barrier into the per-vertex phase, of its packets
+// (48 / 96): for the kernels with 256 registers per thread.
+template <int EB, bool PRECISE>
+struct WinTriRecs { int4 r[EB]; float4 D[EB]; float4 Dl[PRECISE ? EB : 1]; };
+template <int EB, bool PRECISE>
+struct WinBendRecs { int4 r[EB]; float4 w[EB]; float4 wl[PRECISE ? EB : 1]; };
+
+template <int THREADS, bool PRECISE = false, bool PF = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, float *lds, Stage1 stage1,
                                                   In2 in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
   const int tid = threadIdx.x, lane = tid & 63;
   const WinLds L = win_lds(S, lds);
+  constexpr int MB = kWinMaxBatch;
+  constexpr int VPB = 12;
+  constexpr bool PAIR = THREADS < 1024;
   for (int w = w0; w < w1; w++) {
     const int4 d0 = S.win[2 * w], d1 = S.win[2 * w + 1];
     const int v0 = d0.x, v1 = d0.y, lo = d0.z, vs = d0.w, toff = d1.x, nt = d1.y, boff = d1.z, nb = d1.w;
+    WPH_DECL
+    // record loads of a batch (clamped index, no divergence); ahead of time (PF) always MB records, of which a batch computes the first EB
+    constexpr std::integral_constant<int, MB> mbc{};
+    auto tri_load = [&](auto nc, WinTriRecs<MB, PRECISE> &R, int t0) {
+#pragma unroll
+      for (int j = 0; j < decltype(nc)::value; j++) {
+        const int t = min(t0 + j * THREADS, nt - 1);
+        R.r[j] = S.wtri_rec[toff + t]; R.D[j] = S.wtri_D[toff + t];
+        if constexpr (PRECISE) R.Dl[j] = S.wtri_Dlo[toff + t];
+      }
+    };
+    auto bend_load = [&](auto nc, WinBendRecs<MB, PRECISE> &R, int e0) {
+#pragma unroll
+      for (int j = 0; j < decltype(nc)::value; j++) {
+        const int e = min(e0 + j * THREADS, nb - 1);
+        R.r[j] = S.wbend_rec[boff + e]; R.w[j] = S.wbend_w[boff + e];
+        if constexpr (PRECISE) R.wl[j] = S.wbend_lo[boff + e];
+      }
+    };
+    WinTriRecs<MB, PRECISE> tcur;
+    WinBendRecs<MB, PRECISE> bcur;
+    if constexpr (PF) { if (nt > 0) tri_load(mbc, tcur, tid); else if (nb > 0) bend_load(mbc, bcur, tid); }
     __syncthreads();
     // two span vertices per thread and round (clamped index, no divergence): their global loads overlap
     for (int j0 = tid; j0 < vs; j0 += 2 * THREADS) {
@@ -75,76 +124,110 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
       if (vb) { stw(L.a2xy, L.a2z, jb, ub); stw(L.a1xy, L.a1z, jb, sb); }
     }
     __syncthreads();
+    WPH(0)
     // per-element phase: up to 4 elements of a thread at a time, their records loaded up front (clamped index, no
     // divergence) so that the L2 round trips and the gather -> math chains of a batch overlap instead of queueing up.
     // The batch size follows the number of rounds left (4, 3 or 2 elements per thread: three unrolled variants) so that
     // e.g. 2250 triangles on 1024 threads cost 3 rounds, not 4. (Exactly ceil(n / THREADS) rounds behind wave-uniform
     // branches inside ONE batch was 2x slower: the branches end the overlap.)
-    auto tri_batch = [&](auto ebc, int t0) {
+    auto tri_compute = [&](auto ebc, const WinTriRecs<MB, PRECISE> &R, int t0) {
       constexpr int EB = decltype(ebc)::value;
-      int4 r[EB];
-      float4 D[EB], Dl[PRECISE ? EB : 1];
-#pragma unroll
-      for (int j = 0; j < EB; j++) {
-        const int t = min(t0 + j * THREADS, nt - 1);
-        r[j] = S.wtri_rec[toff + t]; D[j] = S.wtri_D[toff + t];
-        if constexpr (PRECISE) Dl[j] = S.wtri_Dlo[toff + t];
-      }
 #pragma unroll
       for (int j = 0; j < EB; j++) {
         const int t = t0 + j * THREADS;
-        const int j0 = r[j].x & 0xffff, j1 = (int) ((unsigned) r[j].x >> 16), j2 = r[j].y;
+        const int j0 = R.r[j].x & 0xffff, j1 = (int) ((unsigned) R.r[j].x >> 16), j2 = R.r[j].y;
         f3 r0, r1;
         if constexpr (PRECISE)
           tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
-                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D[j], Dl[j], __int_as_float(r[j].z), r0, r1);
+                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), R.D[j], R.Dl[j], __int_as_float(R.r[j].z), r0, r1);
         else
           tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
-                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), D[j], __int_as_float(r[j].z), r0, r1);
-        if (t < nt) { stw(L.erxy, L.erz, 2 * t, r0); stw(L.erxy, L.erz, 2 * t + 1, r1); }
+                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), R.D[j], __int_as_float(R.r[j].z), r0, r1);
+        if (t < nt) { stw(L.erxy, L.erz, t, r0); stw(L.erxy, L.erz, nt + t, r1); }
       }
     };
-    auto bend_batch = [&](auto ebc, int e0) {
+    auto bend_compute = [&](auto ebc, const WinBendRecs<MB, PRECISE> &R, int e0) {
       constexpr int EB = decltype(ebc)::value;
-      int4 r[EB];
-      float4 wq[EB], wl[PRECISE ? EB : 1];
-#pragma unroll
-      for (int j = 0; j < EB; j++) {
-        const int e = min(e0 + j * THREADS, nb - 1);
-        r[j] = S.wbend_rec[boff + e]; wq[j] = S.wbend_w[boff + e];
-        if constexpr (PRECISE) wl[j] = S.wbend_lo[boff + e];
-      }
 #pragma unroll
       for (int j = 0; j < EB; j++) {
         const int e = e0 + j * THREADS;
-        const int j0 = r[j].x & 0xffff, j1 = (int) ((unsigned) r[j].x >> 16), j2 = r[j].y & 0xffff, j3 = (int) ((unsigned) r[j].y >> 16);
+        const int j0 = R.r[j].x & 0xffff, j1 = (int) ((unsigned) R.r[j].x >> 16), j2 = R.r[j].y & 0xffff, j3 = (int) ((unsigned) R.r[j].y >> 16);
         f3 res;
         if constexpr (PRECISE)
           bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
-                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq[j], wl[j],
-                  __int_as_float(r[j].z), __int_as_float(r[j].w), res);
+                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), R.w[j], R.wl[j],
+                  __int_as_float(R.r[j].z), __int_as_float(R.r[j].w), res);
         else
           bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
-                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), wq[j],
-                  __int_as_float(r[j].z), __int_as_float(r[j].w), res);
+                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), R.w[j],
+                  __int_as_float(R.r[j].z), __int_as_float(R.r[j].w), res);
         if (e < nb) stw(L.erxy, L.erz, 2 * nt + e, res);
       }
     };
-    for (int q = 0, rounds = (nt + THREADS - 1) / THREADS; q < rounds;) {      // wave-uniform control flow
-      const int left = rounds - q, t0 = q * THREADS + tid;
-      q += batch_dispatch<kWinMaxBatch>(left, [&](auto ebc) { tri_batch(ebc, t0); });
-    }
-    for (int q = 0, rounds = (nb + THREADS - 1) / THREADS; q < rounds;) {
-      const int left = rounds - q, e0 = q * THREADS + tid;
-      q += batch_dispatch<kWinMaxBatch>(left, [&](auto ebc) { bend_batch(ebc, e0); });
+    // first coefficient packets of the per-vertex phase (PF: loaded before the last element batch is computed)
+    const int ia0 = v0 + tid, ib0 = ia0 + THREADS;
+    const int iac = min(ia0, v1 - 1), ibc = min(ib0, v1 - 1);          // clamped: threads without a vertex load a valid row
+    constexpr bool PFP = PF && (DC_WIN_PFP != 0);
+    int4 pea[PFP ? VPB : 1], peb[(PFP && PAIR) ? VPB : 1];
+    auto packets_load = [&]() {
+      if constexpr (!PFP) return;
+      const int cha = __builtin_amdgcn_readfirstlane(iac >> 6);
+      const int npa = S.winc_n[cha];
+      const int4 DC_G *rowa = S.winc + S.winc_ptr[cha] + lane;
+#pragma unroll
+      for (int j = 0; j < VPB; j++) pea[PFP ? j : 0] = rowa[min(j, npa - 1) * 64];
+      if constexpr (PAIR) {
+        const int chb = __builtin_amdgcn_readfirstlane(ibc >> 6);
+        const int npb = S.winc_n[chb];
+        const int4 DC_G *rowb = S.winc + S.winc_ptr[chb] + lane;
+#pragma unroll
+        for (int j = 0; j < VPB; j++) peb[(PFP && PAIR) ? j : 0] = rowb[min(j, npb - 1) * 64];
+      }
+    };
+    const int trounds = (nt + THREADS - 1) / THREADS, brounds = (nb + THREADS - 1) / THREADS;
+    if constexpr (PF) {
+      for (int q = 0; q < trounds;) {      // wave-uniform control flow
+        const int left = trounds - q, t0 = q * THREADS + tid;
+        const int take = left >= MB ? MB : (left > 2 ? left : 2);
+        WinTriRecs<MB, PRECISE> tnxt;
+        const bool more = q + take < trounds;
+        if (more) tri_load(mbc, tnxt, (q + take) * THREADS + tid);
+        else if (nb > 0) bend_load(mbc, bcur, tid);
+        else packets_load();
+        batch_dispatch<MB>(left, [&](auto ebc) { tri_compute(ebc, tcur, t0); });
+        if (more) tcur = tnxt;
+        q += take;
+      }
+      WPH(1)
+      for (int q = 0; q < brounds;) {
+        const int left = brounds - q, e0 = q * THREADS + tid;
+        const int take = left >= MB ? MB : (left > 2 ? left : 2);
+        WinBendRecs<MB, PRECISE> bnxt;
+        const bool more = q + take < brounds;
+        if (more) bend_load(mbc, bnxt, (q + take) * THREADS + tid);
+        else packets_load();
+        batch_dispatch<MB>(left, [&](auto ebc) { bend_compute(ebc, bcur, e0); });
+        if (more) bcur = bnxt;
+        q += take;
+      }
+      if (trounds == 0 && brounds == 0) packets_load();
+    } else {
+      for (int q = 0; q < trounds;) {      // wave-uniform control flow
+        const int left = trounds - q, t0 = q * THREADS + tid;
+        q += batch_dispatch<MB>(left, [&](auto ebc) { tri_load(ebc, tcur, t0); tri_compute(ebc, tcur, t0); });
+      }
+      WPH(1)
+      for (int q = 0; q < brounds;) {
+        const int left = brounds - q, e0 = q * THREADS + tid;
+        q += batch_dispatch<MB>(left, [&](auto ebc) { bend_load(ebc, bcur, e0); bend_compute(ebc, bcur, e0); });
+      }
     }
     __syncthreads();
+    WPH(2)
     // per-vertex phase. All packets of a vertex travel in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2
     // + 12 flaps = 24 pairs); clamped index + masked coefficient instead of divergence, wider rows take another round.
     // With fewer threads than owned vertices (512-thread kernels) a thread handles two vertices at once so that the
     // table loads of both rounds overlap.
-    constexpr int VPB = 12;
-    constexpr bool PAIR = THREADS < 1024;
     auto gather = [&](const int4 (&e)[VPB], int s0, int np, float &sx, float &sy, float &sz) {
 #pragma unroll
       for (int j = 0; j < VPB; j++) {
@@ -156,7 +239,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
       }
     };
-    for (int i = v0 + tid; i < v1; i += (PAIR ? 2 : 1) * THREADS) {
+    for (int i = ia0; i < v1; i += (PAIR ? 2 : 1) * THREADS) {
+      const bool first = PFP && i == ia0;
       const int cha = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
       const int npa = S.winc_n[cha];
       const int4 DC_G *rowa = S.winc + S.winc_ptr[cha] + lane;
@@ -170,8 +254,13 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         float bx = 0.f, by = 0.f, bz = 0.f;
         for (int s0 = 0; s0 < max(npa, npb); s0 += VPB) {
           int4 ea[VPB], eb[VPB];
+          if (first && s0 == 0) {
 #pragma unroll
-          for (int j = 0; j < VPB; j++) { ea[j] = rowa[min(s0 + j, npa - 1) * 64]; eb[j] = rowb[min(s0 + j, npb - 1) * 64]; }
+            for (int j = 0; j < VPB; j++) { ea[j] = pea[PFP ? j : 0]; eb[j] = peb[(PFP && PAIR) ? j : 0]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < VPB; j++) { ea[j] = rowa[min(s0 + j, npa - 1) * 64]; eb[j] = rowb[min(s0 + j, npb - 1) * 64]; }
+          }
           gather(ea, s0, npa, ax, ay, az);
           gather(eb, s0, npb, bx, by, bz);
         }
@@ -180,20 +269,26 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
       } else {
         for (int s0 = 0; s0 < npa; s0 += VPB) {
           int4 ea[VPB];
+          if (first && s0 == 0) {
 #pragma unroll
-          for (int j = 0; j < VPB; j++) ea[j] = rowa[min(s0 + j, npa - 1) * 64];
+            for (int j = 0; j < VPB; j++) ea[j] = pea[PFP ? j : 0];
+          } else {
+#pragma unroll
+            for (int j = 0; j < VPB; j++) ea[j] = rowa[min(s0 + j, npa - 1) * 64];
+          }
           gather(ea, s0, npa, ax, ay, az);
         }
         vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
       }
     }
+    WPH(3)
   }
 }
 
-template <int THREADS, bool PRECISE = false, class Stage1, class TriOp, class BendOp, class VertOp>
+template <int THREADS, bool PRECISE = false, bool PF = false, class Stage1, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, Stage1 stage1,
                                                 const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
-  element_windows_t<THREADS, PRECISE>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
+  element_windows_t<THREADS, PRECISE, PF>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
 }
 
 // ---- forward local step: a = x_n, b = v (current iterate); x = x_n + h v, edges formed as differences first ----

@@ -42,6 +42,8 @@ def bench_args(**over):
     d = dict(grid=100, fold_rows=5, fold_gap=0.02, flap_force=2.0, h=1.0 / 180, fwd_tol=1e-8, bwd_tol=5e-4, cg_tol=1e-4, cg_max=500,
              adjoint_mode=1, adjoint_rel_tol=1e-6, block_precond=0, selfcollision=1, warmup=5, cpu_threads=0)
     d.update(over)
+    if os.environ.get("BENCH_CG_TOL"):          # development: the parity gate at another inner tolerance
+        d["cg_tol"] = float(os.environ["BENCH_CG_TOL"])
     return types.SimpleNamespace(**d)
 
 
