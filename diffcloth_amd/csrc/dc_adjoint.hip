@@ -221,15 +221,21 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   const int N = S.N;
   const float h2 = S.h * S.h;
   float a1 = 0.f, a2 = 0.f;
-  auto vert = [&](int i, f3 sum, f3 yi) {
-    f3 z = ld3(zin, i, N);
-    if (precond) z = z * S.dinv[i];
-    f3 o = z * S.mass[i] + sum;
-    if (S.att_of_vertex[i] >= 0) o = o + yi * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
+  struct VertIn { f3 z, d; float m; int a; };      // a vertex's global reads, issued ahead of the gather (dc_winlib.h)
+  auto vert = vert_with_pre([&](int i) {
+    VertIn q;
+    q.z = ld3(zin, i, N);
+    if (precond) q.z = q.z * S.dinv[i];
+    q.d = d1 ? ld3(d1, i, N) : mk(0, 0, 0);
+    q.m = S.mass[i]; q.a = S.att_of_vertex[i];
+    return q;
+  }, [&](int i, f3 sum, f3 yi, const VertIn &q) {
+    f3 o = q.z * q.m + sum;
+    if (q.a >= 0) o = o + yi * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
     st3(out, i, N, o);
-    if (d1) a1 += dot(o, ld3(d1, i, N));
+    if (d1) a1 += dot(o, q.d);
     a2 += dot(o, o);
-  };
+  });
   // y = (I + dr_df)^T z differs from z only at the contact vertices: the layered self contacts couple the ~2 x nself vertices of
   // their working set (the layers run on those alone, in LDS, before the windows use it), the primitive contacts are block diagonal
   // (one pass over the list of their vertices); both leave y in global memory, every other vertex is staged as z itself. (Before:

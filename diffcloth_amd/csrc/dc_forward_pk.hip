@@ -148,6 +148,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     if (S.win_ok) {
       // ---- local step + vertex pass, window by window inside LDS (dc_winlib.h) ----
       float *scr = W.cg_r + off;
+      // (issuing the vertex's global reads ahead of the gather — dc_winlib.h, vert_with_pre — costs this kernel 176 B more scratch per
+      // lane and 3 ms per batch step: its registers are the PCG's)
       auto vert = [&](int i, f3 sum, f3) {
         f3 rhs = vertex_body(i, sum);
         st3(scr, i, N, rhs);

@@ -68,6 +68,20 @@ static __device__ long long g_win_ph[4];
 
 // PRECISE: the element operators also receive the low-order parts of the element's rest data (wtri_Dlo / wbend_lo) — the
 // fp64-strain operators of the forward step (PreciseTriOp / PreciseBendOp, HybridTriOp / HybridBendOp below).
+// A per-vertex operator may come with a `pre(i)` member: the global loads its vertex needs (returned as a value, handed back as the
+// fourth argument). The per-vertex phase calls it BEFORE the coefficient packets are consumed, for both vertices of a pair, so that
+// those loads travel with the packets instead of starting after the gather — and, for the second vertex of a pair, after the first
+// vertex's stores, which the compiler may not move them across (one exposed L2 round trip per vertex and window otherwise).
+template <class V, class = void> struct vert_has_pre : std::false_type {};
+template <class V> struct vert_has_pre<V, std::void_t<decltype(std::declval<V &>().pre(0))>> : std::true_type {};
+template <class P, class O>
+struct VertWithPre {
+  P p; O o;
+  __device__ __forceinline__ auto pre(int i) { return p(i); }
+  template <class Q> __device__ __forceinline__ void operator()(int i, f3 sum, f3 a, const Q &q) { o(i, sum, a, q); }
+};
+template <class P, class O> __device__ __forceinline__ VertWithPre<P, O> vert_with_pre(P p, O o) { return VertWithPre<P, O>{p, o}; }
+
 // PF (software pipelining): the table records of a batch are loaded one batch ahead — the first triangle batch before the window is
 // staged, the next batch (or the first bending batch, or the first coefficient packets of the per-vertex phase) before the current
 // one is computed — so that an L2 round trip (1.5-2 k cycles, and both waves of a SIMD sit in the same phase) is no longer exposed
@@ -252,6 +266,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         const int npb = S.winc_n[chb];
         const int4 DC_G *rowb = S.winc + S.winc_ptr[chb] + lane;
         float bx = 0.f, by = 0.f, bz = 0.f;
+        auto prea = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(i); else return 0; }();
+        auto preb = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(vb ? ib : i); else return 0; }();
         for (int s0 = 0; s0 < max(npa, npb); s0 += VPB) {
           int4 ea[VPB], eb[VPB];
           if (first && s0 == 0) {
@@ -264,9 +280,15 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
           gather(ea, s0, npa, ax, ay, az);
           gather(eb, s0, npb, bx, by, bz);
         }
-        vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
-        if (vb) vert_op(ib, mk(bx, by, bz), ldw(L.a1xy, L.a1z, ib - lo));
+        if constexpr (vert_has_pre<VertOp>::value) {
+          vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo), prea);
+          if (vb) vert_op(ib, mk(bx, by, bz), ldw(L.a1xy, L.a1z, ib - lo), preb);
+        } else {
+          vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
+          if (vb) vert_op(ib, mk(bx, by, bz), ldw(L.a1xy, L.a1z, ib - lo));
+        }
       } else {
+        auto prea = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(i); else return 0; }();
         for (int s0 = 0; s0 < npa; s0 += VPB) {
           int4 ea[VPB];
           if (first && s0 == 0) {
@@ -278,7 +300,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
           }
           gather(ea, s0, npa, ax, ay, az);
         }
-        vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
+        if constexpr (vert_has_pre<VertOp>::value) vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo), prea);
+        else vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));
       }
     }
     WPH(3)
