@@ -121,7 +121,7 @@ static void check_windows(const HostSystem &H, size_t budget, int expect_min_win
       for (int q = 0; q < 3; q++) if (lo + j[q] != H.tri[3 * t + q]) fail("windows: triangle record vertices");
       if (asfloat(r[2]) != (float) H.tri_w2[t]) fail("windows: triangle weight");
       for (int q = 0; q < 4; q++) if (W.tri_D[4 * (size_t) (toff + k) + q] != (float) H.tri_D[4 * t + q]) fail("windows: triangle D");
-      er[2 * k] = r0[t]; er[2 * k + 1] = r1[t];
+      er[k] = r0[t]; er[nt + k] = r1[t];          // two result planes: first columns [0, nt), second [nt, 2 nt)
     }
     // flaps are identified by their vertices
     std::map<std::vector<int>, int> flap;
