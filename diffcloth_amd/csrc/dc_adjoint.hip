@@ -214,7 +214,9 @@ struct SelfInOut {
 };
 
 // Same operator with the element pass inside LDS (element windows, dc_winlib.h): no corner array, no atomics.
-template <int THREADS, bool WIN>
+// PRE: the per-vertex phase issues a vertex's global reads ahead of the gather (vert_with_pre, dc_winlib.h) — pays on the 10 000-vertex
+// cloth (12.95 -> 12.73 ms per batch step), costs the block-preconditioned garment kernels 36 B more scratch and 3 ... 8 % (they pass false)
+template <int THREADS, bool WIN, bool PRE>
 __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCtx &C, const float *zin, bool precond,
                                                  float *out, const float *d1, float &dot1, float &dot2) {
   if constexpr (!WIN) { adjoint_operator_global<THREADS>(S, C, zin, precond, out, d1, dot1, dot2); return; }
@@ -222,7 +224,16 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
   const float h2 = S.h * S.h;
   float a1 = 0.f, a2 = 0.f;
   struct VertIn { f3 z, d; float m; int a; };      // a vertex's global reads, issued ahead of the gather (dc_winlib.h)
-  auto vert = vert_with_pre([&](int i) {
+  auto vert_plain = [&](int i, f3 sum, f3 yi) {
+    f3 z = ld3(zin, i, N);
+    if (precond) z = z * S.dinv[i];
+    f3 o = z * S.mass[i] + sum;
+    if (S.att_of_vertex[i] >= 0) o = o + yi * (h2 * S.k_att);
+    st3(out, i, N, o);
+    if (d1) a1 += dot(o, ld3(d1, i, N));
+    a2 += dot(o, o);
+  };
+  auto vert_pre = vert_with_pre([&](int i) {
     VertIn q;
     q.z = ld3(zin, i, N);
     if (precond) q.z = q.z * S.dinv[i];
@@ -236,12 +247,24 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
     if (d1) a1 += dot(o, q.d);
     a2 += dot(o, o);
   });
+  auto vert = [&]() { if constexpr (PRE) return vert_pre; else return vert_plain; }();
   // y = (I + dr_df)^T z differs from z only at the contact vertices: the layered self contacts couple the ~2 x nself vertices of
   // their working set (the layers run on those alone, in LDS, before the windows use it), the primitive contacts are block diagonal
   // (one pass over the list of their vertices); both leave y in global memory, every other vertex is staged as z itself. (Before:
   // two passes over all N vertices per operator application, 49 k of its 290 k cycles on the 10 000-vertex cloth with 500 self and
   // 400 primitive contacts; forming y_i inside the staging instead costs three dependent loads per span vertex, halo included.)
   APH_DECL
+  if (C.nself == 0 && (C.mark == nullptr || S.nwin < 4)) {
+    // primitive contacts only on a mesh of a few windows (the garment scenes): an operator application there is a chain of latencies, and
+    // the list pass with its barrier is one more link — y_i is formed per vertex while the window is staged (the halo is small)
+    element_windows<THREADS>(S, C.lds, [&](int i) {
+      f3 z = ld3(zin, i, N);
+      if (precond) z = z * S.dinv[i];
+      return z + contact_JT(S, C, i, z);
+    }, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
+    dot1 = a1; dot2 = a2;
+    return;
+  }
   bool sparse = C.mark != nullptr;
   if (sparse && C.nself > 0) sparse = self_JT_layers_lds_v<THREADS>(S, C.self, C.b, SelfInOut{zin, precond ? S.dinv : nullptr, C.y, N}, C.lds, C.lds_floats);   // ends with a barrier
   if (sparse) {
@@ -255,8 +278,8 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
     }
     __syncthreads();
     APH(0)
-    element_windows<THREADS>(S, C.lds, [&](int i) {      // (both candidates loaded, then selected: one memory round trip, not two)
-      const int m = mark[i];
+    element_windows<THREADS>(S, C.lds, [&](int i) {      // (both candidates loaded, then selected: one memory round trip, not two —
+      const int m = mark[i];                              //  loading y only behind the mark: 12.7 -> 13.2 ms per batch step)
       const f3 yi = ld3(C.y, i, N);
       f3 z = ld3(zin, i, N);
       if (precond) z = z * S.dinv[i];
@@ -311,8 +334,8 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
     int in_status = (rr <= in_stop) ? 1 : 0;
     for (int k = kdone; k < kcap && in_status == 0; k++, kdone++) {
       // v = K M^-1 p ;  alpha = rho / (rhat . v)
-      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, ph, false, v, rhat, d1, d2);
-      else adjoint_operator<THREADS, WIN>(S, C, p, true, v, rhat, d1, d2);
+      if constexpr (BLK) adjoint_operator<THREADS, WIN, false>(S, C, ph, false, v, rhat, d1, d2);
+      else adjoint_operator<THREADS, WIN, true>(S, C, p, true, v, rhat, d1, d2);
       double rv = block_sum<THREADS>((double) d1, red);
       if (!(fabs(rv) > 1e-300)) { in_status = 2; break; }
       const float alpha = (float) (rho / rv);
@@ -339,8 +362,8 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
         rr = ss; in_status = 1; break;
       }
       // t = K M^-1 s ;  omega = (t . s) / (t . t)
-      if constexpr (BLK) adjoint_operator<THREADS, WIN>(S, C, sh, false, t, r, d1, d2);
-      else adjoint_operator<THREADS, WIN>(S, C, r, true, t, r, d1, d2);
+      if constexpr (BLK) adjoint_operator<THREADS, WIN, false>(S, C, sh, false, t, r, d1, d2);
+      else adjoint_operator<THREADS, WIN, true>(S, C, r, true, t, r, d1, d2);
       double ts = (double) d1, tt = (double) d2;
       block_sum2<THREADS>(ts, tt, red);
       if (!(tt > 1e-300)) { in_status = 2; break; }
@@ -479,7 +502,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     int since_progress = 0;
     for (int it = 0; it < A.it_cap; it++) {
       float d1, d2;
-      adjoint_operator<THREADS, WIN>(S, C, u, false, cg_ap, nullptr, d1, d2);
+      adjoint_operator<THREADS, WIN, false>(S, C, u, false, cg_ap, nullptr, d1, d2);
       __syncthreads();          // the windows hand out vertices in their own order: K u is complete only after a barrier
       part = 0.f;
       for (int i = tid; i < N; i += THREADS) {

@@ -29,11 +29,6 @@
 
 namespace dc {
 
-#ifndef DC_WIN_PF
-#define DC_WIN_PF 0
-#endif
-constexpr bool kWinPrefetchFwd = DC_WIN_PF != 0;     // software-pipelined table loads in the element windows (dc_winlib.h)
-
 #ifdef DC_PROFILE_PHASES
 #define PH_DECL long long ph_t = clock64(); long long ph_acc[6] = {0, 0, 0, 0, 0, 0}; if (blockIdx.x == 0 && threadIdx.x == 0) { g_win_ph[0] = g_win_ph[1] = g_win_ph[2] = g_win_ph[3] = 0; }
 #define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
@@ -155,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         st3(scr, i, N, rhs);
         part += dot(rhs, rhs);
       };
-      element_windows<THREADS, kFwdOpsPrecise, kWinPrefetchFwd>(S, lp, StagePlanar{xn, N}, vnow, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
+      element_windows<THREADS, kFwdOpsPrecise>(S, lp, StagePlanar{xn, N}, vnow, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
       __syncthreads();
       PH(0)
       if (nself > 0 && !A.self_full) {
@@ -486,11 +481,7 @@ bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &
   if (!S.pk_ok) return false;
 #ifdef DC_PK_ONLY20      // development builds: only the 10 000-vertex variant (compile time)
   if (S.pk_vpt != 20) return false;
-#ifdef DC_PK_1024
-  launch_pk<1024, 10, DC_PK_1024>(S, W, A, B, st);
-#else
   launch_pk<512, 20, 6>(S, W, A, B, st);
-#endif
   return true;
 #else
   switch (S.pk_vpt) {

@@ -43,9 +43,6 @@ struct In2Plain {
 #define DC_WIN_EB 4
 #endif
 constexpr int kWinMaxBatch = DC_WIN_EB;
-#ifndef DC_WIN_PFP
-#define DC_WIN_PFP 1
-#endif
 template <int MAXB, class F>
 __device__ __forceinline__ int batch_dispatch(int left, F f) {
   if constexpr (MAXB <= 2) { f(std::integral_constant<int, 2>()); return 2; }
@@ -82,17 +79,12 @@ struct VertWithPre {
 };
 template <class P, class O> __device__ __forceinline__ VertWithPre<P, O> vert_with_pre(P p, O o) { return VertWithPre<P, O>{p, o}; }
 
-// PF (software pipelining): the table records of a batch are loaded one batch ahead — the first triangle batch before the window is
-// staged, the next batch (or the first bending batch, or the first coefficient packets of the per-vertex phase) before the current
-// one is computed — so that an L2 round trip (1.5-2 k cycles, and both waves of a SIMD sit in the same phase) is no longer exposed
-// at every batch. Costs the registers of one more batch (48) and, across the barrier into the per-vertex phase, of its packets
-// (48 / 96): for the kernels with 256 registers per thread.
 template <int EB, bool PRECISE>
 struct WinTriRecs { int4 r[EB]; float4 D[EB]; float4 Dl[PRECISE ? EB : 1]; };
 template <int EB, bool PRECISE>
 struct WinBendRecs { int4 r[EB]; float4 w[EB]; float4 wl[PRECISE ? EB : 1]; };
 
-template <int THREADS, bool PRECISE = false, bool PF = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
+template <int THREADS, bool PRECISE = false, class TB, class Stage1, class In2, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, float *lds, Stage1 stage1,
                                                   In2 in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -104,8 +96,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     const int4 d0 = S.win[2 * w], d1 = S.win[2 * w + 1];
     const int v0 = d0.x, v1 = d0.y, lo = d0.z, vs = d0.w, toff = d1.x, nt = d1.y, boff = d1.z, nb = d1.w;
     WPH_DECL
-    // record loads of a batch (clamped index, no divergence); ahead of time (PF) always MB records, of which a batch computes the first EB
-    constexpr std::integral_constant<int, MB> mbc{};
+    // record loads of a batch (clamped index, no divergence)
     auto tri_load = [&](auto nc, WinTriRecs<MB, PRECISE> &R, int t0) {
 #pragma unroll
       for (int j = 0; j < decltype(nc)::value; j++) {
@@ -124,7 +115,6 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     };
     WinTriRecs<MB, PRECISE> tcur;
     WinBendRecs<MB, PRECISE> bcur;
-    if constexpr (PF) { if (nt > 0) tri_load(mbc, tcur, tid); else if (nb > 0) bend_load(mbc, bcur, tid); }
     __syncthreads();
     // two span vertices per thread and round (clamped index, no divergence): their global loads overlap
     for (int j0 = tid; j0 < vs; j0 += 2 * THREADS) {
@@ -178,63 +168,14 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         if (e < nb) stw(L.erxy, L.erz, 2 * nt + e, res);
       }
     };
-    // first coefficient packets of the per-vertex phase (PF: loaded before the last element batch is computed)
-    const int ia0 = v0 + tid, ib0 = ia0 + THREADS;
-    const int iac = min(ia0, v1 - 1), ibc = min(ib0, v1 - 1);          // clamped: threads without a vertex load a valid row
-    constexpr bool PFP = PF && (DC_WIN_PFP != 0);
-    int4 pea[PFP ? VPB : 1], peb[(PFP && PAIR) ? VPB : 1];
-    auto packets_load = [&]() {
-      if constexpr (!PFP) return;
-      const int cha = __builtin_amdgcn_readfirstlane(iac >> 6);
-      const int npa = S.winc_n[cha];
-      const int4 DC_G *rowa = S.winc + S.winc_ptr[cha] + lane;
-#pragma unroll
-      for (int j = 0; j < VPB; j++) pea[PFP ? j : 0] = rowa[min(j, npa - 1) * 64];
-      if constexpr (PAIR) {
-        const int chb = __builtin_amdgcn_readfirstlane(ibc >> 6);
-        const int npb = S.winc_n[chb];
-        const int4 DC_G *rowb = S.winc + S.winc_ptr[chb] + lane;
-#pragma unroll
-        for (int j = 0; j < VPB; j++) peb[(PFP && PAIR) ? j : 0] = rowb[min(j, npb - 1) * 64];
-      }
-    };
-    const int trounds = (nt + THREADS - 1) / THREADS, brounds = (nb + THREADS - 1) / THREADS;
-    if constexpr (PF) {
-      for (int q = 0; q < trounds;) {      // wave-uniform control flow
-        const int left = trounds - q, t0 = q * THREADS + tid;
-        const int take = left >= MB ? MB : (left > 2 ? left : 2);
-        WinTriRecs<MB, PRECISE> tnxt;
-        const bool more = q + take < trounds;
-        if (more) tri_load(mbc, tnxt, (q + take) * THREADS + tid);
-        else if (nb > 0) bend_load(mbc, bcur, tid);
-        else packets_load();
-        batch_dispatch<MB>(left, [&](auto ebc) { tri_compute(ebc, tcur, t0); });
-        if (more) tcur = tnxt;
-        q += take;
-      }
-      WPH(1)
-      for (int q = 0; q < brounds;) {
-        const int left = brounds - q, e0 = q * THREADS + tid;
-        const int take = left >= MB ? MB : (left > 2 ? left : 2);
-        WinBendRecs<MB, PRECISE> bnxt;
-        const bool more = q + take < brounds;
-        if (more) bend_load(mbc, bnxt, (q + take) * THREADS + tid);
-        else packets_load();
-        batch_dispatch<MB>(left, [&](auto ebc) { bend_compute(ebc, bcur, e0); });
-        if (more) bcur = bnxt;
-        q += take;
-      }
-      if (trounds == 0 && brounds == 0) packets_load();
-    } else {
-      for (int q = 0; q < trounds;) {      // wave-uniform control flow
-        const int left = trounds - q, t0 = q * THREADS + tid;
-        q += batch_dispatch<MB>(left, [&](auto ebc) { tri_load(ebc, tcur, t0); tri_compute(ebc, tcur, t0); });
-      }
-      WPH(1)
-      for (int q = 0; q < brounds;) {
-        const int left = brounds - q, e0 = q * THREADS + tid;
-        q += batch_dispatch<MB>(left, [&](auto ebc) { bend_load(ebc, bcur, e0); bend_compute(ebc, bcur, e0); });
-      }
+    for (int q = 0, rounds = (nt + THREADS - 1) / THREADS; q < rounds;) {      // wave-uniform control flow
+      const int left = rounds - q, t0 = q * THREADS + tid;
+      q += batch_dispatch<MB>(left, [&](auto ebc) { tri_load(ebc, tcur, t0); tri_compute(ebc, tcur, t0); });
+    }
+    WPH(1)
+    for (int q = 0, rounds = (nb + THREADS - 1) / THREADS; q < rounds;) {
+      const int left = rounds - q, e0 = q * THREADS + tid;
+      q += batch_dispatch<MB>(left, [&](auto ebc) { bend_load(ebc, bcur, e0); bend_compute(ebc, bcur, e0); });
     }
     __syncthreads();
     WPH(2)
@@ -253,8 +194,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         sx = fmaf(cb, qb.x, sx); sy = fmaf(cb, qb.y, sy); sz = fmaf(cb, zb, sz);
       }
     };
-    for (int i = ia0; i < v1; i += (PAIR ? 2 : 1) * THREADS) {
-      const bool first = PFP && i == ia0;
+    for (int i = v0 + tid; i < v1; i += (PAIR ? 2 : 1) * THREADS) {
       const int cha = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
       const int npa = S.winc_n[cha];
       const int4 DC_G *rowa = S.winc + S.winc_ptr[cha] + lane;
@@ -270,13 +210,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         auto preb = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(vb ? ib : i); else return 0; }();
         for (int s0 = 0; s0 < max(npa, npb); s0 += VPB) {
           int4 ea[VPB], eb[VPB];
-          if (first && s0 == 0) {
 #pragma unroll
-            for (int j = 0; j < VPB; j++) { ea[j] = pea[PFP ? j : 0]; eb[j] = peb[(PFP && PAIR) ? j : 0]; }
-          } else {
-#pragma unroll
-            for (int j = 0; j < VPB; j++) { ea[j] = rowa[min(s0 + j, npa - 1) * 64]; eb[j] = rowb[min(s0 + j, npb - 1) * 64]; }
-          }
+          for (int j = 0; j < VPB; j++) { ea[j] = rowa[min(s0 + j, npa - 1) * 64]; eb[j] = rowb[min(s0 + j, npb - 1) * 64]; }
           gather(ea, s0, npa, ax, ay, az);
           gather(eb, s0, npb, bx, by, bz);
         }
@@ -291,13 +226,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         auto prea = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(i); else return 0; }();
         for (int s0 = 0; s0 < npa; s0 += VPB) {
           int4 ea[VPB];
-          if (first && s0 == 0) {
 #pragma unroll
-            for (int j = 0; j < VPB; j++) ea[j] = pea[PFP ? j : 0];
-          } else {
-#pragma unroll
-            for (int j = 0; j < VPB; j++) ea[j] = rowa[min(s0 + j, npa - 1) * 64];
-          }
+          for (int j = 0; j < VPB; j++) ea[j] = rowa[min(s0 + j, npa - 1) * 64];
           gather(ea, s0, npa, ax, ay, az);
         }
         if constexpr (vert_has_pre<VertOp>::value) vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo), prea);
@@ -308,10 +238,10 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
   }
 }
 
-template <int THREADS, bool PRECISE = false, bool PF = false, class Stage1, class TriOp, class BendOp, class VertOp>
+template <int THREADS, bool PRECISE = false, class Stage1, class TriOp, class BendOp, class VertOp>
 __device__ __forceinline__ void element_windows(const DevSystem &S, float *lds, Stage1 stage1,
                                                 const float *__restrict__ in2, TriOp tri_op, BendOp bend_op, VertOp vert_op) {
-  element_windows_t<THREADS, PRECISE, PF>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
+  element_windows_t<THREADS, PRECISE>(S, 0, S.nwin, lds, stage1, In2Plain{in2, S.N}, tri_op, bend_op, vert_op);
 }
 
 // ---- forward local step: a = x_n, b = v (current iterate); x = x_n + h v, edges formed as differences first ----
