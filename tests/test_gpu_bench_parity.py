@@ -51,6 +51,8 @@ def bench_args(**over):
 def test_bench_configuration_matches_oracle(B, sample):
     """B = 256: bench.py --gpus 1; B = 32: one rank of bench.py --gpus 8 (the metric's batch sharded), each rollout split over 8 CUs."""
     args = bench_args()
+    if os.environ.get("BENCH_PARITY_N"):      # a wider sample for a one-off survey (DESIGN.md section 5): that many rollouts, evenly spaced
+        sample = tuple(int(q) for q in np.linspace(0, B - 1, int(os.environ["BENCH_PARITY_N"])))
     W, S = 5, 3
     V, F, V0, flap, center = bench.scene(args)
     e = bench.make_engine(0, args, V, F, center)
