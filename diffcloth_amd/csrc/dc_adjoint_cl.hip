@@ -17,6 +17,16 @@
 #include "dc_adjoint64.h"
 #include <algorithm>
 
+#ifdef DC_PROFILE_PHASES
+#define CAPH_DECL long long caph_t = clock64(); long long caph[4] = {0, 0, 0, 0};
+#define CAPH(k) { long long n_ = clock64(); caph[k] += n_ - caph_t; caph_t = n_; }
+#define CAPH_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("[phases adj-cl] iters %d cycles %d | per step: setup %lld fp32 solves %lld fp64 residuals %lld final %lld cycles\n", iters, cycles, caph[0], caph[1], caph[2], caph[3]);
+#else
+#define CAPH_DECL
+#define CAPH(k)
+#define CAPH_PRINT
+#endif
+
 namespace dc {
 
 constexpr int kMaxRefine = 6;          // fp32 correction solves of the mixed-precision direct adjoint solve before the fp64 fall-back
@@ -224,10 +234,12 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   W64.u = W.u64 + off; W64.r = W.r64 + off; W64.y = W.y64 + off; W64.x = W.x64 + off; W64.corner = W.c64 + (size_t) b * 3 * S.NC;
   W64.rhat = W.k64[0] + off; W64.p = W.k64[1] + off; W64.v = W.k64[2] + off; W64.t = W.k64[3] + off; W64.ph = W.k64[4] + off; W64.sh = W.k64[5] + off;
   int cycles = 0, iters64 = 0;
+  CAPH_DECL
   for (int i = r0 + tid; i < r1; i += THREADS) st3d(W64.u, i, N, mkd(0, 0, 0));
   tm.X = X;
   if (!prepare_x64<THREADS>(S, C64, tm, W64.x)) return;
   X = tm.X;
+  CAPH(0)
   double rr_true = gnorm * gnorm;
   if (gnorm > 0) {
     // ---- direct solve of K u = g in mixed precision (see dc_adjoint.hip): fp32 BiCGSTAB for corrections of the fp64 residual ----
@@ -375,9 +387,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     // per step on the 10k-vertex workload; the first solve, whose right-hand side is g itself, is always checked in fp64.
     if (!A.verify_all && cycles >= 1 && in_status == 1 && rr <= 0.25 * stop) { rr_true = rr; status = 1; cycles++; break; }
     // the true residual, in fp64
+    CAPH(1)
     tm.X = X;
     auto rs = residual64<THREADS>(S, C64, tm, W64, gx, gscale);
     tm = rs.tm; X = tm.X;
+    CAPH(2)
     if (rs.res < 0) return;
     double rr_new = rs.rr;
     if (rr_new <= stop) { rr_true = rr_new; status = 1; cycles++; break; }
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   }
   udiff = sqrt(rr_true) / (gnorm > 0 ? gnorm : 1.0);     // relative residual: fp64-evaluated (mixed precision) or the fp32 recurrence's
   __syncthreads();
+  CAPH(1)
   // ---- gradients w.r.t. the previous state and parameters (Simulation.cpp:1534, 1608-1650), in fp64 from u ----
   {
     tm.X = X;
@@ -430,6 +445,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     tm = rf.tm; X = tm.X;
     if (rf.res < 0) return;
   }
+  CAPH(3)
+  CAPH_PRINT
   if (tid == 0 && part == 0) {
     dc_bwd_stats s;
     s.converged = status; s.adjoint_iters = iters; s.cg_iters = 0; s.clipped = clipped;

@@ -1,4 +1,4 @@
-OUT=gpurun_out/r03y; mkdir -p $OUT
+OUT=gpurun_out/round_check; mkdir -p $OUT
 for a in "" "--total-batch 32"; do
 ( timeout 300 python bench.py --steps 20 --warmup 5 --tshirt 0 --cpu-steps 0 $a > $OUT/bench.log 2>&1 )
 grep '"metric"' $OUT/bench.log | python -c "
