@@ -168,6 +168,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   int lb, part;
   cluster_map(K, lb, part);
   if (lb >= nb_real) return;       // padding workgroups: the launch is rounded up to a multiple of 8 rollouts (see the launcher)
+  if (CL.test_drop && lb == 0 && part == K - 1) return;      // test hook: a part that never arrives (tests/test_gpu_cluster.py)
   const int b = b0 + lb;
   Xch X = xch_init(CL, lb, part, dyn_lds + tail_off);
   if (!xch_hello<THREADS>(X)) return;

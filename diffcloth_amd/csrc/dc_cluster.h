@@ -50,6 +50,8 @@ struct DevCluster {
   int pk_vpt, pad0;            // rows per thread of the 512-thread forward kernel = ceil(R / 512)
   v4i *xch;                    // [nb][K][2][xch_stride] granules, zeroed before every launch
   unsigned *err;               // [4] sticky: [0] != 0 -> an exchange timed out
+  long long spin_limit;        // bound of every spin in ticks of the 100 MHz wall clock (kSpinLimit; tests shorten it: DC_TEST_SPIN_MS)
+  int test_drop;               // test hook (DC_TEST_DROP_PART=1): the last part of the launch's first rollout leaves at once — its peers must time out cleanly
   const DevCluster *self_dev;
 };
 
@@ -93,6 +95,7 @@ struct Xch {
   int part, K, HB, stride;
   int site;                     // diagnostic: which exchange of the kernel is running (recorded when a poll gives up)
   bool same_xcd;                // every part of this rollout runs on one XCD (xch_hello): granules may stay in its L2
+  long long limit;              // spin bound (DevCluster::spin_limit)
   float *lsum;                  // LDS [2][4]: the totals of the current exchange, double-buffered by sequence parity
   int *ldead;                   // LDS flag: an exchange of this workgroup timed out
   unsigned *err;
@@ -111,7 +114,7 @@ __device__ __forceinline__ Xch xch_init(const DevCluster &CL, int lb, int part, 
   const size_t per = (size_t) CL.K * 2 * CL.xch_stride;
   X.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (CL.xch + (size_t) lb * per), 0, (int) (per * 16), 0x00020000);
   X.seq = 0; X.site = 0; X.same_xcd = false; X.part = part; X.K = CL.K; X.HB = CL.HB; X.stride = CL.xch_stride;
-  X.lsum = lds_tail; X.ldead = (int *) (lds_tail + 8); X.err = CL.err;
+  X.lsum = lds_tail; X.ldead = (int *) (lds_tail + 8); X.err = CL.err; X.limit = CL.spin_limit;
   if (threadIdx.x == 0) *X.ldead = 0;
   return X;
 }
@@ -167,7 +170,7 @@ __device__ __forceinline__ bool xch_poll(const Xch &X, int off, v4i &g) {
       const long long now = (long long) __builtin_amdgcn_s_memrealtime();
       if (t0 == 0) t0 = now;
       else if (__hip_atomic_load(X.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      else if (now - t0 > kSpinLimit) {
+      else if (now - t0 > X.limit) {
         // the first poll to give up leaves a record: [1] sequence number waited for, [2] tag seen, [3] site | part << 8 | granule offset << 12
         if (atomicCAS(X.err, 0u, 1u) == 0u) { X.err[1] = X.seq; X.err[2] = (unsigned) g.w; X.err[3] = (unsigned) X.site | ((unsigned) X.part << 8) | ((unsigned) (off / 16) << 12); }
         return false;

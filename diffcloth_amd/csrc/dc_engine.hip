@@ -315,6 +315,9 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   DevCluster &D = cl.D;
   std::memset(&D, 0, sizeof(D));
   D.K = K; D.R = R; D.HB = HB; D.wpp = wpp; D.xch_stride = kXchWaves + 2 * HB; D.pk_vpt = vpt;
+  D.spin_limit = kSpinLimit; D.test_drop = 0;
+  if (const char *ev = getenv("DC_TEST_SPIN_MS")) { const long long ms = atoll(ev); if (ms > 0) D.spin_limit = ms * 100000ll; }      // test hooks
+  if (const char *ev = getenv("DC_TEST_DROP_PART")) D.test_drop = ev[0] == '1';
   int rc;
   const int *ip; const float *fp;
   if ((rc = upload_cl<int>(c, &ip, HW.win))) return rc;

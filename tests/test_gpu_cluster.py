@@ -283,3 +283,41 @@ def test_split_on_a_garment_with_moving_clips_agrees_with_one_workgroup():
             if mode == 1 and state <= 5e-5 and param <= 1e-4:
                 tight += 1
     assert tight >= 2, tight
+
+
+def test_a_part_that_never_arrives_is_a_clean_error_not_a_hang(monkeypatch):
+    """What a second tenant on the GPU can do to a split launch — a part of a rollout is not running while its peers wait for it — provoked
+    deterministically: the engine's test hook makes the last part of the first rollout leave at once (DC_TEST_DROP_PART) and shortens the
+    spin bound from 2 s to 0.2 s (DC_TEST_SPIN_MS). Every exchange of that rollout must time out, the kernels must end, the call must
+    fail with DC_ERR_HIP and a message that says what happened — for the forward and for the backward kernel — the other rollouts of the
+    launch are not part of the claim; a context built afterwards (one workgroup per rollout) works."""
+    import time
+    monkeypatch.setenv("DC_TEST_SPIN_MS", "200")
+    monkeypatch.setenv("DC_TEST_DROP_PART", "1")
+    B = 8
+    V, F, e, o = sphere_scene(48)
+    X0, MU = starts(V, B)
+    with cluster_env(4):
+        e.alloc_batch(B, 2)
+    assert e.cluster() == 4
+    e.set_mu(MU)
+    e.set_state(0, X0, np.zeros_like(X0))
+    t0 = time.perf_counter()
+    with pytest.raises(capi.DcError, match="exchange timed out"):
+        e.step_forward(0)
+    with pytest.raises(capi.DcError, match="exchange timed out"):
+        e.rollout_forward(0, 2)
+    gx = f32(np.random.default_rng(1).standard_normal(X0.shape))
+    with pytest.raises(capi.DcError, match="exchange timed out"):
+        e.step_backward(1, gx, np.zeros_like(gx), is_start=True)
+    took = time.perf_counter() - t0
+    print(f"\n[time-out path] three failing calls in {took:.2f} s")
+    assert took < 30.0
+    monkeypatch.delenv("DC_TEST_SPIN_MS"); monkeypatch.delenv("DC_TEST_DROP_PART")
+    V, F, e1, o = sphere_scene(48)
+    with cluster_env(1):
+        e1.alloc_batch(B, 1)
+    e1.set_mu(MU)
+    e1.set_state(0, X0, np.zeros_like(X0))
+    st = e1.step_forward(0)
+    assert np.all(st["converged"] == 1)
