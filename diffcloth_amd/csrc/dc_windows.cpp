@@ -92,7 +92,7 @@ Plan plan_for(const HostSystem &H, int own, const std::vector<int> &emin, const 
       if (in(q[0]) || in(q[1]) || in(q[2]) || in(q[3])) { nb++; lo = std::min(lo, emin[id]); hi = std::max(hi, emax[id] + 1); }
     }
     p.vcap = std::max(p.vcap, hi - lo);
-    p.nrcap = std::max(p.nrcap, 2 * nt + nb);
+    p.nrcap = std::max(p.nrcap, 2 * nt + nb + 1);      // + the zero vector the padding entries of the incidence rows point at
   }
   return p;
 }
@@ -122,7 +122,7 @@ bool HostWindows::build(const HostSystem &H, size_t lds_budget) {
     if (nw > 1 && (kmax + nw - 2) / (nw - 1) == k) continue;      // same window size as the previous candidate
     Plan p = plan_for(H, 64 * k, emin, emax);
     const size_t bytes = sizeof(float) * ((size_t) 6 * p.vcap + (size_t) 3 * p.nrcap);
-    if (bytes <= lds_budget && p.vcap <= 65535 && p.nrcap <= 65535) { best = p; best_own = 64 * k; }
+    if (bytes <= lds_budget && p.vcap <= 65535 && p.nrcap <= 32767) { best = p; best_own = 64 * k; }
   }
   if (best_own == 0) return false;
   // the per-vertex phase runs one owned vertex per thread and round: a window of a whole number of 1024-vertex rounds
@@ -150,7 +150,7 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
     emax[T + e] = std::max({q[0], q[1], q[2], q[3]});
   }
   const Plan best = plan_for(H, own_size, emin, emax);
-  if (best.vcap > 65535 || best.nrcap > 65535) return false;
+  if (best.vcap > 65535 || best.nrcap > 32767) return false;      // positions travel as 15 bits + sign
   const int best_own = own_size;
   own = best_own; nwin = best.nwin; vcap = best.vcap; nrcap = best.nrcap;
   lds_bytes = sizeof(float) * ((size_t) 6 * vcap + (size_t) 3 * nrcap);
@@ -191,10 +191,14 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
       for (int c = 1; c < 4; c++) bend_lo.push_back((float) (H.bend_w[4 * e + c] - (double) (float) H.bend_w[4 * e + c]));
       bend_lo.push_back((float) (H.bend_n[e] - (double) (float) H.bend_n[e]));
     }
-    // incidence pairs of the owned vertices, in the corner order of HostSystem::inc_idx
+    // incidence rows of the owned vertices, in the corner order of HostSystem::inc_idx. A triangle's two result vectors are its
+    // contributions to its corners 1 and 2 (the device multiplies the residual columns by inv_deltaUV in the per-element phase), corner 0
+    // gets minus their sum: triangle entries are positions with a sign, 16 bits each; a flap's single vector needs its corner weight.
+    const int zero_slot = 2 * ntri + nbend;
     for (int ch = v0 / 64; ch < (v1 + 63) / 64; ch++) {
+      std::vector<std::vector<int>> codes(64);
       std::vector<std::vector<std::pair<int, float>>> rows(64);
-      int width = 0;
+      int wt = 0, wb = 0;
       for (int l = 0; l < 64; l++) {
         const int v = 64 * ch + l;
         if (v >= v1) break;
@@ -202,29 +206,38 @@ bool HostWindows::build_own(const HostSystem &H, int own_size) {
           const int idx = H.inc_idx[k];
           if (idx < 3 * T) {
             const int corner = idx / T, t = idx % T;
-            const float Dx = (float) H.tri_D[4 * t], Dy = (float) H.tri_D[4 * t + 1], Dz = (float) H.tri_D[4 * t + 2],
-                        Dw = (float) H.tri_D[4 * t + 3];
-            float a, b;
-            if (corner == 1) { a = Dx; b = Dy; }
-            else if (corner == 2) { a = Dz; b = Dw; }
-            else { a = -(Dx + Dz); b = -(Dy + Dw); }
-            rows[l].push_back({tri_local[t], a});               // result planes: first columns [0, ntri), second [ntri, 2 ntri), bending
-            rows[l].push_back({ntri + tri_local[t], b});
+            const int p0 = tri_local[t], p1 = ntri + tri_local[t];
+            if (corner == 1) codes[l].push_back(p0 << 1);
+            else if (corner == 2) codes[l].push_back(p1 << 1);
+            else { codes[l].push_back((p0 << 1) | 1); codes[l].push_back((p1 << 1) | 1); }
           } else {
             const int corner = (idx - 3 * T) / E, e = (idx - 3 * T) % E;
             rows[l].push_back({2 * ntri + bend_local[e], (float) H.bend_w[4 * e + corner]});
           }
         }
-        width = std::max(width, (int) rows[l].size());
+        wt = std::max(wt, (int) codes[l].size());
+        wb = std::max(wb, (int) rows[l].size());
       }
-      const int np = std::max(4, ((width + 1) / 2 + 3) / 4 * 4);
-      inc_ptr[ch] = (int) (inc.size() / 4); inc_n[ch] = np;
-      inc.resize(inc.size() + (size_t) 4 * 64 * np, 0);
-      for (int l = 0; l < 64; l++)
+      const int nt4 = std::max(1, (wt + 7) / 8);             // packets of 8 triangle entries
+      const int nb4 = std::max(2, ((wb + 1) / 2 + 1) / 2 * 2);   // packets of 2 flap pairs, an even number of them
+      inc_ptr[ch] = (int) (inc.size() / 4); inc_n[ch] = nb4 | (nt4 << 16);
+      const size_t base = inc.size();
+      inc.resize(base + (size_t) 4 * 64 * (nt4 + nb4), 0);
+      for (int l = 0; l < 64; l++) {
+        for (int k = 0; k < 8 * nt4; k++) {
+          const int code = k < (int) codes[l].size() ? codes[l][k] : (zero_slot << 1);
+          const size_t o = base + 4 * ((size_t) (k / 8) * 64 + l) + (k % 8) / 2;
+          inc[o] |= (k % 2) ? (code << 16) : code;
+        }
         for (size_t k = 0; k < rows[l].size(); k++) {
-          const size_t o = 4 * ((size_t) inc_ptr[ch] + (size_t) (k / 2) * 64 + l) + 2 * (k % 2);
+          const size_t o = base + 4 * ((size_t) (nt4 + k / 2) * 64 + l) + 2 * (k % 2);
           inc[o] = rows[l][k].first; inc[o + 1] = fbits(rows[l][k].second);
         }
+        for (size_t k = rows[l].size(); k < (size_t) 2 * nb4; k++) {      // padding pairs: the zero vector, weight 0
+          const size_t o = base + 4 * ((size_t) (nt4 + k / 2) * 64 + l) + 2 * (k % 2);
+          inc[o] = zero_slot; inc[o + 1] = 0;
+        }
+      }
     }
   }
   ok = true;

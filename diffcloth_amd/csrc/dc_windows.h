@@ -25,7 +25,7 @@ struct HostWindows {
   int own = 0;                    // owned vertices per window (multiple of 64)
   int nwin = 0;
   int vcap = 0;                   // max vertex span of a window
-  int nrcap = 0;                  // max result vectors of a window (2 * triangles + flaps)
+  int nrcap = 0;                  // max result vectors of a window (2 * triangles + flaps + 1 zero vector)
   size_t lds_bytes = 0;           // 4 * (6 * vcap + 3 * nrcap)
   std::vector<int> win;           // 8 ints per window: v0, v1, lo, vs, tri_off, ntri, bend_off, nbend
   std::vector<int> tri_rec;       // 4 ints per window-triangle: j0 | j1 << 16, j2, bits(area * k_stretch), global triangle id
@@ -36,7 +36,8 @@ struct HostWindows {
   // PreciseBendOp): tri_Dlo = those of inv_deltaUV; bend_lo = those of the cotan weights 1..3 and of the rest norm
   std::vector<float> tri_Dlo, bend_lo;
   // vertex -> (result vector, coefficient) pairs, wave-sliced by 64-vertex chunk: pair-packet (s, lane) at
-  // inc[inc_ptr[c] + 64 s + lane] = {q0, bits(c0), q1, bits(c1)}; inc_n[c] packets per row (a multiple of 4)
+  // chunk c of 64 owned vertices: inc_n[c] = nb4 | nt4 << 16; first nt4 packets of 8 triangle entries (16 bits: position << 1 | minus),
+  // inc[inc_ptr[c] + 64 s + lane], s < nt4; then nb4 packets {q0, bits(w0), q1, bits(w1)} of flap pairs, s - nt4 < nb4
   std::vector<int> inc;
   std::vector<int> inc_ptr, inc_n;
 

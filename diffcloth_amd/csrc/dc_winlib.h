@@ -90,7 +90,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
   const int tid = threadIdx.x, lane = tid & 63;
   const WinLds L = win_lds(S, lds);
   constexpr int MB = kWinMaxBatch;
-  constexpr int VPB = 12;
+  constexpr int VPB = 6;
   constexpr bool PAIR = THREADS < 1024;
   for (int w = w0; w < w1; w++) {
     const int4 d0 = S.win[2 * w], d1 = S.win[2 * w + 1];
@@ -127,6 +127,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
       stw(L.a1xy, L.a1z, j0, sa);
       if (vb) { stw(L.a2xy, L.a2z, jb, ub); stw(L.a1xy, L.a1z, jb, sb); }
     }
+    if (tid == 0) stw(L.erxy, L.erz, 2 * nt + nb, mk(0, 0, 0));      // the zero vector the padding entries of the per-vertex rows point at
     __syncthreads();
     WPH(0)
     // per-element phase: up to 4 elements of a thread at a time, their records loaded up front (clamped index, no
@@ -147,7 +148,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         else
           tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
                  ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), R.D[j], __int_as_float(R.r[j].z), r0, r1);
-        if (t < nt) { stw(L.erxy, L.erz, t, r0); stw(L.erxy, L.erz, nt + t, r1); }
+        // the triangle's contributions to its corners 1 and 2 (Triangle.cpp: A^T applied to the residual columns; corner 0 = -(c1 + c2))
+        if (t < nt) { stw(L.erxy, L.erz, t, r0 * R.D[j].x + r1 * R.D[j].y); stw(L.erxy, L.erz, nt + t, r0 * R.D[j].z + r1 * R.D[j].w); }
       }
     };
     auto bend_compute = [&](auto ebc, const WinBendRecs<MB, PRECISE> &R, int e0) {
@@ -179,10 +181,23 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     }
     __syncthreads();
     WPH(2)
-    // per-vertex phase. All packets of a vertex travel in one batch of loads (12 = a valence-6 vertex: 6 triangles x 2
-    // + 12 flaps = 24 pairs); clamped index + masked coefficient instead of divergence, wider rows take another round.
-    // With fewer threads than owned vertices (512-thread kernels) a thread handles two vertices at once so that the
-    // table loads of both rounds overlap.
+    // per-vertex phase. A triangle's two result vectors are its contributions to its corners 1 and 2 (corner 0: minus their sum), so a
+    // triangle entry of a vertex is a position with a sign (16 bits, 8 per packet); a flap entry is a position with the corner's weight
+    // (2 per packet). All packets of a vertex travel in one batch of loads (1 + 6 = a valence-6 vertex: 8 triangle entries + 12
+    // flaps); clamped index + masked coefficient instead of divergence, wider rows take another round. With fewer threads than owned
+    // vertices (512-thread kernels) a thread handles two vertices at once so that the table loads of both rounds overlap.
+    auto gather_tri = [&](const int4 &w, bool live, float &sx, float &sy, float &sz) {
+      const int wd[4] = {w.x, w.y, w.z, w.w};
+      const int one = live ? 0x3f800000 : 0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int code = (e & 1) ? (int) ((unsigned) wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffff);
+        const float c = __int_as_float(one | ((code & 1) << 31));      // +1 / -1 (0 for a masked packet)
+        const float2 q = L.erxy[code >> 1];
+        const float z = L.erz[code >> 1];
+        sx = fmaf(c, q.x, sx); sy = fmaf(c, q.y, sy); sz = fmaf(c, z, sz);
+      }
+    };
     auto gather = [&](const int4 (&e)[VPB], int s0, int np, float &sx, float &sy, float &sz) {
 #pragma unroll
       for (int j = 0; j < VPB; j++) {
@@ -196,24 +211,46 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     };
     for (int i = v0 + tid; i < v1; i += (PAIR ? 2 : 1) * THREADS) {
       const int cha = __builtin_amdgcn_readfirstlane(i >> 6);     // v0 and THREADS are multiples of 64
-      const int npa = S.winc_n[cha];
+      const int na = S.winc_n[cha], nta = na >> 16, nba = na & 0xffff;
       const int4 DC_G *rowa = S.winc + S.winc_ptr[cha] + lane;
+      const int4 DC_G *frowa = rowa + nta * 64;
       float ax = 0.f, ay = 0.f, az = 0.f;
       if constexpr (PAIR) {
         const int ib = i + THREADS;
         const bool vb = ib < v1;
         const int chb = __builtin_amdgcn_readfirstlane((vb ? ib : i) >> 6);
-        const int npb = S.winc_n[chb];
+        const int nb_ = S.winc_n[chb], ntb = nb_ >> 16, nbb = nb_ & 0xffff;
         const int4 DC_G *rowb = S.winc + S.winc_ptr[chb] + lane;
+        const int4 DC_G *frowb = rowb + ntb * 64;
         float bx = 0.f, by = 0.f, bz = 0.f;
         auto prea = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(i); else return 0; }();
         auto preb = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(vb ? ib : i); else return 0; }();
-        for (int s0 = 0; s0 < max(npa, npb); s0 += VPB) {
+        {   // first batch: the triangle packet and the first flap packets of both vertices in flight together
+          const int4 ta = rowa[0], tb = rowb[0];
+          const int4 ta1 = rowa[min(1, nta - 1) * 64], tb1 = rowb[min(1, ntb - 1) * 64];      // (irregular meshes: up to 16 entries in the first batch)
           int4 ea[VPB], eb[VPB];
 #pragma unroll
-          for (int j = 0; j < VPB; j++) { ea[j] = rowa[min(s0 + j, npa - 1) * 64]; eb[j] = rowb[min(s0 + j, npb - 1) * 64]; }
-          gather(ea, s0, npa, ax, ay, az);
-          gather(eb, s0, npb, bx, by, bz);
+          for (int j = 0; j < VPB; j++) { ea[j] = frowa[min(j, nba - 1) * 64]; eb[j] = frowb[min(j, nbb - 1) * 64]; }
+          gather_tri(ta, true, ax, ay, az);
+          gather_tri(tb, true, bx, by, bz);
+          if (max(nta, ntb) > 1) {      // wave-uniform
+            gather_tri(ta1, nta > 1, ax, ay, az);
+            gather_tri(tb1, ntb > 1, bx, by, bz);
+          }
+          gather(ea, 0, nba, ax, ay, az);
+          gather(eb, 0, nbb, bx, by, bz);
+        }
+        for (int s0 = 2; s0 < max(nta, ntb); s0++) {      // vertices of more than 16 triangle entries
+          const int4 ta = rowa[min(s0, nta - 1) * 64], tb = rowb[min(s0, ntb - 1) * 64];
+          gather_tri(ta, s0 < nta, ax, ay, az);
+          gather_tri(tb, s0 < ntb, bx, by, bz);
+        }
+        for (int s0 = VPB; s0 < max(nba, nbb); s0 += VPB) {
+          int4 ea[VPB], eb[VPB];
+#pragma unroll
+          for (int j = 0; j < VPB; j++) { ea[j] = frowa[min(s0 + j, nba - 1) * 64]; eb[j] = frowb[min(s0 + j, nbb - 1) * 64]; }
+          gather(ea, s0, nba, ax, ay, az);
+          gather(eb, s0, nbb, bx, by, bz);
         }
         if constexpr (vert_has_pre<VertOp>::value) {
           vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo), prea);
@@ -224,11 +261,21 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         }
       } else {
         auto prea = [&]() { if constexpr (vert_has_pre<VertOp>::value) return vert_op.pre(i); else return 0; }();
-        for (int s0 = 0; s0 < npa; s0 += VPB) {
+        {
+          const int4 ta = rowa[0], ta1 = rowa[min(1, nta - 1) * 64];
           int4 ea[VPB];
 #pragma unroll
-          for (int j = 0; j < VPB; j++) ea[j] = rowa[min(s0 + j, npa - 1) * 64];
-          gather(ea, s0, npa, ax, ay, az);
+          for (int j = 0; j < VPB; j++) ea[j] = frowa[min(j, nba - 1) * 64];
+          gather_tri(ta, true, ax, ay, az);
+          if (nta > 1) gather_tri(ta1, true, ax, ay, az);
+          gather(ea, 0, nba, ax, ay, az);
+        }
+        for (int s0 = 2; s0 < nta; s0++) gather_tri(rowa[s0 * 64], true, ax, ay, az);
+        for (int s0 = VPB; s0 < nba; s0 += VPB) {
+          int4 ea[VPB];
+#pragma unroll
+          for (int j = 0; j < VPB; j++) ea[j] = frowa[min(s0 + j, nba - 1) * 64];
+          gather(ea, s0, nba, ax, ay, az);
         }
         if constexpr (vert_has_pre<VertOp>::value) vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo), prea);
         else vert_op(i, mk(ax, ay, az), ldw(L.a1xy, L.a1z, i - lo));

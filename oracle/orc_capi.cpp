@@ -245,5 +245,5 @@ extern "C" void orc_override_record(void *s, int id, const double *x, const doub
 
 // Diagnostic: let the local projections see the deformation gradient (the weighted bending vector) rounded to fp32, as an fp32
 // evaluation of F = [x1 - x0, x2 - x0] inv_deltaUV delivers it — measures what that rounding alone does to a step and its gradient.
-namespace orc { extern bool g_emulate_fp32_F, g_emulate_fp32_v; }
-extern "C" void orc_emulate_fp32_F(int on) { orc::g_emulate_fp32_F = (on & 1) != 0; orc::g_emulate_fp32_v = (on & 2) != 0; }
+namespace orc { extern bool g_emulate_fp32_F, g_emulate_fp32_v, g_cap_keeps_last; }
+extern "C" void orc_emulate_fp32_F(int on) { orc::g_emulate_fp32_F = (on & 1) != 0; orc::g_emulate_fp32_v = (on & 2) != 0; orc::g_cap_keeps_last = (on & 4) != 0; }

@@ -263,6 +263,8 @@ void Sim::mulS(const std::vector<double> &val, const std::vector<double> &x, std
 // Local projections
 // ------------------------------------------------------------------------------------------------
 bool g_emulate_fp32_v = false;   // diagnostic switch: round the velocity iterate to fp32 after every global solve
+bool g_cap_keeps_last = false;   // diagnostic switch (bit 2 of orc_emulate_fp32_F): a PD loop that hits pd_iter_cap returns its LAST iterate instead of
+                                 // reverting to the best one — "the reference's loop stopped after exactly k iterations" (tests/test_gpu_configs.py)
 bool g_emulate_fp32_F = false;   // diagnostic switch (orc_emulate_fp32_F): round the deformation gradient / bending vector to fp32
 
 // Triangle::project -> projectToManifold (Triangle.cpp:310-351): F = [x1-x0, x2-x0] inv_deltaUV; Gram-Schmidt
@@ -837,7 +839,7 @@ int Sim::step(const double *x_n_in, const double *v_n_in, const double *x_fixed_
     if (converged) { rec.converged = true; rec.convergeIter = iter + 1; break; }
     if (iter == PD_TOTAL_ITER - 1) {
       rec.converged = false; rec.convergeIter = PD_TOTAL_ITER;
-      x_new = x_best; v_new = v_best;   // revertToLastConverging
+      if (!g_cap_keeps_last) { x_new = x_best; v_new = v_best; }   // revertToLastConverging
     }
   }
   rec.x = x_new; rec.v = v_new; rec.f = f; rec.r = r;

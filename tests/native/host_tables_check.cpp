@@ -113,15 +113,18 @@ static void check_windows(const HostSystem &H, size_t budget, int expect_min_win
   for (int w = 0; w < W.nwin; w++) {
     const int *d = &W.win[8 * w];
     const int v0 = d[0], v1 = d[1], lo = d[2], vs = d[3], toff = d[4], nt = d[5], boff = d[6], nb = d[7];
-    if (v0 % 64 != 0 || vs > W.vcap || 2 * nt + nb > W.nrcap || lo > v0 || lo + vs < v1) fail("windows: descriptor");
-    std::vector<double> er(2 * nt + nb);
+    if (v0 % 64 != 0 || vs > W.vcap || 2 * nt + nb + 1 > W.nrcap || lo > v0 || lo + vs < v1) fail("windows: descriptor");
+    std::vector<double> er(2 * nt + nb + 1, 0.0);      // + the zero vector of the padding entries
     for (int k = 0; k < nt; k++) {
       const int *r = &W.tri_rec[4 * (size_t) (toff + k)];
       const int t = r[3], j[3] = {r[0] & 0xffff, (int) ((unsigned) r[0] >> 16), r[1]};
       for (int q = 0; q < 3; q++) if (lo + j[q] != H.tri[3 * t + q]) fail("windows: triangle record vertices");
       if (asfloat(r[2]) != (float) H.tri_w2[t]) fail("windows: triangle weight");
       for (int q = 0; q < 4; q++) if (W.tri_D[4 * (size_t) (toff + k) + q] != (float) H.tri_D[4 * t + q]) fail("windows: triangle D");
-      er[k] = r0[t]; er[nt + k] = r1[t];          // two result planes: first columns [0, nt), second [nt, 2 nt)
+      {   // two result planes: the triangle's contributions to its corners 1 and 2 (what the device stores)
+        const float Dx = (float) H.tri_D[4 * t], Dy = (float) H.tri_D[4 * t + 1], Dz = (float) H.tri_D[4 * t + 2], Dw = (float) H.tri_D[4 * t + 3];
+        er[k] = r0[t] * Dx + r1[t] * Dy; er[nt + k] = r0[t] * Dz + r1[t] * Dw;
+      }
     }
     // flaps are identified by their vertices
     std::map<std::vector<int>, int> flap;
@@ -138,12 +141,23 @@ static void check_windows(const HostSystem &H, size_t budget, int expect_min_win
       owner[v]++;
       const int ch = v / 64, l = v % 64;
       double s = 0;
-      for (int pk = 0; pk < W.inc_n[ch]; pk++) {
+      const int nt4 = W.inc_n[ch] >> 16, nb4 = W.inc_n[ch] & 0xffff;
+      if (nt4 < 1 || nb4 < 1) fail("windows: packet counts of a chunk");
+      for (int pk = 0; pk < nt4; pk++) {          // triangle entries: position << 1 | minus, 16 bits each
         const int *q = &W.inc[4 * ((size_t) W.inc_ptr[ch] + (size_t) pk * 64 + l)];
+        for (int e8 = 0; e8 < 8; e8++) {
+          const int code = (e8 & 1) ? (int) ((unsigned) q[e8 >> 1] >> 16) : (q[e8 >> 1] & 0xffff);
+          const int pos = code >> 1;
+          if (pos < 0 || pos > 2 * nt + nb) fail("windows: triangle entry outside the window's result vectors");
+          if (pos >= 2 * nt && pos != 2 * nt + nb) fail("windows: triangle entry points at a flap vector");
+          s += (code & 1) ? -er[pos] : er[pos];
+        }
+      }
+      for (int pk = 0; pk < nb4; pk++) {          // flap pairs
+        const int *q = &W.inc[4 * ((size_t) W.inc_ptr[ch] + (size_t) (nt4 + pk) * 64 + l)];
         for (int h = 0; h < 2; h++) {
           const float coef = asfloat(q[2 * h + 1]);
-          if (coef == 0.f) continue;
-          if (q[2 * h] < 0 || q[2 * h] >= 2 * nt + nb) fail("windows: incidence index outside the window's result vectors");
+          if (q[2 * h] < 2 * nt || q[2 * h] > 2 * nt + nb) fail("windows: flap entry outside the window's flap vectors");
           s += coef * er[q[2 * h]];
         }
       }

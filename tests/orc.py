@@ -220,6 +220,11 @@ class Oracle:
         ff = None if f is None else f64(f).reshape(-1)
         self.L.orc_override_record(self.h, C.c_int(rid), None if xx is None else _d(xx), None if ff is None else _d(ff))
 
+    def diagnostics(self, bits):
+        """process-wide diagnostic switches of the oracle library (orc_emulate_fp32_F): 1 = deformation gradient rounded to fp32, 2 = velocity
+        iterate rounded to fp32, 4 = a PD loop that hits pd_iter_cap keeps its last iterate (the loop stopped after exactly `cap` iterations)"""
+        self.L.orc_emulate_fp32_F(C.c_int(int(bits)))
+
     def adjoint_matrix(self, rid):
         """K = P - dP^T of the direct adjoint solve of record `rid` (3N x 3N, xyz-interleaved) as a scipy CSC matrix — diagnostic
         for the solver prototypes (tests/proto_adjoint.py)."""

@@ -61,7 +61,9 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
     another direction, so its effect on the gradient is of the same size, not the same number. Measured: pressed-on hat,
     sensitivities 1.6e-4 ... 5e-2 on all six sampled rollouts, GPU-vs-oracle differences 4e-6 ... 8e-3, each BELOW its rollout's
     sensitivity; dress, rollout 255 of 256: sensitivity 5.7e-5 (five times its neighbours'), difference 1.2e-4. The rollouts whose
-    sensitivity exceeds grad_tol are returned in st["ill_conditioned"]."""
+    sensitivity exceeds grad_tol are returned in st["ill_conditioned"]. Where the two PD loops stopped one iteration apart (hat, first
+    touch: ~1000 iterations at a contraction of 0.995, the stopping test within rounding of its threshold), the gradient is compared with
+    the oracle's loop stopped after the HIP path's number of iterations."""
     B = len(X0)
     e.alloc_batch(B, 1)
     if mus is not None:
@@ -75,6 +77,7 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
     assert np.all(st["converged"] == 1) and np.all(gb["converged"] == 1)
     worst = dict(dx=0.0, gx=0.0, gv=0.0, gf=0.0)
     ill = []
+    cond_worst = 0.0
     if os.environ.get("DC_DUMP_DIR"):          # the HIP path's tape of the sampled rollouts, for tests/analyze_dump.py
         fr = e.get_record(1)
         os.makedirs(os.environ["DC_DUMP_DIR"], exist_ok=True)
@@ -93,6 +96,25 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
         worst["dx"] = max(worst["dx"], np.abs(x1[b] - ref["x"]).max())
         egx, egv = rel(gb["dL_dx"][b], rb["dL_dx"]), rel(gb["dL_dv"][b], rb["dL_dv"])
         egf = rel(gb["dL_dxfixed"][b], rb["dL_dxfixed"]) if XF is not None else 0.0
+        if conditioning and st["pd_iters"][b] != ref["iters"]:
+            # the PD loop's stopping test (mean |dx| < fwd_tol) came out differently by one iteration — on the hat the map contracts at 0.995
+            # per iteration and the two sides sit within rounding of the threshold for several iterations. The statement that can be
+            # tested: the HIP path's gradient is that of the reference's loop stopped where the HIP path's stopped.
+            o.set(cap=int(st["pd_iters"][b])); o.build(); o.diagnostics(4)      # (4: the capped loop keeps its last iterate)
+            if mus is not None:
+                for g in range(mus.shape[1]):
+                    o.set_mu(g, float(mus[b, g]))
+            ref_same = o.step(X0[b], V0[b], None if XF is None else XF[b])
+            rb_same = o.step_backward(ref_same["id"], gx[b], gv[b], is_start=False, direct=True)
+            o.set(cap=-1); o.build(); o.diagnostics(0)
+            if mus is not None:
+                for g in range(mus.shape[1]):
+                    o.set_mu(g, float(mus[b, g]))
+            print(f"\n[config] rollout {b}: PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}: against the converged oracle dx {egx:.2e} dv {egv:.2e}; "
+                  f"against the oracle stopped after {st['pd_iters'][b]} iterations dx {rel(gb['dL_dx'][b], rb_same['dL_dx']):.2e} dv {rel(gb['dL_dv'][b], rb_same['dL_dv']):.2e}")
+            assert abs(int(st["pd_iters"][b]) - int(ref["iters"])) <= 2
+            egx, egv = rel(gb["dL_dx"][b], rb_same["dL_dx"]), rel(gb["dL_dv"][b], rb_same["dL_dv"])
+            egf = rel(gb["dL_dxfixed"][b], rb_same["dL_dxfixed"]) if XF is not None else 0.0
         if conditioning:
             o.override_record(ref["id"], x=f32(ref["x"]))
             rb2 = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
@@ -106,11 +128,13 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
               f"gradient rel err dx {egx:.2e} dv {egv:.2e} dxfixed {egf:.2e}")
         if conditioning:
             assert max(egx, egv, egf) <= gate_b, (b, egx, egv, egf, gate_b)
+            cond_worst = max(cond_worst, egx, egv, egf)
             continue                                # gated per rollout; the plain gate below is for the other tests
         worst["gx"] = max(worst["gx"], egx); worst["gv"] = max(worst["gv"], egv); worst["gf"] = max(worst["gf"], egf)
     print(f"\n[config] B={B} sampled {list(sample)} pd iters {st['pd_iters'].min()}..{st['pd_iters'].max()} contacts prim "
           f"{st['prim_contacts'].min()}..{st['prim_contacts'].max()} self {st['self_contacts'].max()} | worst max|dx| {worst['dx']:.2e} "
-          f"grad rel err dx {worst['gx']:.2e} dv {worst['gv']:.2e} dxfixed {worst['gf']:.2e}")
+          f"grad rel err dx {worst['gx']:.2e} dv {worst['gv']:.2e} dxfixed {worst['gf']:.2e}"
+          + (f" | gated per rollout (conditioning rule): worst {cond_worst:.2e}" if conditioning else ""))
     assert worst["dx"] <= pos_tol
     assert worst["gx"] <= grad_tol and worst["gv"] <= grad_tol and worst["gf"] <= grad_tol
     st["ill_conditioned"] = ill
