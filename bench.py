@@ -304,7 +304,8 @@ def main():
     # and the resource its inner loop loads is the LDS array. LDS-array cycles per CU (MI355X_MICROARCH.md LDS table: ds_read_b32 / b64
     # 2 cycles per wave-instruction, ds_write_b32 / b64 2 / 4):
     #   per CG iteration   rows/64 * (12 neighbours * (2 + 2) + 14 for reading / rewriting p and the LDS part of x)
-    #   per PD iteration   staging 12 * 1.15 N/64 + triangles (6 * 4 + 12) * T/64 + flaps (8 * 4 + 6) * E/64 + vertex gather 24 * 4 * N/64
+    #   per PD iteration   staging 12 * 1.15 N/64 + triangles (6 * 4 + 12) * T/64 + flaps (8 * 4 + 6) * E/64 + vertex gather 20 * 4 * N/64
+    #                      (a valence-6 vertex reads 8 signed triangle entries + 12 flap entries since round 3)
     # The streaming model of SURVEY.md section 8d ((108 I_pd + 132 I_cg) N: every CG vector through HBM) is kept as a number for reference;
     # it is what the resident design AVOIDS, not a roof for it.
     # Adjoint kernel: its Krylov vectors do stream through HBM — 72 N per step + 388 N per BiCGSTAB iteration (2 operator applications
@@ -312,12 +313,12 @@ def main():
     rows64 = (N + 63) // 64
     bytes_fwd = (108.0 * pd + 64.0 * B * K) * N
     bytes_fwd_stream = (108.0 * pd + 132.0 * cg_f) * N
-    lds_cycles_fwd = (cg_f * rows64 * (12 * 4 + 14) + pd * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 96.0 * rows64)) / max(B * cl, 1)
+    lds_cycles_fwd = (cg_f * rows64 * (12 * 4 + 14) + pd * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 80.0 * rows64)) / max(B * cl, 1)
     if args.adjoint_mode == 1:
         bytes_bwd = (72.0 * B * K + 388.0 * adj + 96.0 * cyc + 100.0 * B * K) * N
     else:
         bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b + 100.0 * B * K) * N
-    lds_cycles_bwd = (2.0 * adj + cyc) * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 96.0 * rows64) / max(B * cl, 1)
+    lds_cycles_bwd = (2.0 * adj + cyc) * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 80.0 * rows64) / max(B * cl, 1)
     try:
         clock_hz = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
     except Exception:
