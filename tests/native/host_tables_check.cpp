@@ -171,6 +171,34 @@ static void check_windows(const HostSystem &H, size_t budget, int expect_min_win
   std::printf("ok windows N=%d nwin=%d own=%d vcap=%d nrcap=%d lds=%zu\n", N, W.nwin, W.own, W.vcap, W.nrcap, W.lds_bytes);
 }
 
+// On a regular mesh the first-use element order makes slot j of consecutive owned vertices consecutive LDS positions (the per-vertex
+// phase then reads its result vectors without bank conflicts): fraction of neighbouring-lane pairs whose slot positions differ by 1.
+static double regular_slot_fraction(const HostWindows &W) {
+  long good = 0, all = 0;
+  for (int w = 0; w < W.nwin; w++) {
+    const int *d = &W.win[8 * w];
+    const int v0 = d[0], v1 = d[1], nt = d[5], nb = d[7];
+    for (int v = v0; v + 1 < v1; v++) {
+      if (v / 64 != (v + 1) / 64) continue;
+      const int ch = v / 64, l = v % 64, nt4 = W.inc_n[ch] >> 16, nb4 = W.inc_n[ch] & 0xffff;
+      for (int pk = 0; pk < nt4; pk++)
+        for (int e8 = 0; e8 < 8; e8++) {
+          auto code = [&](int lane) { const int *q = &W.inc[4 * ((size_t) W.inc_ptr[ch] + (size_t) pk * 64 + lane)]; return (e8 & 1) ? (int) ((unsigned) q[e8 >> 1] >> 16) : (q[e8 >> 1] & 0xffff); };
+          const int a = code(l) >> 1, b = code(l + 1) >> 1;
+          if (a == 2 * nt + nb || b == 2 * nt + nb) continue;
+          all++; good += (b - a == 1);
+        }
+      for (int pk = 0; pk < nb4; pk++)
+        for (int h = 0; h < 2; h++) {
+          const int a = W.inc[4 * ((size_t) W.inc_ptr[ch] + (size_t) (nt4 + pk) * 64 + l) + 2 * h], b = W.inc[4 * ((size_t) W.inc_ptr[ch] + (size_t) (nt4 + pk) * 64 + l + 1) + 2 * h];
+          if (a == 2 * nt + nb || b == 2 * nt + nb) continue;
+          all++; good += (b - a == 1);
+        }
+    }
+  }
+  return all ? (double) good / (double) all : 0.0;
+}
+
 int main() {
   std::vector<double> pos;
   std::vector<int> tri;
@@ -182,6 +210,13 @@ int main() {
   check_packets(H);
   check_windows(H, 150 * 1024, 1);
   check_windows(H, 40 * 1024, 3);
+  {
+    HostWindows W;
+    if (!W.build(H, 150 * 1024)) fail("windows: build");
+    const double frac = regular_slot_fraction(W);
+    std::printf("first-use order on the 60 x 40 grid: %.2f of the neighbouring-lane slot pairs read consecutive positions\n", frac);
+    if (frac < 0.7) fail("windows: the first-use element order does not line the slots of consecutive vertices up");
+  }
   // 2. the same grid with shuffled numbering: bandwidth ~N; RCM brings it back under the packet limit
   grid(60, 40, true, pos, tri);
   const int bw0 = mesh_bandwidth((int) tri.size() / 3, tri.data());
