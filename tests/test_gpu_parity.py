@@ -357,3 +357,51 @@ def test_capped_runs_return_the_best_iterate_like_the_reference():
         worst = max(worst, np.abs(x1[0] - ref["x"]).max())
     print(f"\n[best iterate] caps 2..16, 24, 32, 40: worst max|dx| {worst:.3e}")
     assert worst <= POS_TOL
+
+
+@pytest.mark.parametrize("case", ["one-flap", "grid-6x5-with-clips"])
+def test_local_step_known_answers(case):
+    """Stand-alone check of the per-constraint projections (Triangle::project Triangle.cpp:310-351, TriangleBending::project
+    TriangleBending.cpp:138-151, AttachmentSpring::project AttachmentSpring.cpp:25-29) and of their assembly into the vertex forces: a step
+    capped at ONE PD iteration records f = M (s_n - x_n) / h + h sum_c w_c A_c^T (p_c - A_c x) evaluated at the prescribed state, no solver in
+    between. Strongly deformed random states (edges stretched / compressed by up to 30 %, flaps folded), 32 of them per case as one batch;
+    every component of f against the fp64 oracle's to 5e-6 of the largest force (measured: 4.6e-7 on the flap, 2.4e-6 on the grid, where the
+    stiff clips' fp32 attachment term dominates the largest force)."""
+    rng = np.random.default_rng(11)
+    if case == "one-flap":
+        V = f32(np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 1.0]]) * 0.37)
+        F = np.array([[0, 1, 2], [2, 1, 3]], dtype=np.int32)
+        att = []
+    else:
+        V, F = meshes.grid_cloth(6, 5, 1.5, 1.2, "DOWN")
+        V = f32(V)
+        att = [0, 5]
+    kw = dict(h=1 / 90, density=0.3, k_stretch=500.0, k_bend=0.8)
+    o = orc.Oracle(V, F, fwd_tol=1e-30, bwd_tol=1e-9, attachments=att, contact=False, selfcollision=False, gradient_clipping=False, pd_iter_cap=1, **kw)
+    o.build()
+    e = capi.Engine(0)
+    e.set_mesh(V, F)
+    e.set_attachments(att)
+    e.set_params(time_step=kw["h"], density=kw["density"], k_stretch=kw["k_stretch"], k_bend=kw["k_bend"], forward_tol=1e-30, pd_iter_cap=1,
+                 cg_rel_tol=1e-7, cg_max_iter=500, selfcollision_enabled=0)
+    e.set_primitives([])
+    e.build()
+    B = 32
+    scale = np.abs(V).max()
+    X0 = np.stack([f32((V * (1.0 + 0.3 * rng.uniform(-1, 1, (1, 3))) + 0.08 * scale * rng.standard_normal(V.shape)).reshape(-1)) for _ in range(B)])
+    V0 = np.stack([f32(2.0 * rng.standard_normal(V.size)) for _ in range(B)])
+    XF = np.stack([f32(V[att].reshape(-1) + 0.05 * rng.standard_normal(3 * len(att))) for _ in range(B)]) if att else None
+    e.alloc_batch(B, 1)
+    e.set_state(0, X0, V0)
+    st = e.step_forward(0, fixed_pts=XF)
+    assert np.all(st["pd_iters"] == 1)
+    f_gpu, r_gpu = e.get_record(1)
+    worst = 0.0
+    for b in range(B):
+        ref = o.step(X0[b], V0[b], None if XF is None else XF[b])
+        assert ref["iters"] == 1
+        f_ref, r_ref = o.record_fr(ref["id"])
+        worst = max(worst, np.abs(f_gpu[b] - f_ref).max() / np.abs(f_ref).max())
+        assert np.abs(r_gpu[b]).max() == 0.0 and np.abs(r_ref).max() == 0.0
+    print(f"\n[local step KAT, {case}] worst |f_gpu - f_oracle| / max|f| over {B} states: {worst:.2e}")
+    assert worst <= 5e-6
