@@ -42,7 +42,14 @@ class dc_step_stats(C.Structure):
 
 class dc_bwd_stats(C.Structure):
     _fields_ = [("converged", C.c_int), ("adjoint_iters", C.c_int), ("cg_iters", C.c_int), ("clipped", C.c_int), ("used_direct", C.c_int),
-                ("last_udiff", C.c_float), ("refine_cycles", C.c_int), ("fp64_iters", C.c_int)]
+                ("last_udiff", C.c_float), ("refine_cycles", C.c_int), ("fp64_iters", C.c_int), ("residual_verified", C.c_int)]
+
+
+class dc_record(C.Structure):
+    _fields_ = [("x", C.POINTER(C.c_double)), ("v", C.POINTER(C.c_double)), ("f", C.POINTER(C.c_double)), ("r", C.POINTER(C.c_double)),
+                ("prim", C.POINTER(C.c_int)), ("normal", C.POINTER(C.c_double)), ("x_fixed", C.POINTER(C.c_double)),
+                ("self_count", C.POINTER(C.c_int)), ("self_pairs", C.POINTER(C.c_int)), ("self_layer", C.POINTER(C.c_int)),
+                ("self_normal", C.POINTER(C.c_double)), ("self_d", C.POINTER(C.c_double))]
 
 
 EXPORTED_SYMBOLS = [
@@ -53,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
     "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout", "dc_comm_unique_id", "dc_comm_init", "dc_allreduce_sum", "dc_comm_destroy",
-    "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
+    "dc_set_record", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
 ]
 
 _lib = None
@@ -105,6 +112,7 @@ class Engine:
         if rc != 0:
             raise DcError(f"dc_create failed with code {rc}: no HIP device available (there is no CPU fallback)")
         self.h = h
+        self.device = device
         self.params = dc_params()
         self.lib.dc_default_params(C.byref(self.params))
         self.N = self.T = self.E = self.Af = 0
@@ -237,6 +245,36 @@ class Engine:
         self._chk(self.lib.dc_get_record(self.h, C.c_int(slot), _d(f), _d(r)))
         return f, r
 
+    def set_record(self, slot, x, v, f, prim, normal, r=None, x_fixed=None, self_contacts=None):
+        """dc_set_record: the forward record of `slot` handed in from outside (fp64 values kept for the adjoint's fp64 operator).
+        prim: [B][N] index into the primitive list or -1; self_contacts: per rollout a dict(pairs [C][2], layer [C], normal [C][3], d [C][3])
+        in layer order, or None."""
+        rec = dc_record()
+        keep = []
+
+        def dptr(a, per):
+            if a is None:
+                return None
+            a = self._vec(a, per); keep.append(a)
+            return _d(a)
+        n3 = 3 * self.N
+        rec.x = dptr(x, n3); rec.v = dptr(v, n3); rec.f = dptr(f, n3); rec.r = dptr(r, n3); rec.normal = dptr(normal, n3)
+        rec.x_fixed = dptr(x_fixed, 3 * self.Af)
+        pr = _i32(prim).reshape(-1)
+        if pr.size != self.B * self.N:
+            raise ValueError("prim: expected B x N entries")
+        keep.append(pr); rec.prim = _i(pr)
+        if self_contacts is not None:
+            cnt = _i32([0 if sc is None else len(sc["layer"]) for sc in self_contacts])
+            live = [sc for sc in self_contacts if sc is not None and len(sc["layer"])]
+            pairs = _i32(np.concatenate([np.asarray(sc["pairs"]).reshape(-1, 2) for sc in live]) if live else np.zeros((0, 2)))
+            layer = _i32(np.concatenate([np.asarray(sc["layer"]).reshape(-1) for sc in live]) if live else np.zeros(0))
+            nrm = _f64(np.concatenate([np.asarray(sc["normal"]).reshape(-1, 3) for sc in live]) if live else np.zeros((0, 3)))
+            dd = _f64(np.concatenate([np.asarray(sc["d"]).reshape(-1, 3) for sc in live]) if live else np.zeros((0, 3)))
+            keep += [cnt, pairs, layer, nrm, dd]
+            rec.self_count = _i(cnt); rec.self_pairs = _i(pairs); rec.self_layer = _i(layer); rec.self_normal = _d(nrm); rec.self_d = _d(dd)
+        self._chk(self.lib.dc_set_record(self.h, C.c_int(slot), C.byref(rec)))
+
     def get_contacts(self, slot):
         g = np.zeros((self.B, self.N), dtype=np.int32); n = np.zeros((self.B, 3 * self.N))
         self._chk(self.lib.dc_get_contacts(self.h, C.c_int(slot), _i(g), _d(n)))
@@ -261,16 +299,18 @@ class Engine:
         self._chk(self.lib.dc_step_backward(self.h, C.c_int(slot), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
                                             _d(dx), _d(dv), _d(dxf), _d(dmu), st))
         out = dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:, :3 * self.Af], dL_dmu=dmu)
-        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters"]))
+        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters", "residual_verified"]))
         return out
 
     # ---- device-pointer boundary (torch tensors on this GPU: no host copies, no synchronisation) ----
-    @staticmethod
-    def _tp(t, per):
-        """(device pointer, is_f32) of a contiguous CUDA tensor of B * per elements, fp32 or fp64"""
+    def _tp(self, t, per):
+        """(device pointer, is_f32) of a contiguous CUDA tensor of B * per elements, fp32 or fp64, on the engine's GPU"""
+        dev = getattr(self, "device", None)
         import torch
         if t is None:
             return None, 1
+        if t.is_cuda and dev is not None and t.device.index != dev:
+            raise ValueError(f"tensor on cuda:{t.device.index}, the engine runs on device {dev}")
         if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.float64) or t.numel() != per:
             raise ValueError(f"expected a contiguous CUDA float32 / float64 tensor of {per} elements, got {t.dtype} {tuple(t.shape)} on {t.device}")
         return C.c_void_p(t.data_ptr()), int(t.dtype == torch.float32)
@@ -369,7 +409,7 @@ class Engine:
         f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()
         self._chk(self.lib.dc_get_stats(self.h, C.c_int(slot), f, b))
         return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff", "self_overflow"]),
-                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters"]))
+                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters", "residual_verified"]))
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))

@@ -11,8 +11,7 @@
 // Everything is written once over a Team: TeamOne (one workgroup owns the rollout, dc_adjoint.hip) or TeamParts (K workgroups,
 // part p owns rows [r0, r1), dc_adjoint_cl.hip); a Team supplies the row range, barriers, sums and the access path to the one
 // vector that crosses parts (y = (I + dr_df)^T z).
-// The element pass is vertex-centred: a vertex re-evaluates its incident elements (no corner array: ~3.5 x the arithmetic, none
-// of the 72 B per element of fp64 corner traffic, and a part writes nothing but its own rows).
+// The element pass is element-centred with an fp64 corner array (W.corner; see element_pass64).
 #pragma once
 #include "dc_devlib.h"
 #include "dc_adjprecond.h"
@@ -58,7 +57,16 @@ struct Adj64 {
   int nself, b;
   float *lds;                               // LDS scratch of the layered self-contact pass
   int lds_floats;
+  // record handed in from outside (dc_set_record), this rollout's share: x_new, f, primitive-contact normals as planar [3][N] doubles, the
+  // self contacts' normals / d as [cap][3] doubles in the order of the contact list; null for a record the forward kernels made. The fp64
+  // operator then works on these values (cases decided in fp64, as the reference does) instead of on the fp32 tape.
+  const double *inj_x, *inj_f, *inj_n, *inj_sn, *inj_sd;
 };
+__device__ __forceinline__ void adj64_inject(Adj64 &C, const BwdArgs &A, int b, int N, int cap) {
+  const size_t off = (size_t) b * 3 * N, so = (size_t) b * 3 * cap;
+  C.inj_x = A.inj_x ? A.inj_x + off : nullptr; C.inj_f = A.inj_f ? A.inj_f + off : nullptr; C.inj_n = A.inj_n ? A.inj_n + off : nullptr;
+  C.inj_sn = A.inj_sn ? A.inj_sn + so : nullptr; C.inj_sd = A.inj_sd ? A.inj_sd + so : nullptr;
+}
 
 // ---- one workgroup owns the rollout ----
 template <int THREADS>
@@ -148,6 +156,31 @@ __device__ __forceinline__ d3 dri_dfi_T_d(f3 nf, f3 df, float mu, d3 u) {
   w = w + (q * (sd / nT) + n * dot(a, u)) * (double) mu;
   return w;
 }
+// the same with the contact's n and d given in fp64 (a record handed in from outside, dc_set_record): case decided in fp64
+__device__ __forceinline__ d3 dri_dfi_T_dd(d3 n, d3 d, double mu, d3 u) {
+  const double sd = dot(d, n);
+  if (sd >= 0.0) return mkd(0, 0, 0);
+  const d3 dT = d - n * sd;
+  const double nT = sqrt(dot(dT, dT));
+  if (nT <= mu * fabs(sd)) return mkd(0, 0, 0) - u;
+  const d3 a = dT * (1.0 / nT);
+  d3 q = u - a * dot(a, u);
+  q = q - n * dot(n, q);
+  d3 w = n * (-dot(n, u));
+  w = w + (q * (sd / nT) + n * dot(a, u)) * mu;
+  return w;
+}
+__device__ __forceinline__ d3 dri_dmu_dd(d3 n, d3 d, double mu) {
+  const double sd = dot(d, n);
+  if (sd >= 0.0) return mkd(0, 0, 0);
+  const d3 dT = d - n * sd;
+  const double nT = sqrt(dot(dT, dT));
+  if (!(nT > mu * fabs(sd))) return mkd(0, 0, 0);
+  return dT * (-fabs(sd) / nT);
+}
+__device__ __forceinline__ d3 prim_vout_d(const DevPrim &p, d3 n) {
+  return p.rotates ? cross(mkd(0, 1, 0), n) * 8.0 : mkd(0, 0, 0);   // Primitive.cpp:254-257
+}
 // dr/dmu (Simulation::calculatedri_dmu, Simulation.cpp:865-879), case decided in fp32 like above
 __device__ __forceinline__ d3 dri_dmu_d(f3 nf, f3 df, float mu) {
   const float sdf = dot(df, nf);
@@ -165,6 +198,10 @@ __device__ __forceinline__ d3 contact_JT_d(const DevSystem &S, const Adj64 &C, i
   const int prim = C.rec_prim[i];
   if (prim < 0) return mkd(0, 0, 0);
   const int N = S.N;
+  if (C.inj_f) {
+    const d3 n = ld3d(C.inj_n, i, N);
+    return dri_dfi_T_dd(n, ld3d(C.inj_f, i, N) - prim_vout_d(S.prims[prim], n) * S.mass64[i], (double) C.mu[S.prims[prim].group], z);
+  }
   const f3 n = ld3(C.rec_n, i, N);
   const f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];     // the fp32 record of the forward pass
   return dri_dfi_T_d(n, d, C.mu[S.prims[prim].group], z);
@@ -176,6 +213,7 @@ __device__ __forceinline__ d3 contact_JT_d(const DevSystem &S, const Adj64 &C, i
 // that is not that sum (a step that hit the iteration cap and reverted, Simulation.cpp:1357-1367) is taken as stored.
 __device__ __forceinline__ d3 xnew64(const DevSystem &S, const Adj64 &C, int i) {
   const int N = S.N;
+  if (C.inj_x) return ld3d(C.inj_x, i, N);
   const d3 xs = tod(ld3(C.xnew, i, N));
   const d3 xh = tod(ld3(C.xprev, i, N)) + tod(ld3(C.vnew, i, N)) * S.h64;
   auto pick = [](double s, double h) { return fabs(h - s) <= 2.4e-7 * fmax(fabs(s), 1e-3) ? h : s; };
@@ -195,6 +233,23 @@ __device__ __forceinline__ void self_JT_layers_d(const DevSystem &S, const Adj64
   const float4 *nrm = R.nrm + (size_t) b * cap;
   const float4 *dvec = R.dvec + (size_t) b * cap;
   const int need = 8 * M + 8 * Cn + nl + 8;      // floats: 3 M doubles z, M doubles 1/m, 2 C float4, nl + 1 offsets
+  if (C.inj_sn) {      // record from outside: the contacts' n and d in fp64, through global memory
+    __syncthreads();
+    for (int l = nl - 1; l >= 0; l--) {
+      const int k1 = meta[2 + l + 1];
+      for (int k = meta[2 + l] + tid; k < k1; k += THREADS) {
+        const int2 ab = pair[k];
+        const d3 n = mkd(C.inj_sn[3 * k], C.inj_sn[3 * k + 1], C.inj_sn[3 * k + 2]), d = mkd(C.inj_sd[3 * k], C.inj_sd[3 * k + 1], C.inj_sd[3 * k + 2]);
+        const double mA = S.mass64[ab.x], mB = S.mass64[ab.y];
+        d3 zA = ld3y(z, ab.x, N), zB = ld3y(z, ab.y, N);
+        d3 g = dri_dfi_T_dd(n, d, (double) kClothMu, zA - zB) * ((mA * mB) / (mA + mB));
+        st3y(z, ab.x, N, zA + g * (1.0 / mA));
+        st3y(z, ab.y, N, zB - g * (1.0 / mB));
+      }
+      __syncthreads();
+    }
+    return;
+  }
   if (S.self_lds && need <= C.lds_floats) {
     const int *verts = R.verts + (size_t) b * 2 * cap;
     double *lz = (double *) C.lds, *lim = lz + 3 * M;
@@ -529,10 +584,16 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
     }
     const int prim = C.rec_prim[i];
     if (prim >= 0) {
-      const f3 n = ld3(C.rec_n, i, N);
-      const f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];
       const int grp = S.prims[prim].group;
-      const double contrib = dot(dri_dmu_d(n, d, C.mu[grp]), ui) * h;
+      double contrib;
+      if (C.inj_f) {
+        const d3 n = ld3d(C.inj_n, i, N);
+        contrib = dot(dri_dmu_dd(n, ld3d(C.inj_f, i, N) - prim_vout_d(S.prims[prim], n) * m, (double) C.mu[grp]), ui) * h;
+      } else {
+        const f3 n = ld3(C.rec_n, i, N);
+        const f3 d = ld3(C.rec_f, i, N) - prim_vout(S.prims[prim], n) * S.mass[i];
+        contrib = dot(dri_dmu_d(n, d, C.mu[grp]), ui) * h;
+      }
 #pragma unroll
       for (int k = 0; k < kMaxPrims; k++) dmu_part[k] += (k == grp) ? contrib : 0.0;
     }

@@ -236,8 +236,8 @@ __device__ __forceinline__ bool xch_allsum(Xch &X, float a, float b, float c, do
   return xch_finish<THREADS, 1, false>(X, s, none);
 }
 
-// all-parts sum of one fp64 value (as hi + lo fp32 in the granule) and one fp32 value per thread: every wave reduces in fp64 and
-// publishes {hi, lo, c, tag}; wave 0 of the consumer adds the granules up in fp64. Same protocol and barrier count as xch_allsum.
+// all-parts sum of one fp64 value (its 64 bits in two words of the granule) and one fp32 value per thread: every wave reduces in fp64 and
+// publishes {lo word, hi word, c, tag}; wave 0 of the consumer adds the granules up in fp64. Same protocol and barrier count as xch_allsum.
 template <int THREADS>
 __device__ __forceinline__ bool xch_allsum_d(Xch &X, double a, float c, double &sa, double &sc) {
   constexpr int NW = THREADS / 64;
@@ -246,8 +246,7 @@ __device__ __forceinline__ bool xch_allsum_d(Xch &X, double a, float c, double &
   for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
   c = xch_wave_sum(c);
   if ((threadIdx.x & 63) == 0) {
-    const float hi = (float) a, lo = (float) (a - (double) hi);
-    v4i g = {__float_as_int(hi), __float_as_int(lo), __float_as_int(c), (int) X.seq};
+    v4i g = {__double2loint(a), __double2hiint(a), __float_as_int(c), (int) X.seq};      // the 64 bits of the double: full range and precision
     xch_store(X, g, xch_off(X, X.part, (int) (threadIdx.x >> 6)));
   }
   bool ok = true;
@@ -262,7 +261,7 @@ __device__ __forceinline__ bool xch_allsum_d(Xch &X, double a, float c, double &
       if (j < X.K * NW) {
         v4i g;
         ok = xch_poll(X, xch_off(X, j / NW, j % NW), g) && ok;
-        da += (double) __int_as_float(g.x) + (double) __int_as_float(g.y);
+        da += __hiloint2double(g.y, g.x);
         fc += __int_as_float(g.z);
       }
     }

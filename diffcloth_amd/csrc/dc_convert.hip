@@ -15,6 +15,15 @@ __global__ void k_f64i_to_f32p(const double *__restrict__ src, float *__restrict
   float *d = dst + b * 3 * n;
   d[i] = (float) s[0]; d[n + i] = (float) s[1]; d[2 * n + i] = (float) s[2];
 }
+__global__ void k_f64i_to_f64p(const double *__restrict__ src, double *__restrict__ dst, int n, long total, const int *__restrict__ user_of) {
+  long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  long b = t / n;
+  int i = (int) (t - b * n);
+  const double *s = src + (b * n + (user_of ? user_of[i] : i)) * 3;
+  double *d = dst + b * 3 * n;
+  d[i] = s[0]; d[n + i] = s[1]; d[2 * n + i] = s[2];
+}
 __global__ void k_f32p_to_f64i(const float *__restrict__ src, double *__restrict__ dst, int n, long total, const int *__restrict__ user_of) {
   long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
@@ -65,6 +74,11 @@ void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, const int 
   long total = (long) B * n;
   if (total == 0) return;
   hipLaunchKernelGGL(k_f64i_to_f32p, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total, user_of);
+}
+void launch_f64i_to_f64p(const double *src, double *dst, int B, int n, const int *user_of, hipStream_t st) {
+  long total = (long) B * n;
+  if (total == 0) return;
+  hipLaunchKernelGGL(k_f64i_to_f64p, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, st, src, dst, n, total, user_of);
 }
 void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, const int *user_of, hipStream_t st) {
   long total = (long) B * n;

@@ -62,12 +62,13 @@ struct DevSystem {
   const int DC_G *ell_w;             // [ceil(N/64)] width of the chunk
   // P once more, symmetrically scaled to unit diagonal (D^-1/2 P D^-1/2) and packed for dc_forward_pk.hip: per
   // 64-row chunk pk_n[c] 16-byte packets per row (a multiple of 4), packet (s, lane) at pk[pk_ptr[c] + 64 s + lane] =
-  // {v0, v1, v2, d0 | d1 << 10 | d2 << 20}, d = column - row + 512; chunks cover 512 * pk_vpt rows
+  // {v0, v1, v2, d0 | d1 << 10 | d2 << 20}, d = column - row + 512; chunks cover pk_threads * pk_vpt rows
   const int4 DC_G *pk;
   const int DC_C *pk_ptr;
   const int DC_C *pk_n;
-  const float DC_G *sq_dinv;         // [512 * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
+  const float DC_G *sq_dinv;         // [pk_threads * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
+  int pk_threads, pad3;         // threads of the packet kernel the tables are padded for (512 or 768)
   // explicit inverse of the scaled matrix for small meshes (dc_dense.h): [N + pad][dense_ld] fp32, null = not built
   const float DC_G *dense_inv;
   int dense_ld;
@@ -199,6 +200,9 @@ struct BwdArgs {
   int nsteps, slot;
   size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements); d_xfixed steps by slot_xf too
   size_t slot_ix;               // seed schedule: ix / iv of step s are ix - s * slot_ix (0: none / the same buffer)
+  // record handed in from outside (dc_set_record): the fp64 values of x_new, f, the primitive-contact normals ([B][3][N] planar) and of
+  // the self contacts' normals / d ([B][cap][3]) for the fp64 operator; all null for a record the forward kernels made
+  const double *inj_x, *inj_f, *inj_n, *inj_sn, *inj_sd;
 };
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);
@@ -210,6 +214,7 @@ void launch_self_detect(const DevSystem &S, const DevWork &W, const FwdArgs &A, 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st);
 void launch_f64i_to_f32p(const double *src, float *dst, int B, int n, const int *user_of, hipStream_t st);
 void launch_f32p_to_f64i(const float *src, double *dst, int B, int n, const int *user_of, hipStream_t st);
+void launch_f64i_to_f64p(const double *src, double *dst, int B, int n, const int *user_of, hipStream_t st);
 void launch_dev_to_planar(const void *src, int is_f32, float *dst, int B, int n, const int *user_of, hipStream_t st);
 void launch_planar_to_dev(const float *src, void *dst, int is_f32, int B, int n, const int *user_of, hipStream_t st);
 void launch_copy_cast(const float *src, void *dst, int is_f32, long total, hipStream_t st);

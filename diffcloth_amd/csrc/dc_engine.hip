@@ -12,6 +12,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #define NCCL_UNIQUE_ID_BYTES 128
 }
 #include <dlfcn.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -88,6 +89,10 @@ struct dc_ctx {
   void *comm = nullptr;             // RCCL communicator of dc_comm_init (ncclComm_t), one rank per context
   int comm_ranks = 0;
   std::vector<void *> sched_pool;
+  // record handed in from outside (dc_set_record): fp64 values of x_new, f, primitive-contact normals [B][3][N], self-contact normals / d
+  // [B][cap][3]; allocated on first use, valid for tape slot inj_slot only (-1 = none)
+  double *INJ_X = nullptr, *INJ_F = nullptr, *INJ_N = nullptr, *INJ_SN = nullptr, *INJ_SD = nullptr;
+  int inj_slot = -1;
   dc_step_stats *fstats = nullptr;  // [(tape+1)][B]
   dc_bwd_stats *bstats = nullptr;   // [(tape+1)][B], indexed by the slot whose record was differentiated
   double *stage[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -240,6 +245,9 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   { const char *envp = getenv("DC_ADJ_DENSEY"); A.dense_y = envp ? (envp[0] == '1') : 0; }
   { const char *envp = getenv("DC_ADJ_VERIFY"); A.verify_all = envp ? (envp[0] == '1') : 0; }     // (development switch)
   A.nsteps = 1; A.slot = slot;
+  const bool inj = c->inj_slot == slot && c->INJ_X;
+  A.inj_x = inj ? c->INJ_X : nullptr; A.inj_f = inj ? c->INJ_F : nullptr; A.inj_n = inj ? c->INJ_N : nullptr;
+  A.inj_sn = inj ? c->INJ_SN : nullptr; A.inj_sd = inj ? c->INJ_SD : nullptr;
   A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   A.slot_param = (size_t) c->B * 8; A.slot_xf = (size_t) c->B * 3 * c->S.Af; A.slot_stats = (size_t) c->B;
   return A;
@@ -414,6 +422,10 @@ bool use_cluster_fwd(const dc_ctx *c) { return c->cl.ok; }
 bool use_cluster_bwd(const dc_ctx *c) { return c->cl.ok && c->params.adjoint_mode == 1; }
 
 int enqueue_pd_step(dc_ctx *c, const FwdArgs &A) {
+  {   // a forward step overwrites records: a record handed in from outside for one of them (dc_set_record) is gone
+    const long first = (long) ((A.x_out - c->X) / (long) slot_elems(c));
+    if (c->inj_slot >= first && c->inj_slot < first + A.nsteps) c->inj_slot = -1;
+  }
   if (!use_cluster_fwd(c)) { launch_pd_step(c->S, c->W, A, c->B, c->stream); HIPCHK(c, hipGetLastError()); return DC_OK; }
   for (int b0 = 0; b0 < c->B; b0 += c->cl.nb) {
     HIPCHK(c, hipMemsetAsync(c->cl.D.xch, 0, c->cl.xch_bytes, c->stream));
@@ -573,7 +585,7 @@ int dc_build(dc_ctx *c) {
     HostWindows HW; HostPackets HP;
     c->S.win_ok = HW.build(H, (size_t) 150 * 1024) ? 1 : 0;
     c->S.pk_ok = HP.build(H) ? 1 : 0;
-    c->S.nwin = HW.nwin; c->S.pk_vpt = HP.vpt;
+    c->S.nwin = HW.nwin; c->S.pk_vpt = HP.vpt; c->S.pk_threads = HP.threads;
     c->built = true;
     return DC_OK;
   }
@@ -725,7 +737,7 @@ int dc_build(dc_ctx *c) {
       if ((rc = upload<int>(c, &S.pk_ptr, HP.pk_ptr))) return rc;
       if ((rc = upload<int>(c, &S.pk_n, HP.pk_n))) return rc;
       if ((rc = upload<float>(c, &S.sq_dinv, HP.sq_dinv))) return rc;
-      S.pk_vpt = HP.vpt; S.pk_ok = 1;
+      S.pk_vpt = HP.vpt; S.pk_threads = HP.threads; S.pk_ok = 1;
     }
   }
   {  // small meshes: explicit inverse of the scaled matrix (dc_dense.h) for the forward global step
@@ -901,6 +913,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->FU_S, (size_t) B * 3 * slots))) return rc;
   if ((rc = dev_alloc(c, pool, &c->FVS_S, (size_t) B * slots))) return rc;
   c->SEEDX = c->SEEDV = nullptr;
+  c->INJ_X = c->INJ_F = c->INJ_N = c->INJ_SN = c->INJ_SD = nullptr; c->inj_slot = -1;
   c->sched_xf.assign(slots + 1, 0); c->sched_fu.assign(slots + 1, 0); c->sched_fvs.assign(slots + 1, 0); c->sched_seed.assign(slots + 1, 0);
   if ((rc = dev_alloc(c, pool, &c->DMU, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->target, (size_t) 3 * N))) return rc;
@@ -1075,6 +1088,102 @@ int dc_get_self_contacts(dc_ctx *c, int slot, int rollout, int cap, int *count, 
     if (normal) { normal[3 * k] = nr[k].x; normal[3 * k + 1] = nr[k].y; normal[3 * k + 2] = nr[k].z; }
     if (layer) { int l = 0; while (l + 1 < nl && k >= meta[2 + l + 1]) l++; layer[k] = l; }
   }
+  return DC_OK;
+}
+
+int dc_set_record(dc_ctx *c, int slot, const dc_record *rec) {
+  int rc = check_batch(c, slot, slot);
+  if (rc) return rc;
+  if (slot < 1) return fail(c, DC_ERR_INVALID, "dc_set_record: slot 0 has no record");
+  if (!rec || !rec->x || !rec->v || !rec->f || !rec->prim || !rec->normal) return fail(c, DC_ERR_INVALID, "dc_set_record: x, v, f, prim and normal are required");
+  if (rec->self_count && (!rec->self_pairs || !rec->self_layer || !rec->self_normal || !rec->self_d)) return fail(c, DC_ERR_INVALID, "dc_set_record: incomplete self-contact lists");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->host.N, B = c->B, Af = c->S.Af, cap = c->self_cap, np = (int) c->prims.size();
+  const size_t se = slot_elems(c), sp = (size_t) B * N;
+  if (!c->INJ_X) {
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->INJ_X, se))) return rc;
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->INJ_F, se))) return rc;
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->INJ_N, se))) return rc;
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->INJ_SN, (size_t) B * cap * 3))) return rc;
+    if ((rc = dev_alloc(c, c->batch_allocs, &c->INJ_SD, (size_t) B * cap * 3))) return rc;
+  }
+  c->inj_slot = -1;
+  // per-vertex part: fp32 tape entries + fp64 planes (device numbering)
+  struct { const double *src; float *dst32; double *dst64; } planes[5] = {
+      {rec->x, c->X + se * slot, c->INJ_X}, {rec->v, c->V + se * slot, nullptr}, {rec->f, c->F + se * slot, c->INJ_F},
+      {rec->r, c->R + se * slot, nullptr}, {rec->normal, c->NRM + se * slot, c->INJ_N}};
+  for (auto &pl : planes) {
+    if (!pl.src) continue;
+    HIPCHK(c, hipMemcpyAsync(c->stage[0], pl.src, se * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_f64i_to_f32p(c->stage[0], pl.dst32, B, N, c->d_user_of, c->stream);
+    if (pl.dst64) launch_f64i_to_f64p(c->stage[0], pl.dst64, B, N, c->d_user_of, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  {
+    std::vector<int> prim(sp);
+    for (int b = 0; b < B; b++)
+      for (int i = 0; i < N; i++) {
+        const int q = rec->prim[(size_t) b * N + (c->user_of.empty() ? i : c->user_of[i])];
+        if (q >= np) return fail(c, DC_ERR_INVALID, "dc_set_record: primitive index out of range");
+        prim[(size_t) b * N + i] = q < 0 ? -1 : q;
+      }
+    HIPCHK(c, hipMemcpy(c->PRIM + sp * slot, prim.data(), sp * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (rec->x_fixed && Af > 0) {
+    if ((rc = h2d_planar(c, rec->x_fixed, c->XF + (size_t) B * 3 * Af * slot, Af, 2, false))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  {  // self contacts: the record layout the detection kernel leaves (dc_selflib.h): contacts by layer, pairs in device numbering (.x = the
+     // caller's smaller id), working-set slots = rank of the caller's ids among the contact vertices, offsets and counts in the meta block
+    std::vector<int> meta((size_t) B * kMetaStride, 0), verts((size_t) B * 2 * cap, 0);
+    std::vector<int2> pair((size_t) B * cap, make_int2(0, 0));
+    std::vector<float4> nrm((size_t) B * cap, make_float4(0, 0, 0, 0)), dv((size_t) B * cap, make_float4(0, 0, 0, 0));
+    std::vector<double> sn((size_t) B * cap * 3, 0.0), sd((size_t) B * cap * 3, 0.0);
+    size_t at = 0;
+    for (int b = 0; b < B && rec->self_count; b++) {
+      const int C = rec->self_count[b];
+      if (C < 0 || C > cap) return fail(c, DC_ERR_CAPACITY, "dc_set_record: more self contacts than max_self_contacts = " + std::to_string(cap));
+      int *m = meta.data() + (size_t) b * kMetaStride;
+      std::vector<int> ids;
+      int nl = 0;
+      for (int k = 0; k < C; k++) {
+        const int p1 = rec->self_pairs[2 * (at + k)], p2 = rec->self_pairs[2 * (at + k) + 1], l = rec->self_layer[at + k];
+        if (p1 < 0 || p2 >= N || p1 >= p2) return fail(c, DC_ERR_INVALID, "dc_set_record: self contact pair must satisfy 0 <= id1 < id2 < N");
+        if (l < 0 || l >= kMaxLayers || (k > 0 && l < rec->self_layer[at + k - 1])) return fail(c, DC_ERR_INVALID, "dc_set_record: self contacts must come in layer order");
+        nl = std::max(nl, l + 1);
+        ids.push_back(p1); ids.push_back(p2);
+      }
+      std::sort(ids.begin(), ids.end());
+      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+      const int M = (int) ids.size();
+      m[0] = C; m[1] = C > 0 ? nl : 0;
+      for (int k = 0; k < C; k++) m[2 + rec->self_layer[at + k] + 1]++;
+      for (int l = 0; l < nl; l++) m[2 + l + 1] += m[2 + l];
+      m[kMetaStride - 1] = M; m[kMetaStride - 2] = 0; m[kMetaStride - 3] = C;
+      for (int q = 0; q < M; q++) verts[(size_t) b * 2 * cap + q] = c->dev_of.empty() ? ids[q] : c->dev_of[ids[q]];
+      for (int k = 0; k < C; k++) {
+        const int p1 = rec->self_pairs[2 * (at + k)], p2 = rec->self_pairs[2 * (at + k) + 1];
+        const int s1 = (int) (std::lower_bound(ids.begin(), ids.end(), p1) - ids.begin()), s2 = (int) (std::lower_bound(ids.begin(), ids.end(), p2) - ids.begin());
+        const size_t o = (size_t) b * cap + k;
+        pair[o] = make_int2(c->dev_of.empty() ? p1 : c->dev_of[p1], c->dev_of.empty() ? p2 : c->dev_of[p2]);
+        const int slots = s1 | (s2 << 16);
+        float w; std::memcpy(&w, &slots, sizeof(float));
+        nrm[o] = make_float4((float) rec->self_normal[3 * (at + k)], (float) rec->self_normal[3 * (at + k) + 1], (float) rec->self_normal[3 * (at + k) + 2], w);
+        dv[o] = make_float4((float) rec->self_d[3 * (at + k)], (float) rec->self_d[3 * (at + k) + 1], (float) rec->self_d[3 * (at + k) + 2], 0.f);
+        for (int d = 0; d < 3; d++) { sn[3 * o + d] = rec->self_normal[3 * (at + k) + d]; sd[3 * o + d] = rec->self_d[3 * (at + k) + d]; }
+      }
+      at += C;
+    }
+    const size_t sc = (size_t) B * cap * slot;
+    HIPCHK(c, hipMemcpy(c->SC_meta + (size_t) B * kMetaStride * slot, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->SC_pair + sc, pair.data(), pair.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->SC_nrm + sc, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->SC_d + sc, dv.data(), dv.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->SC_verts + 2 * sc, verts.data(), verts.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->INJ_SN, sn.data(), sn.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->INJ_SD, sd.data(), sd.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  c->inj_slot = slot;
   return DC_OK;
 }
 
@@ -1270,7 +1379,9 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
     if (ns % nsteps) return fail(c, DC_ERR_INVALID, "dc_rollout_backward: the seed schedule covers only part of the slots " + std::to_string(slot - nsteps) + " .. " + std::to_string(slot - 1));
   }
   if (c->S.Af > 0) HIPCHK(c, hipMemsetAsync(c->DXF + (size_t) c->B * 3 * c->S.Af * (slot - nsteps + 1), 0, sizeof(float) * c->B * 3 * c->S.Af * nsteps, c->stream));
-  if (fuse_ok && nsteps > 1) {
+  const bool inj_inside = c->inj_slot >= slot - nsteps + 1 && c->inj_slot <= slot;      // (dc_set_record: that step gets a launch of its own)
+  const bool fused_bwd = fuse_ok && nsteps > 1 && !inj_inside;
+  if (fused_bwd) {
     BwdArgs A = bwd_args(c, slot, slot == 1, false);
     A.nsteps = nsteps;                       // the whole sweep of a rollout in one launch
     if ((rc = enqueue_adjoint_step(c, A))) return rc;
@@ -1286,7 +1397,7 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   float ms = 0;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_a, c->ev_b));
   const int chunks = use_cluster_bwd(c) ? (c->B + c->cl.nb - 1) / c->cl.nb : 1;
-  c->bwd_ms += ms; c->bwd_launches += ((fuse_ok && nsteps > 1) ? 1 : nsteps) * chunks;
+  c->bwd_ms += ms; c->bwd_launches += (fused_bwd ? 1 : nsteps) * chunks;
   return cluster_check(c);
 }
 

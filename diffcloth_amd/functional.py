@@ -30,16 +30,36 @@ class BatchedSim:
         self.step_num = int(step_num)
         self.step_idx = 0
         self._stream = None
+        self._bwd_slots = set()
 
-    def on_current_stream(self):
-        """order the engine's work with torch's current CUDA stream (once per stream change)"""
-        st = torch.cuda.current_stream()
+    def on_current_stream(self, device=None):
+        """order the engine's work with torch's current CUDA stream of the tensors' device (once per stream change). torch's default
+        stream has handle 0, which dc_use_stream reads as "the context's own stream": ordering with torch's kernels on the legacy
+        default stream then rests on its implicit synchronisation with blocking streams (the context's stream is a blocking one)."""
+        st = torch.cuda.current_stream(device)
         if self._stream is None or self._stream.cuda_stream != st.cuda_stream:
             self.engine.use_stream(st)
             self._stream = st
 
+    def check_episode(self):
+        """Surface engine errors of the episode so far: the device-pointer calls (dc_*_dev) only enqueue work and report nothing, so a
+        timed-out exchange of the split kernels (sticky error word), a self-contact list overflow or an adjoint solve that did not converge
+        would otherwise flow into the optimiser as garbage states / gradients. One synchronisation + the statistics of the recorded steps;
+        called at the end of an episode's backward sweep (slot 1) and by reset(). Raises capi.DcError / RuntimeError."""
+        e = self.engine
+        e.sync()                                     # raises on a timed-out exchange
+        for slot in range(1, self.step_idx + 1):
+            fwd, bwd = e.get_stats(slot)             # raises DC_ERR_CAPACITY on a self-contact overflow of that step
+            if slot in self._bwd_slots and (bwd["converged"] == 0).any():
+                bad = int(np.nonzero(bwd["converged"] == 0)[0][0])
+                raise RuntimeError(f"BatchedSim: the adjoint solve of step {slot}, rollout {bad} did not converge "
+                                   f"(relative residual {float(bwd['last_udiff'][bad]):.2e})")
+
     def reset(self, x0, v0=None):
         """Start a new episode from the given states ([B, 3N]); returns them as float32 tensors like getStateInfo()."""
+        if self.step_idx > 0:
+            self.check_episode()
+        self._bwd_slots = set()
         x0 = np.asarray(x0, dtype=np.float64).reshape(self.engine.B, -1)
         v0 = np.zeros_like(x0) if v0 is None else np.asarray(v0, dtype=np.float64).reshape(self.engine.B, -1)
         self.engine.set_state(0, x0, v0)
@@ -56,19 +76,20 @@ class BatchedSimFunction(torch.autograd.Function):
             raise RuntimeError("BatchedSimFunction: tape exhausted, call BatchedSim.reset()")
         ctx.sim = sim
         ctx.slot = slot + 1
-        sim.step_idx = slot + 1
         if x.is_cuda:           # device path: pointers in, pointers out, torch's stream
-            sim.on_current_stream()
+            sim.on_current_stream(x.device)
             xd, vd = x.detach().contiguous(), v.detach().to(x.dtype).contiguous()
             e.set_state_dev(slot, xd, vd)
             e.step_forward_dev(slot, None if e.Af == 0 else a.detach().to(x.dtype).contiguous())
             xn, vn = torch.empty_like(xd), torch.empty_like(vd)
             e.get_state_dev(slot + 1, xn, vn)
+            sim.step_idx = slot + 1            # (only once the step is enqueued: a raised error leaves the tape index where it was)
             return xn, vn
         e.set_state(slot, np.float64(x.contiguous().detach().numpy()), np.float64(v.contiguous().detach().numpy()))
         act = None if e.Af == 0 else np.float64(a.contiguous().detach().numpy())
         e.step_forward(slot, fixed_pts=act, want_stats=False)
         xn, vn = e.get_state(slot + 1)
+        sim.step_idx = slot + 1
         return torch.as_tensor(xn).to(x.dtype), torch.as_tensor(vn).to(v.dtype)
 
     @staticmethod
@@ -76,8 +97,9 @@ class BatchedSimFunction(torch.autograd.Function):
         sim, slot = ctx.sim, ctx.slot
         e = sim.engine
         last = slot == sim.step_num            # functional.py:66-75
+        sim._bwd_slots.add(slot)
         if dL_dx_next.is_cuda:
-            sim.on_current_stream()
+            sim.on_current_stream(dL_dx_next.device)
             gx = dL_dx_next.detach().contiguous(); gv = dL_dv_next.detach().to(gx.dtype).contiguous()
             dx, dv = torch.empty_like(gx), torch.empty_like(gx)
             da = torch.zeros((e.B, max(3 * e.Af, 1)), dtype=gx.dtype, device=gx.device)[:, :3 * e.Af].contiguous()
@@ -90,6 +112,8 @@ class BatchedSimFunction(torch.autograd.Function):
                 n = da.norm(dim=1, keepdim=True)
                 scale = torch.where(n > 1e-7, n.clamp(min=0.05, max=4.0 * da.shape[1]) / n.clamp(min=1e-30), torch.ones_like(n))
                 da = da * scale
+            if slot == 1:
+                sim.check_episode()            # end of the episode's backward sweep: one synchronisation, errors surface here
             return dx, dv, da, None
         gx = np.float64(dL_dx_next.contiguous().detach().numpy())
         gv = np.float64(dL_dv_next.contiguous().detach().numpy())

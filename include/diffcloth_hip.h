@@ -113,10 +113,13 @@ typedef struct dc_bwd_stats {
   int cg_iters;
   int clipped;
   int used_direct;       /* 1 when the direct (Krylov) solve ran; adjoint_iters then counts its iterations too */
-  float last_udiff;      /* mode 0: |u_new - u|_2 / N; direct solve: relative residual |g - K u| / |g| (mixed precision: the TRUE
-                            residual, evaluated in fp64; adjoint_fp32_only: the fp32 recurrence's)                          */
+  float last_udiff;      /* mode 0: |u_new - u|_2 / N; direct solve: relative residual |g - K u| / |g| — mixed precision: the TRUE
+                            residual evaluated in fp64 (residual_verified = 1), or, when the last fp32 correction solve was accepted
+                            without a further fp64 evaluation, an upper bound: its recurrence residual + twice the measured fp32
+                            operator error (residual_verified = 0); adjoint_fp32_only: the fp32 recurrence's                 */
   int refine_cycles;     /* direct solve, mixed precision: fp32 solves run (each followed by an fp64 residual evaluation)    */
   int fp64_iters;        /* BiCGSTAB iterations of the fp64 fall-back (0: the fp32 corrections were enough)                 */
+  int residual_verified; /* direct solve, mixed precision: 1 = last_udiff is an fp64-evaluated residual, 0 = the bound described there */
 } dc_bwd_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -183,6 +186,31 @@ int dc_get_contacts(dc_ctx *ctx, int slot, int *prim_group, double *normal);
  * per contact; at most `cap` entries are written, *count receives the total.                                  */
 int dc_get_self_contacts(dc_ctx *ctx, int slot, int rollout, int cap, int *count, int *num_layers, int *pairs /*2*cap*/,
                          int *layer /*cap*/, double *normal /*3*cap*/);
+
+/* A forward record handed in from OUTSIDE. Simulation::stepBackward differentiates the ForwardInformation it is given, whoever made it
+ * (Simulation.cpp:1455-1551 reads forwardInfo_new.x / .x_prev / .v_prev / .f / .x_fixedpoints / .collisionInfos; records also come from
+ * disk, resetForwardRecordsFromFolder): dc_set_record writes record `slot` of all B rollouts — the tape entries in fp32 AND the values
+ * as passed (fp64) for the adjoint's fp64 operator, so that dc_step_backward(slot) solves the adjoint system of exactly this record
+ * (teacher-forced parity tests upload the fp64 oracle's record; the forward kernels are not involved). The state the step started from
+ * (x_prev, v_prev) is slot - 1 (dc_set_state). The fp64 copy belongs to this one slot and is dropped when a forward step overwrites the
+ * slot, when another record is set, or by dc_alloc_batch; a fused backward sweep over an injected slot runs step by step.             */
+typedef struct dc_record {
+  const double *x, *v;          /* B*3N  ForwardInformation::x, ::v — the state after the step                                       */
+  const double *f;              /* B*3N  ForwardInformation::f (b~ - C v of the last PD iteration: the contact vectors d derive from it) */
+  const double *r;              /* B*3N  ForwardInformation::r, may be NULL (the adjoint does not read it)                           */
+  const int *prim;              /* B*N   primitive in contact with the vertex: index into the dc_set_primitives array (LowerLeg children
+                                          flattened), -1 = none (PrimitiveCollisionInformation::primitiveId)                          */
+  const double *normal;         /* B*3N  contact normal at the vertices in contact (ignored elsewhere)                               */
+  const double *x_fixed;        /* B*3Af ForwardInformation::x_fixedpoints of the step; NULL keeps the slot's                        */
+  /* layered self contacts (collisionInfos.second, the output of contactSorting): self_count[b] contacts per rollout, concatenated in
+   * rollout order; within a rollout in layer order (self_layer non-decreasing, starting at 0)                                       */
+  const int *self_count;        /* B, or NULL = no self contacts                                                                     */
+  const int *self_pairs;        /* 2 per contact: particleId1 < particleId2                                                          */
+  const int *self_layer;        /* 1 per contact: layerId                                                                            */
+  const double *self_normal;    /* 3 per contact                                                                                     */
+  const double *self_d;         /* 3 per contact: SelfCollisionInformation::d of the last friction evaluation                        */
+} dc_record;
+int dc_set_record(dc_ctx *ctx, int slot, const dc_record *rec);
 
 /* Simulation::stepBackward()/stepBackwardNN() (Simulation.cpp:1443-1780) through the step that produced
  * `slot` (forwardInfo_new = record `slot`). Inputs B*3N each; dL_dxinit/dL_dvinit may be NULL (zeros).

@@ -171,7 +171,8 @@ int orc_get_self_contacts(void *s, int id, int *ints, double *dbls, int cap) {
     }
   return total;
 }
-// Backward through record `id`. scal: [dL_dk_stretch, dL_dk_bend, dL_dk_att, dL_ddensity, dL_dwind(5), dL_dwindtimestep] (10 doubles)
+// Backward through record `id`. scal: [dL_dk_stretch, dL_dk_bend, dL_dk_att, dL_ddensity, dL_dwind(5), dL_dwindtimestep, relative
+// residual of the direct solve or -1] (11 doubles)
 // info: [converged, backwardIters, usedDirect]
 void orc_step_backward(void *s, int id, const double *dL_dxnew, const double *dL_dvnew, const double *dL_dxinit,
                        const double *dL_dvinit, int isStart, int forceDirect, double *dL_dx, double *dL_dv,
@@ -184,7 +185,7 @@ void orc_step_backward(void *s, int id, const double *dL_dxnew, const double *dL
   if (dL_dmu) std::memcpy(dL_dmu, o.dL_dmu.data(), sizeof(double) * o.dL_dmu.size());
   if (scal) { for (int k = 0; k < 3; k++) scal[k] = o.dL_dk[k]; scal[3] = o.dL_ddensity; for (int k = 0; k < 5; k++) scal[4 + k] = o.dL_dwind[k]; }
   if (info) { info[0] = o.converged; info[1] = o.backwardIters; info[2] = o.usedDirect; }
-  if (scal) scal[9] = o.dL_dwindtimestep;
+  if (scal) { scal[9] = o.dL_dwindtimestep; scal[10] = o.directResidual; }
   if (dfext_vec) std::memcpy(dfext_vec, o.dL_dfext_vec.data(), sizeof(double) * o.dL_dfext_vec.size());
 }
 // Collision detection + layering only (for tests of Sim.cpp:225-624).
@@ -241,6 +242,41 @@ extern "C" void orc_override_record(void *s, int id, const double *x, const doub
     rec.f.assign(f, f + rec.f.size());
     S->dryFrictionVector(rec.f, rec.prim, rec.layers, rec.r);
   }
+}
+
+// Diagnostic: the solution a forced direct solve of orc_step_backward is to take (3N doubles; NULL: solve with GMRES again)
+extern "C" void orc_set_given_u(void *s, const double *u) {
+  Sim *S = (Sim *) s;
+  if (u) S->given_u.assign(u, u + 3 * (size_t) S->N); else S->given_u.clear();
+}
+
+// Diagnostic, used with orc_override_record to differentiate a record that another engine produced (the "same record on both sides"
+// parity tests): contact normals of record `id` replaced — prim_normal (3N, read at the vertices in contact with a primitive; a rotating
+// sphere's v_out follows its normal, Primitive.cpp:254-257) and the normals of the self contacts named by pairs (particleId1, particleId2).
+// Call it BEFORE orc_override_record(f): that call re-derives d and r of every contact with the normals in place.
+extern "C" int orc_override_contacts(void *s, int id, const double *prim_normal, int nself, const int *pairs, const double *self_normal) {
+  Sim *S = (Sim *) s; Record &rec = S->records[id];
+  if (prim_normal)
+    for (PrimContact &c : rec.prim) {
+      if (c.primitiveId < 0) continue;
+      const V3 old_n = c.normal;
+      c.normal = V3(prim_normal[3 * c.particleId], prim_normal[3 * c.particleId + 1], prim_normal[3 * c.particleId + 2]);
+      const Primitive &p = S->prims[c.primitiveId];
+      if (p.rotates) c.v_out += (V3(0, 1, 0).cross(c.normal) - V3(0, 1, 0).cross(old_n)) * 8;
+    }
+  int matched = 0;
+  if (nself > 0 && pairs && self_normal) {
+    std::map<std::pair<int, int>, int> where;
+    for (int k = 0; k < nself; k++) where[{pairs[2 * k], pairs[2 * k + 1]}] = k;
+    for (auto &layer : rec.layers)
+      for (SelfContact &c : layer) {
+        auto it = where.find({c.particleId1, c.particleId2});
+        if (it == where.end()) continue;
+        c.normal = V3(self_normal[3 * it->second], self_normal[3 * it->second + 1], self_normal[3 * it->second + 2]);
+        matched++;
+      }
+  }
+  return matched;
 }
 
 // Diagnostic: let the local projections see the deformation gradient (the weighted bending vector) rounded to fp32, as an fp32

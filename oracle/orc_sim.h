@@ -76,6 +76,7 @@ struct BackwardOut {      // BackwardInformation, Simulation.h:136-162 (hot-path
   bool converged = false;
   int backwardIters = 0;
   bool usedDirect = false;
+  double directResidual = -1;        // relative residual |g - K u| / |g| the direct solve ended with (-1: it did not run)
 };
 
 struct Params {
@@ -98,6 +99,8 @@ struct Params {
 
 struct Sim {
   Params P;
+  std::vector<double> given_u;   // diagnostic (orc_set_given_u): when it has 3N entries, a forced direct solve of stepBackward takes THIS solution instead of
+                                 // running GMRES — tests solve near-singular adjoint systems with a sparse LU (scipy) as the reference's SparseLU does
   int N = 0;
   std::vector<double> windFallOff;          // 3N (Simulation.h:349), empty = ones
   std::vector<double> external_force_field; // 3N (Simulation.h:418)

@@ -206,19 +206,55 @@ class Oracle:
         iv = f64(dL_dvinit if dL_dvinit is not None else z).reshape(-1)
         num_mu = self.nprim if num_mu is None else num_mu
         dx = f64(np.zeros(n3)); dv = f64(np.zeros(n3)); dxf = f64(np.zeros(max(3 * self.Af, 1)))
-        dmu = f64(np.zeros(max(num_mu, 1))); scal = f64(np.zeros(10)); info = i32(np.zeros(3)); fvec = f64(np.zeros(n3))
+        dmu = f64(np.zeros(max(num_mu, 1))); scal = f64(np.zeros(11)); info = i32(np.zeros(3)); fvec = f64(np.zeros(n3))
         self.L.orc_step_backward(self.h, C.c_int(rid), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
                                  C.c_int(int(direct)), _d(dx), _d(dv), _d(dxf), C.c_int(num_mu), _d(dmu), _d(scal), _i(info), _d(fvec))
         return dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:3 * self.Af], dL_dmu=dmu[:num_mu], dL_dk=scal[0:3],
                     dL_ddensity=scal[3], dL_dwind=scal[4:9], dL_dwindtimestep=float(scal[9]), dL_dfext_vec=fvec,
                     converged=bool(info[0]), iters=int(info[1]),
-                    used_direct=bool(info[2]))
+                    used_direct=bool(info[2]), direct_residual=float(scal[10]))
 
     def override_record(self, rid, x=None, f=None):
         """diagnostic: replace x_new and / or f of record `rid` (contact vectors d, r re-derived from f)"""
         xx = None if x is None else f64(x).reshape(-1)
         ff = None if f is None else f64(f).reshape(-1)
         self.L.orc_override_record(self.h, C.c_int(rid), None if xx is None else _d(xx), None if ff is None else _d(ff))
+
+    def adopt_record(self, rid, x, f, prim_normal=None, self_pairs=None, self_normal=None):
+        """Make record `rid` the record ANOTHER engine holds of the same step (same contact sets): x_new, f, and — when given — the
+        contact normals (prim_normal: 3N, read at the vertices in primitive contact; self contacts matched by their (id1, id2) pair);
+        d and r of every contact are re-derived from f with those normals. Returns the number of self contacts matched."""
+        matched = 0
+        pn = None if prim_normal is None else f64(prim_normal).reshape(-1)
+        if pn is not None or self_pairs is not None:
+            sp = i32(self_pairs if self_pairs is not None else np.zeros((0, 2))).reshape(-1)
+            sn = f64(self_normal if self_normal is not None else np.zeros((0, 3))).reshape(-1)
+            self.L.orc_override_contacts.restype = C.c_int
+            matched = self.L.orc_override_contacts(self.h, C.c_int(rid), None if pn is None else _d(pn), C.c_int(sp.size // 2), _i(sp), _d(sn))
+        self.override_record(rid, x=x, f=f)
+        return matched
+
+    def step_backward_lu(self, rid, dL_dxnew, dL_dvnew, **kw):
+        """step_backward(direct=True) with the adjoint system K u = g solved by a sparse LU of the explicit K (scipy, SuperLU) — what the
+        reference's solveDirect does (SparseLU, Simulation.cpp:1431-1440) and the robust choice for near-singular K, where the oracle's
+        restarted GMRES needs thousands of products. Gradient clipping must be off (g is taken as passed). Returns the usual dict plus
+        lu_residual = |g - K u| / |g|."""
+        import scipy.sparse.linalg as spla
+        assert not self.flags["clip"], "step_backward_lu: gradient clipping rescales g inside the oracle"
+        K = self.adjoint_matrix(rid)
+        g = f64(dL_dxnew).reshape(-1)
+        lu = spla.splu(K.tocsc())
+        u = lu.solve(g)
+        u = u + lu.solve(g - K @ u)                  # one step of iterative refinement
+        res = float(np.linalg.norm(g - K @ u) / max(np.linalg.norm(g), 1e-300))
+        uu = f64(u)
+        self.L.orc_set_given_u(self.h, _d(uu))
+        try:
+            out = self.step_backward(rid, dL_dxnew, dL_dvnew, direct=True, **kw)
+        finally:
+            self.L.orc_set_given_u(self.h, None)
+        out["lu_residual"] = res
+        return out
 
     def diagnostics(self, bits):
         """process-wide diagnostic switches of the oracle library (orc_emulate_fp32_F): 1 = deformation gradient rounded to fp32, 2 = velocity

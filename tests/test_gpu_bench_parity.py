@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 import bench                      # noqa: E402  (the workload definition under test is bench.py's)
 import meshes                     # noqa: E402
 import orc                        # noqa: E402
+import records                    # noqa: E402
 from diffcloth_amd import capi    # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -69,10 +70,12 @@ def test_bench_configuration_matches_oracle(B, sample):
     states = [e.get_state(W + s) for s in range(S + 1)]
     gscale = 2.0 / ((S + 1) * e.N)
     e.seed_gradient(W + S, None, gscale)
-    carried = [e.get_gradient()[:2]]
+    carried = [e.get_gradient()]               # (dL_dx, dL_dv, dL_dmu accumulated over the sweep — what bench.py all-reduces)
     for s in range(S):
         e.rollout_backward(W + S - s, 1)
-        carried.append(e.get_gradient()[:2])
+        carried.append(e.get_gradient())
+    recs_f = [e.get_record(W + s + 1)[0] for s in range(S)]
+    nrm_gpu = [e.get_contacts(W + s + 1)[1] for s in range(S)]
     stats = [e.get_stats(W + s + 1) for s in range(S)]
     for s in range(S):
         fs, bs = stats[s]
@@ -85,7 +88,7 @@ def test_bench_configuration_matches_oracle(B, sample):
     o.build()
     o.set_force_extras(None, field, 1.0)
     worst_x = worst_g = 0.0
-    errs = []
+    errs, mu_errs, same_errs = [], [], []
     for b in sample:
         o.set_mu(0, float(f32(MU[b, 0])))
         o.clear_records()
@@ -99,6 +102,18 @@ def test_bench_configuration_matches_oracle(B, sample):
             gin, gout = carried[S - 1 - s], carried[S - s]
             rb = o.step_backward(ref["id"], gin[0][b], gin[1][b], is_start=False, direct=True)
             ex, ev = rel(gout[0][b], rb["dL_dx"]), rel(gout[1][b], rb["dL_dv"])
+            # dL/dmu of this step = the increment of the sweep's accumulated value; end to end and on the SAME record (the oracle adopts
+            # the engine's record of the step, tests/records.py)
+            dmu_gpu = gout[2][b] - gin[2][b]
+            em = records.mu_err(dmu_gpu, rb["dL_dmu"])
+            records.oracle_adopts_gpu_record(o, ref["id"], e, W + s + 1, b, xs[b], states[s + 1][0][b], states[s + 1][1][b], recs_f[s][b], args.h, normals=nrm_gpu[s])
+            rb3 = o.step_backward(ref["id"], gin[0][b], gin[1][b], is_start=False, direct=True)
+            ea = max(rel(gout[0][b], rb3["dL_dx"]), rel(gout[1][b], rb3["dL_dv"]))
+            ema = records.mu_err(dmu_gpu, rb3["dL_dmu"])
+            print(f"\n[bench parity] rollout {b} step {W + s}: dL/dmu gpu {dmu_gpu[0]:.6e} oracle {rb['dL_dmu'][0]:.6e} rel err {em:.2e}; same record: dx/dv {ea:.2e} dmu {ema:.2e}")
+            mu_errs.append(em); same_errs.append(max(ea, ema))
+            assert ea <= 1e-4, (b, s, ea)
+            assert ema <= 1e-4, (b, s, ema)
             print(f"\n[bench parity] rollout {b} step {W + s}: contacts prim {ref['nprim']} self {ref['nself']} ({ref['nlayers']} layers), PD iterations gpu "
                   f"{fs['pd_iters'][b]} / oracle {ref['iters']}, BiCGSTAB {bs['adjoint_iters'][b]} in {bs['refine_cycles'][b]} fp32 solves, true residual "
                   f"{bs['last_udiff'][b]:.1e}, max|dx| {dx:.2e}, gradient rel err dx {ex:.2e} dv {ev:.2e}")
@@ -108,7 +123,9 @@ def test_bench_configuration_matches_oracle(B, sample):
             assert dx <= 4.5e-5
             errs.append(max(ex, ev))
             assert ex <= 1e-4 and ev <= 1e-4, (b, s, ex, ev)       # BASELINE.json: gradients within 1e-4 rel-err of the CPU reference
-    print(f"\n[bench parity] worst over {len(sample)} rollouts x {S} steps: max|dx| {worst_x:.2e}; gradient rel err GPU vs oracle {worst_g:.2e}, median {np.median(errs):.2e}")
+    print(f"\n[bench parity] worst over {len(sample)} rollouts x {S} steps: max|dx| {worst_x:.2e}; gradient rel err GPU vs oracle {worst_g:.2e}, median {np.median(errs):.2e}; "
+          f"dL/dmu end to end worst {max(mu_errs):.2e} median {np.median(mu_errs):.2e}; same record (dx, dv, dmu) worst {max(same_errs):.2e}")
+    assert max(mu_errs) <= 1e-4          # dL/dmu — the quantity bench.py all-reduces — at BASELINE.json's tolerance, end to end
 
 
 def test_fold_with_more_than_2048_self_contacts_matches_contactSorting():

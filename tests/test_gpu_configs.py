@@ -12,6 +12,7 @@ import pytest
 
 import meshes
 import orc
+import records
 import scenes
 from diffcloth_amd import capi
 
@@ -48,23 +49,27 @@ def settle(o, x, v, xf, steps, tol=1e-6):
     return f32(x), f32(v)
 
 
-def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, conditioning=False):
-    """One forward + backward step of the batch; the sampled rollouts against their own fp64 oracle run: contact sets identical,
-    positions within pos_tol, every gradient output within grad_tol (BASELINE.json: 1e-4) of the oracle's direct adjoint.
+def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, conditioning=False, h=None, same_record_tol=1e-4):
+    """One forward + backward step of the batch; the sampled rollouts against their own fp64 oracle run. Three statements per rollout:
 
-    conditioning=True (the hat scenes and the dress at 256 rollouts): the oracle also differentiates the step with ITS OWN x_new rounded to float32 — a
-    perturbation of 3e-8 relative, the precision the state crosses every boundary of the reference's Python callers with
-    (functional.py:30-34 casts to float32 tensors). Where that alone moves the reference's gradient by more than grad_tol the
-    adjoint matrix of the step is close to singular (sliding contacts next to the stick cone; BiCGSTAB needs its fp64 stage) and the
-    gradient is not defined to 1e-4 by the step's inputs. The gate of a rollout is max(1e-4, 3 x that sensitivity): the HIP path's
-    x_new differs from the oracle's by about as much as a float32 rounding does (max|dx| 2e-7 ... 7e-7, the PD iterate in fp32), in
-    another direction, so its effect on the gradient is of the same size, not the same number. Measured: pressed-on hat,
-    sensitivities 1.6e-4 ... 5e-2 on all six sampled rollouts, GPU-vs-oracle differences 4e-6 ... 8e-3, each BELOW its rollout's
-    sensitivity; dress, rollout 255 of 256: sensitivity 5.7e-5 (five times its neighbours'), difference 1.2e-4. The rollouts whose
-    sensitivity exceeds grad_tol are returned in st["ill_conditioned"]. Where the two PD loops stopped one iteration apart (hat, first
-    touch: ~1000 iterations at a contraction of 0.995, the stopping test within rounding of its threshold), the gradient is compared with
-    the oracle's loop stopped after the HIP path's number of iterations."""
+    (1) END TO END: contact sets identical, positions within pos_tol, every gradient output (dL_dx, dL_dv, dL_dxfixed, dL_dmu) within
+        grad_tol (BASELINE.json: 1e-4) of the oracle's direct adjoint of ITS OWN forward step.
+    (2) SAME RECORD, oracle side ("adoption"): the oracle takes over the engine's record of the step (x_new as the adjoint kernel
+        re-forms it, f, the contact normals: tests/records.py) and differentiates THAT — flat same_record_tol (1e-4), no rule.
+    (3) SAME RECORD, engine side ("teacher forcing"): the oracle's record is uploaded with dc_set_record and the engine differentiates
+        THAT — flat same_record_tol, no rule. (2) and (3) compare solutions of one linear system: they test the adjoint kernels.
+
+    conditioning=True (the hat scenes, the dress at 256 rollouts) relaxes (1) ONLY, and reports it as what it is — a statement about
+    the conditioning of the step, not about the kernels: the oracle also differentiates the step with ITS OWN x_new rounded to float32
+    (3e-8 relative, the precision the state crosses the reference's Python boundary with, functional.py:30-34). Where that alone moves
+    the reference's gradient by more than grad_tol, the adjoint matrix of the step is close to singular (sliding contacts next to the
+    stick cone) and the gradient is not defined to 1e-4 by the step's inputs; the end-to-end gate of such a rollout is
+    max(1e-4, min(3 x that sensitivity, 2e-2)). The HIP path's x_new differs from the oracle's by about as much as a float32 rounding
+    does (2e-7 ... 7e-7: the PD iterate in fp32), in another direction. Where the two PD loops stopped one iteration apart (hat, first
+    touch: ~1000 iterations at a contraction of 0.995), the end-to-end comparison is with the oracle's loop stopped after the HIP path's
+    number of iterations. Rollouts whose sensitivity exceeds grad_tol are returned in st["ill_conditioned"]."""
     B = len(X0)
+    h = float(o.params["h"]) if h is None else h
     e.alloc_batch(B, 1)
     if mus is not None:
         e.set_mu(mus)
@@ -75,69 +80,108 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
     gx = f32(rng.standard_normal(X0.shape)); gv = f32(rng.standard_normal(X0.shape) * 0.01)
     gb = e.step_backward(1, gx, gv, is_start=False)
     assert np.all(st["converged"] == 1) and np.all(gb["converged"] == 1)
-    worst = dict(dx=0.0, gx=0.0, gv=0.0, gf=0.0)
+    fr = e.get_record(1)
+    nrm_gpu = e.get_contacts(1)[1]
+    worst = dict(dx=0.0, gx=0.0, gv=0.0, gf=0.0, gm=0.0)
+    same = dict(adopt=0.0, forced=0.0)
     ill = []
     cond_worst = 0.0
     if os.environ.get("DC_DUMP_DIR"):          # the HIP path's tape of the sampled rollouts, for tests/analyze_dump.py
-        fr = e.get_record(1)
         os.makedirs(os.environ["DC_DUMP_DIR"], exist_ok=True)
         for b in sample:
             np.savez_compressed(os.path.join(os.environ["DC_DUMP_DIR"], f"cfg_B{B}_N{X0.shape[1] // 3}_b{b}.npz"), x0=X0[b], v0=V0[b],
                                 xf=(XF[b] if XF is not None else np.zeros(0)), x1=x1[b], v1=v1[b], f=fr[0][b], r=fr[1][b], gin_x=gx[b], gin_v=gv[b],
                                 gout_x=gb["dL_dx"][b], gout_v=gb["dL_dv"][b], mu=(mus[b, 0] if mus is not None else 0.0))
-    for b in sample:
+
+    def set_mus(b):
         if mus is not None:
             for g in range(mus.shape[1]):
                 o.set_mu(g, float(mus[b, g]))
+
+    def errs(g, b, r):
+        """rel errors (dx, dv, dxfixed, dmu) of the engine's outputs g for rollout row b against the oracle's r"""
+        ef = rel(g["dL_dxfixed"][b], r["dL_dxfixed"]) if XF is not None else 0.0
+        em = records.mu_err(g["dL_dmu"][b], r["dL_dmu"][:g["dL_dmu"].shape[1]]) if o.nprim > 0 else 0.0
+        return rel(g["dL_dx"][b], r["dL_dx"]), rel(g["dL_dv"][b], r["dL_dv"]), ef, em
+
+    recs, refs_b = [], []
+    for b in sample:
+        set_mus(b)
         ref = o.step(X0[b], V0[b], None if XF is None else XF[b])
         assert ref["converged"]
         assert st["prim_contacts"][b] == ref["nprim"] and st["self_contacts"][b] == ref["nself"]
         rb = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
+        assert 0 <= rb["direct_residual"] <= 1e-10, "the oracle's own direct solve must have converged"
+        recs.append(records.oracle_record(o, ref)); refs_b.append(rb)          # (before any override of the record)
         worst["dx"] = max(worst["dx"], np.abs(x1[b] - ref["x"]).max())
-        egx, egv = rel(gb["dL_dx"][b], rb["dL_dx"]), rel(gb["dL_dv"][b], rb["dL_dv"])
-        egf = rel(gb["dL_dxfixed"][b], rb["dL_dxfixed"]) if XF is not None else 0.0
+        egx, egv, egf, egm = errs(gb, b, rb)
         if conditioning and st["pd_iters"][b] != ref["iters"]:
             # the PD loop's stopping test (mean |dx| < fwd_tol) came out differently by one iteration — on the hat the map contracts at 0.995
-            # per iteration and the two sides sit within rounding of the threshold for several iterations. The statement that can be
-            # tested: the HIP path's gradient is that of the reference's loop stopped where the HIP path's stopped.
-            o.set(cap=int(st["pd_iters"][b])); o.build(); o.diagnostics(4)      # (4: the capped loop keeps its last iterate)
-            if mus is not None:
-                for g in range(mus.shape[1]):
-                    o.set_mu(g, float(mus[b, g]))
-            ref_same = o.step(X0[b], V0[b], None if XF is None else XF[b])
-            rb_same = o.step_backward(ref_same["id"], gx[b], gv[b], is_start=False, direct=True)
-            o.set(cap=-1); o.build(); o.diagnostics(0)
-            if mus is not None:
-                for g in range(mus.shape[1]):
-                    o.set_mu(g, float(mus[b, g]))
+            # per iteration and the two sides sit within rounding of the threshold for several iterations. The end-to-end statement that can
+            # be tested: the HIP path's gradient is that of the reference's loop stopped where the HIP path's stopped.
+            try:
+                o.set(cap=int(st["pd_iters"][b])); o.build(); o.diagnostics(4)      # (4: the capped loop keeps its last iterate)
+                set_mus(b)
+                ref_same = o.step(X0[b], V0[b], None if XF is None else XF[b])
+                rb_same = o.step_backward(ref_same["id"], gx[b], gv[b], is_start=False, direct=True)
+            finally:
+                o.set(cap=-1); o.build(); o.diagnostics(0)
+                set_mus(b)
+            e_same = errs(gb, b, rb_same)
             print(f"\n[config] rollout {b}: PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}: against the converged oracle dx {egx:.2e} dv {egv:.2e}; "
-                  f"against the oracle stopped after {st['pd_iters'][b]} iterations dx {rel(gb['dL_dx'][b], rb_same['dL_dx']):.2e} dv {rel(gb['dL_dv'][b], rb_same['dL_dv']):.2e}")
+                  f"against the oracle stopped after {st['pd_iters'][b]} iterations dx {e_same[0]:.2e} dv {e_same[1]:.2e}")
             assert abs(int(st["pd_iters"][b]) - int(ref["iters"])) <= 2
-            egx, egv = rel(gb["dL_dx"][b], rb_same["dL_dx"]), rel(gb["dL_dv"][b], rb_same["dL_dv"])
-            egf = rel(gb["dL_dxfixed"][b], rb_same["dL_dxfixed"]) if XF is not None else 0.0
+            egx, egv, egf, egm = e_same
+        gate_b = grad_tol
         if conditioning:
             o.override_record(ref["id"], x=f32(ref["x"]))
             rb2 = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
             sens = max(rel(rb2["dL_dx"], rb["dL_dx"]), rel(rb2["dL_dv"], rb["dL_dv"]))
-            print(f"\n[config] rollout {b}: the oracle's own gradient moves by {sens:.2e} when its x_new is rounded to float32")
-            gate_b = max(grad_tol, 3.0 * sens)
+            gate_b = max(grad_tol, min(3.0 * sens, 2e-2))
+            print(f"\n[config] rollout {b}: the oracle's own gradient moves by {sens:.2e} when its x_new is rounded to float32 (end-to-end gate {gate_b:.1e})")
             if sens > grad_tol:
                 ill.append(b)
+        # (2) the oracle differentiates the ENGINE's record
+        matched = records.oracle_adopts_gpu_record(o, ref["id"], e, 1, b, X0[b], x1[b], v1[b], fr[0][b], h, normals=nrm_gpu)
+        assert matched == ref["nself"]
+        rb3 = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
+        assert 0 <= rb3["direct_residual"] <= 1e-10
+        ea = errs(gb, b, rb3)
+        same["adopt"] = max(same["adopt"], *ea)
         print(f"\n[config] rollout {b}: PD iterations gpu {st['pd_iters'][b]} / oracle {ref['iters']}, contacts prim {ref['nprim']} self {ref['nself']}, "
-              f"BiCGSTAB {gb['adjoint_iters'][b]} in {gb['refine_cycles'][b]} fp32 solves (+ {gb['fp64_iters'][b]} fp64 iterations), true residual {gb['last_udiff'][b]:.1e}; "
-              f"gradient rel err dx {egx:.2e} dv {egv:.2e} dxfixed {egf:.2e}")
+              f"BiCGSTAB {gb['adjoint_iters'][b]} in {gb['refine_cycles'][b]} fp32 solves (+ {gb['fp64_iters'][b]} fp64 iterations), residual {gb['last_udiff'][b]:.1e} "
+              f"({'fp64-evaluated' if gb['residual_verified'][b] else 'bound'}); gradient rel err END TO END dx {egx:.2e} dv {egv:.2e} dxfixed {egf:.2e} dmu {egm:.2e} | "
+              f"SAME RECORD (oracle adopts the engine's) dx {ea[0]:.2e} dv {ea[1]:.2e} dxfixed {ea[2]:.2e} dmu {ea[3]:.2e}")
+        assert max(ea) <= same_record_tol, (b, ea)
         if conditioning:
-            assert max(egx, egv, egf) <= gate_b, (b, egx, egv, egf, gate_b)
-            cond_worst = max(cond_worst, egx, egv, egf)
+            assert max(egx, egv, egf, egm) <= gate_b, (b, egx, egv, egf, egm, gate_b)
+            cond_worst = max(cond_worst, egx, egv, egf, egm)
             continue                                # gated per rollout; the plain gate below is for the other tests
-        worst["gx"] = max(worst["gx"], egx); worst["gv"] = max(worst["gv"], egv); worst["gf"] = max(worst["gf"], egf)
+        worst["gx"] = max(worst["gx"], egx); worst["gv"] = max(worst["gv"], egv); worst["gf"] = max(worst["gf"], egf); worst["gm"] = max(worst["gm"], egm)
+    # (3) the engine differentiates the ORACLE's records (dc_set_record): a batch of the sampled rollouts
+    sl = list(sample)
+    e.alloc_batch(len(sl), 1)
+    if mus is not None:
+        e.set_mu(mus[sl])
+    e.set_state(0, X0[sl], V0[sl])
+    records.upload_oracle_records(e, 1, recs, x_fixed=None if XF is None else XF[sl])
+    gt = e.step_backward(1, gx[sl], gv[sl], is_start=False)
+    assert np.all(gt["converged"] == 1)
+    for k, b in enumerate(sl):
+        et = errs(gt, k, refs_b[k])
+        same["forced"] = max(same["forced"], *et)
+        print(f"\n[config] rollout {b}: TEACHER FORCED (the engine differentiates the oracle's record) dx {et[0]:.2e} dv {et[1]:.2e} dxfixed {et[2]:.2e} dmu {et[3]:.2e}; "
+              f"BiCGSTAB {gt['adjoint_iters'][k]} (+ {gt['fp64_iters'][k]} fp64), residual {gt['last_udiff'][k]:.1e}")
+        assert max(et) <= same_record_tol, (b, et)
     print(f"\n[config] B={B} sampled {list(sample)} pd iters {st['pd_iters'].min()}..{st['pd_iters'].max()} contacts prim "
           f"{st['prim_contacts'].min()}..{st['prim_contacts'].max()} self {st['self_contacts'].max()} | worst max|dx| {worst['dx']:.2e} "
-          f"grad rel err dx {worst['gx']:.2e} dv {worst['gv']:.2e} dxfixed {worst['gf']:.2e}"
-          + (f" | gated per rollout (conditioning rule): worst {cond_worst:.2e}" if conditioning else ""))
+          f"end-to-end grad rel err dx {worst['gx']:.2e} dv {worst['gv']:.2e} dxfixed {worst['gf']:.2e} dmu {worst['gm']:.2e}"
+          + (f" | end to end gated per rollout (conditioning report): worst {cond_worst:.2e}" if conditioning else "")
+          + f" | same record: oracle adopts {same['adopt']:.2e}, teacher forced {same['forced']:.2e} (gate {same_record_tol:.0e})")
     assert worst["dx"] <= pos_tol
-    assert worst["gx"] <= grad_tol and worst["gv"] <= grad_tol and worst["gf"] <= grad_tol
+    assert worst["gx"] <= grad_tol and worst["gv"] <= grad_tol and worst["gf"] <= grad_tol and worst["gm"] <= grad_tol
     st["ill_conditioned"] = ill
+    st["same_record"] = same
     return st
 
 
@@ -270,9 +314,11 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
     contact set, PD iteration count). Its adjoint system is beyond an fp32 Krylov solve (compressed fine sheets: cond(K) = 3e7, K
     indefinite — the fp32 BiCGSTAB diverges; the reference factorises it in fp64, solveDirect, Simulation.cpp:1431-1440): the engine
     must notice (no progress of the TRUE residual), switch to its fp64 BiCGSTAB on the same operator and return a CONVERGED solve
-    (round 2 returned converged = 0 here). What remains against the oracle's gradient sits in the ~20 vertices of the buckling
-    region where K is nearly singular (99 % of the difference; everywhere else <= 2e-3): there a 1e-9 difference of the forward
-    states moves the solution by percents, on either side."""
+    (round 2 returned converged = 0 here) — and the gradient must be the reference's to the flat 1e-4, end to end and on the same record.
+    The oracle side solves this system with a sparse LU of the explicit K, as the reference does (SparseLU): round 3 compared against
+    the oracle's restarted GMRES, which had silently stagnated at 1e-3 on this K (GMRES(80) x 40), read the 2e-2 ... 5e-2 difference as
+    ill-conditioning of the step and gated at 6e-2. With a converged reference (LU residual 2e-13; the GMRES run to 1.6e-12 agrees with it
+    to 1e-13) the engine's gradient is within 1.6e-5 / 3.3e-5 end to end."""
     V, F = scenes.load_mesh("dress7k")
     cfg = dict(h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
     P, rmin, rmax = scenes.normalise_model(V, "FRONT", 8.0)
@@ -306,7 +352,10 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
     assert dx <= 8e-5
     gx = f32(rng.standard_normal(x0.shape)); gv = f32(0.01 * rng.standard_normal(x0.shape))
     gb = e.step_backward(1, gx, gv, is_start=False)
-    rb = o.step_backward(ref["id"], gx[0], gv[0], is_start=False, direct=True)
+    # the oracle's adjoint system solved with a sparse LU (as the reference's solveDirect does: SparseLU) — its restarted GMRES needs
+    # thousands of products on this K (round 3 compared against a GMRES(80) x 40 that had stagnated, and blamed the conditioning)
+    rb = o.step_backward_lu(ref["id"], gx[0], gv[0], is_start=False)
+    assert rb["lu_residual"] <= 1e-10
     N = P.shape[0]
     d = (gb["dL_dx"][0] - rb["dL_dx"]).reshape(N, 3)
     per_vertex = np.sqrt((d ** 2).sum(axis=1))
@@ -320,4 +369,17 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
     assert gb["converged"][0] == 1 and gb["fp64_iters"][0] > 0          # solved — by the fp64 fall-back
     assert gb["last_udiff"][0] <= 1e-7                                   # the caller's tolerance (engine_for), on the residual evaluated in fp64
     assert np.isfinite(gb["dL_dx"]).all() and np.isfinite(gb["dL_dv"]).all()
-    assert rel(gb["dL_dx"][0], rb["dL_dx"]) <= 6e-2 and share >= 0.95 and err_rest <= 5e-3
+    assert rel(gb["dL_dx"][0], rb["dL_dx"]) <= 1e-4 and rel(gb["dL_dv"][0], rb["dL_dv"]) <= 1e-4 and rel(gb["dL_dxfixed"][0], rb["dL_dxfixed"]) <= 1e-4
+    rec = records.oracle_record(o, ref)                       # (before the adoption overrides the oracle's record)
+    fr = e.get_record(1)
+    matched = records.oracle_adopts_gpu_record(o, ref["id"], e, 1, 0, x0[0], x1[0], v1[0], fr[0][0], cfg["h"])
+    assert matched == ref["nself"]
+    rb3 = o.step_backward_lu(ref["id"], gx[0], gv[0], is_start=False)
+    ea = max(rel(gb["dL_dx"][0], rb3["dL_dx"]), rel(gb["dL_dv"][0], rb3["dL_dv"]), rel(gb["dL_dxfixed"][0], rb3["dL_dxfixed"]))
+    records.upload_oracle_records(e, 1, [rec], x_fixed=xf)
+    gt = e.step_backward(1, gx, gv, is_start=False)
+    et = max(rel(gt["dL_dx"][0], rb["dL_dx"]), rel(gt["dL_dv"][0], rb["dL_dv"]), rel(gt["dL_dxfixed"][0], rb["dL_dxfixed"]))
+    print(f"[dress 7742] SAME RECORD: the oracle differentiates the engine's record {ea:.2e}; the engine differentiates the oracle's (dc_set_record) {et:.2e} "
+          f"(fp64 fall-back {gt['fp64_iters'][0]} iterations, residual {gt['last_udiff'][0]:.1e})")
+    assert gt["converged"][0] == 1
+    assert ea <= 1e-4 and et <= 1e-4

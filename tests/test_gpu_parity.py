@@ -11,6 +11,7 @@ import pytest
 
 import meshes
 import orc
+import records
 from diffcloth_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -138,13 +139,32 @@ def test_backward_step_matches_oracle(mu):
         return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
     ex, ev = rel(gb["dL_dx"][0], rb["dL_dx"]), rel(gb["dL_dv"][0], rb["dL_dv"])
     ef = rel(gb["dL_dxfixed"][0], rb["dL_dxfixed"])
-    em = abs(gb["dL_dmu"][0, 0] - rb["dL_dmu"][0]) / max(abs(rb["dL_dmu"][0]), 1e-12)
+    em = records.mu_err(gb["dL_dmu"][0], rb["dL_dmu"])
     types = o.prim_contacts(ref["id"])["type"]
+    # dL/dmu = h sum over the SLIDING contacts of -|d_n| (d_T / |d_T|) . u* (Simulation.cpp:1622-1632, 865-879): the direction of the small
+    # tangential part d_T of the recorded contact vector enters, so the sum is far more sensitive to the forward record than dL_dx — measured
+    # by letting the oracle differentiate its own record with x_new rounded to float32 (sens) — while on the SAME record the two sides agree:
+    rec = records.oracle_record(o, ref)
+    o.override_record(ref["id"], x=f32(ref["x"]))
+    sens = records.mu_err(o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)["dL_dmu"], rb["dL_dmu"])
+    x1, v1 = e.get_state(1)
+    records.oracle_adopts_gpu_record(o, ref["id"], e, 1, 0, x0, x1[0], v1[0], e.get_record(1)[0][0], 1 / 180)
+    rb3 = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    em_adopt = records.mu_err(gb["dL_dmu"][0], rb3["dL_dmu"])
+    ex_adopt = max(rel(gb["dL_dx"][0], rb3["dL_dx"]), rel(gb["dL_dv"][0], rb3["dL_dv"]))
+    records.upload_oracle_records(e, 1, [rec], x_fixed=xf)
+    gt = e.step_backward(1, gx, gv, is_start=False)
+    em_forced = records.mu_err(gt["dL_dmu"][0], rb["dL_dmu"])
+    ex_forced = max(rel(gt["dL_dx"][0], rb["dL_dx"]), rel(gt["dL_dv"][0], rb["dL_dv"]))
     print(f"\n[bwd mu={mu}] adjoint iters {gb['adjoint_iters'][0]} cg {gb['cg_iters'][0]} rel err dx {ex:.2e} dv {ev:.2e} dxfixed {ef:.2e} dmu {em:.2e}"
-          f" (stick {np.sum(types == 1)}, slide {np.sum(types == 2)}, takeoff {np.sum(types == 0)})")
+          f" (stick {np.sum(types == 1)}, slide {np.sum(types == 2)}, takeoff {np.sum(types == 0)}); dL/dmu gpu {gb['dL_dmu'][0, 0]:.6e} oracle {rb['dL_dmu'][0]:.6e}; "
+          f"same record: oracle adopts dmu {em_adopt:.2e} dx {ex_adopt:.2e}, teacher forced dmu {em_forced:.2e} dx {ex_forced:.2e}; "
+          f"the oracle's own dL/dmu moves by {sens:.2e} under a float32 rounding of its x_new")
     assert ex <= GRAD_TOL and ev <= GRAD_TOL and ef <= GRAD_TOL
-    if abs(rb["dL_dmu"][0]) > 1e-8:
-        assert em <= 5e-3      # a signed sum over the sliding contacts: cancellation amplifies fp32 rounding
+    assert max(em_adopt, ex_adopt, em_forced, ex_forced) <= GRAD_TOL          # the adjoint kernels, on one and the same record
+    sens_stop = records.stopping_sensitivity(o, x0, v0, xf, ref["iters"], gx, gv, rb)
+    print(f"[bwd mu={mu}] ... and by {sens_stop:.2e} when its PD loop runs one iteration past its stopping rule ({ref['iters']} iterations)")
+    assert em <= max(GRAD_TOL, min(3 * max(sens, sens_stop), 5e-3))           # end to end: within the record's own conditioning
 
 
 def test_batch_of_rollouts_each_matches_its_own_oracle_run():
@@ -255,8 +275,23 @@ def test_direct_adjoint_solve_matches_oracle(mu):
     def rel(a, b):
         return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
     ex, ev, ef = rel(gb["dL_dx"][0], rb["dL_dx"]), rel(gb["dL_dv"][0], rb["dL_dv"]), rel(gb["dL_dxfixed"][0], rb["dL_dxfixed"])
-    print(f"\n[direct adjoint mu={mu}] bicgstab iters {gb['adjoint_iters'][0]} rel res {gb['last_udiff'][0]:.1e} rel err dx {ex:.2e} dv {ev:.2e} dxfixed {ef:.2e}")
+    em = records.mu_err(gb["dL_dmu"][0], rb["dL_dmu"])
+    # dL/dmu: same record on both sides at the flat gate, end to end within the record's own conditioning (test_backward_step_matches_oracle)
+    rec = records.oracle_record(o, ref)
+    o.override_record(ref["id"], x=f32(ref["x"]))
+    sens = records.mu_err(o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)["dL_dmu"], rb["dL_dmu"])
+    x1, v1 = e.get_state(1)
+    records.oracle_adopts_gpu_record(o, ref["id"], e, 1, 0, x0, x1[0], v1[0], e.get_record(1)[0][0], 1 / 180)
+    rb3 = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    ea = max(rel(gb["dL_dx"][0], rb3["dL_dx"]), rel(gb["dL_dv"][0], rb3["dL_dv"]), rel(gb["dL_dxfixed"][0], rb3["dL_dxfixed"]), records.mu_err(gb["dL_dmu"][0], rb3["dL_dmu"]))
+    records.upload_oracle_records(e, 1, [rec], x_fixed=xf)
+    gt = e.step_backward(1, gx, gv, is_start=False)
+    et = max(rel(gt["dL_dx"][0], rb["dL_dx"]), rel(gt["dL_dv"][0], rb["dL_dv"]), rel(gt["dL_dxfixed"][0], rb["dL_dxfixed"]), records.mu_err(gt["dL_dmu"][0], rb["dL_dmu"]))
+    print(f"\n[direct adjoint mu={mu}] bicgstab iters {gb['adjoint_iters'][0]} rel res {gb['last_udiff'][0]:.1e} rel err dx {ex:.2e} dv {ev:.2e} dxfixed {ef:.2e} dmu {em:.2e} "
+          f"(oracle's own float32-x_new sensitivity of dL/dmu {sens:.2e}); same record: oracle adopts {ea:.2e}, teacher forced {et:.2e}")
     assert ex <= GRAD_TOL and ev <= GRAD_TOL and ef <= GRAD_TOL
+    assert ea <= GRAD_TOL and et <= GRAD_TOL
+    assert em <= max(GRAD_TOL, min(3 * sens, 5e-3))
 
 
 def test_free_running_tshirt_rollout_tracks_the_reference_golden_frames():

@@ -7,6 +7,7 @@ import pytest
 
 import meshes
 import orc
+import records
 from diffcloth_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -89,19 +90,28 @@ def test_random_scene_step_matches_oracle(seed):
           f"adjoint its {gb['adjoint_iters'][0]} status {gb['converged'][0]}")
     assert dx <= 5e-5 * max(dim / 4.5, 1.0)
     assert np.array_equal(x1[0], x1[1]) and np.array_equal(gb["dL_dx"][0], gb["dL_dx"][1])       # the two slots got the same input
-    # Slowly converging (stiff, ~1000 PD iterations at a contraction of 0.99) scenes stop a few iterations apart on the two
-    # sides: positions differ by ~2e-6 and, through the moved linearisation point, the gradients by up to 1e-3 (the hat scene
-    # of test_gpu_configs.py shows the same); where both sides stop at the same point the 1e-4-level bound holds.
-    gtol = 3e-4 if dx <= 1e-6 else 2e-3
-    # Contacts within 1e-4 of a switching surface of the friction law (take-off / stick / slide) can land on the other side
-    # of it in fp32: the step is not differentiable there and the two gradients then belong to different branches (seen:
-    # one of 334 contacts classified differently, 5 % gradient difference). Those draws only check the forward step.
+    # END TO END the flat 1e-4 gate holds wherever the two PD loops stopped after the same number of iterations and no contact sits on a
+    # switching surface of the friction law. Slowly converging draws (stiff, ~1000 PD iterations at a contraction of 0.99) can stop a few
+    # iterations apart: positions then differ by ~2e-6 and, through the moved linearisation point, the gradients by up to 1e-3 (the hat
+    # scene of test_gpu_configs.py shows the same). Contacts within 1e-4 of a switching surface (take-off / stick / slide) can land on
+    # the other side of it in fp32: the step is not differentiable there and the two gradients belong to different branches (seen: one of
+    # 334 contacts classified differently, 5 % gradient difference). Those draws REPORT the end-to-end difference; what is gated on EVERY
+    # draw is the adjoint on one and the same record (the oracle adopts the engine's, tests/records.py) — flat 1e-4.
     con = o.prim_contacts(ref["id"])
     fo, _ = o.record_fr(ref["id"])
     near = 0
     for k, i in enumerate(con["particle"]):
         n = con["normal"][k]; d = fo[3 * i:3 * i + 3]; sd = d @ n; dT = d - sd * n; nd = max(np.linalg.norm(d), 1e-30)
         near += abs(np.linalg.norm(dT) - mu * abs(sd)) / nd < 1e-4 or abs(sd) / nd < 1e-4
-    if near:
-        gtol = 0.2
-    assert ex <= gtol and ev <= gtol
+    same_stop = int(st["pd_iters"][0]) == int(ref["iters"])
+    matched = records.oracle_adopts_gpu_record(o, ref["id"], e, 1, 0, x, x1[0], v1[0], e.get_record(1)[0][0], h)
+    assert matched == ref["nself"]
+    rb3 = o.step_backward(ref["id"], gx, gv, is_start=False, direct=True)
+    ea = max(rel(gb["dL_dx"][0], rb3["dL_dx"]), rel(gb["dL_dv"][0], rb3["dL_dv"]))
+    print(f"[random scene {seed}] same record (oracle adopts the engine's): {ea:.1e}; end to end {'GATED 1e-4' if same_stop and not near else 'reported'} "
+          f"(same PD stop {same_stop}, contacts near a switching surface {near})")
+    assert ea <= 1e-4
+    if same_stop and not near:
+        assert ex <= 1e-4 and ev <= 1e-4
+    else:
+        assert ex <= 0.2 and ev <= 0.2          # sanity only: a different branch / stopping point, not a different algorithm
