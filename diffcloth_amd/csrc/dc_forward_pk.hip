@@ -42,16 +42,26 @@ namespace dc {
 // DETECT: the self-collision detection + layering of every step is inlined (fused sweeps with self-collision). It is a
 // template parameter, not a run-time branch: the mere presence of that code in the kernel changes the register allocation
 // of the PCG loop (SpMV 21 k -> 29 k cycles), which runs without it must not pay for.
-template <int THREADS, int VPT, int XL, bool DETECT, bool DENSE>
+// H16: the search direction lives in LDS as four halves per row (x, y, z, unused) scaled by a power of two per iteration: one ds_read_b64
+// per non-zero instead of a b64 + a b32, 8 instead of 12 bytes per row — the LDS this frees holds more rows of the iterate (XL), i.e. fewer
+// registers. CG does not need an exact direction, only consistency: the step length is the exact line search along the direction actually
+// used, alpha = <d, r> / <d, A d>, and r, x are updated with that same d, so r stays the residual of x (fp32, as before) and the stopping
+// rule is unchanged; the rounding of d (2^-11 relative) costs a little conjugacy, nothing else. Needs the element windows (S.win_ok).
+template <int THREADS, int VPT, int XL, bool DETECT, bool DENSE, bool H16>
 __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
+  static_assert(!(H16 && DENSE), "the explicit-inverse solve keeps the fp32 planes");
   const DevSystem &S = *Sp;
   constexpr int NP = THREADS * VPT;
   constexpr int WAVES = THREADS / 64;
   constexpr int XR = VPT - XL;
-  extern __shared__ float lp[];          // search direction: float2 (x, y) [NP] then float z [NP]; then x rows [XL][3][THREADS]
-  float *lx = lp + 3 * NP;
+  constexpr int PF = H16 ? 2 : 3;        // floats per row of the search direction in LDS
+  extern __shared__ float lp[];          // search direction: float2 (x, y) [NP] then float z [NP] (H16: h4 [NP]); then x rows [XL][3][THREADS]
+  float *lx = lp + PF * NP;
+  h4 *lh = (h4 *) lp;
+  const unsigned lh_addr = lds_byte_address(lp);
   float *ldense = lp + 3 * THREADS * (VPT + XL);      // DENSE: partial sums of the product with the explicit inverse
   __shared__ double red[THREADS / 64];
+  __shared__ double red2[H16 ? 2 * (THREADS / 64) : 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = S.N, T = S.T, E = S.E, NC = S.NC;
@@ -110,6 +120,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   bool improved = false, converged = false, stalled = false, best_is_current = false;
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
+  float dnorm = 0.f;                        // H16: |d_prev|_2, the scaled correction of the previous PD iteration
 
   PH_DECL
   for (int iter = 0; iter < A.pd_cap; iter++) {
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           part = 0.f;
         }
       }
+      if constexpr (!H16) {
       for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread (clamped index), then the LDS stores
         float t[4][3];
 #pragma unroll
@@ -185,6 +197,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
             if (self_done) part += dot(mk(t[j][0], t[j][1], t[j][2]), mk(t[j][0], t[j][1], t[j][2]));
           }
         }
+      }
       }
     } else {
       // ---- local step: per-element projection residual, written per constraint corner (global memory) ----
@@ -229,29 +242,59 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       for (int i = tid; i < NP; i += THREADS) {
         f3 rhs = mk(0, 0, 0);
         if (i < N) rhs = (ld3(rec_f, i, N) + ld3(rec_r, i, N) - ld3(vnow, i, N) * S.mass[i]) * S.sq_dinv[i];
-        ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z;
+        if constexpr (H16) { if (i < N) st3(W.cg_r + off, i, N, rhs); }
+        else { ((float2 *) lp)[i] = make_float2(rhs.x, rhs.y); lp[2 * NP + i] = rhs.z; }
         part += dot(rhs, rhs);
+      }
+      if constexpr (H16) __syncthreads();
+    }
+    // residual, A p and (most of) the iterate of the scaled CG live in registers from here to the update
+    float rr[VPT][3], ap[VPT][3], xx[XR > 0 ? XR : 1][3];
+    if constexpr (H16) {      // the right-hand side goes from the work array straight into the residual registers
+      const float *scr = W.cg_r + off;
+      part = 0.f;
+#pragma unroll
+      for (int k0 = 0; k0 < VPT; k0 += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (k0 + j < VPT) {
+            const int k = k0 + j, i = tq + k * THREADS, ic = min(i, N - 1);
+            const float ok = (i < N) ? 1.f : 0.f;
+            rr[k][0] = scr[ic] * ok; rr[k][1] = scr[N + ic] * ok; rr[k][2] = scr[2 * N + ic] * ok;
+            part = fmaf(rr[k][0], rr[k][0], fmaf(rr[k][1], rr[k][1], fmaf(rr[k][2], rr[k][2], part)));
+          }
+        }
       }
     }
     double rz = block_sum<THREADS>((double) part, red);
-    // residual, A p and (most of) the iterate of the scaled CG live in registers from here to the update
-    float rr[VPT][3], ap[VPT][3], xx[XR > 0 ? XR : 1][3];
+    float hs = 1.f, pn = 0.f;               // H16: scale of the direction in LDS (a power of two) and the bound on its entries it comes from
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
       const int i = tq + k * THREADS;
-      const float2 q = ((const float2 *) lp)[i];
-      rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = lp[2 * NP + i];
+      if constexpr (!H16) {
+        const float2 q = ((const float2 *) lp)[i];
+        rr[k][0] = q.x; rr[k][1] = q.y; rr[k][2] = lp[2 * NP + i];
+      }
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         if (k < XR) xx[k < XR ? k : 0][c] = 0.f;
         else lx[((k - XR) * 3 + c) * THREADS + tq] = 0.f;
       }
     }
+    if constexpr (H16) {                    // first direction d = r (|r|_inf <= |r|_2 = sqrt(rz)), rounded to halves
+      pn = sqrtf((float) rz); hs = half_scale(pn);
+#pragma unroll
+      for (int k = 0; k < VPT; k++) lh[tq + k * THREADS] = pack_h4(rr[k][0] * hs, rr[k][1] * hs, rr[k][2] * hs);
+    }
     PH(1)
     // ap = Ahat * (the vector in lp), part2 += <lp, ap>; rows of a thread tid + k * THREADS
     auto spmv = [&](int wz, float &part2, bool with_pr, float &part3) {
       int4 nxt[PB];
       load_batch(nxt, S.pk + S.pk_ptr[wz] + lane, 0);
+#ifdef DC_PK_PF2      // packets of the row after next in flight as well (two rows = 8 KB per wave outstanding)
+      int4 nx2[PB];
+      if (VPT > 1) load_batch(nx2, S.pk + S.pk_ptr[wz + WAVES] + lane, 0);
+#endif
 #pragma unroll
       for (int k = 0; k < VPT; k++) {
         const int chunk = wz + k * WAVES;   // wave-uniform: pk_ptr / pk_n are scalar loads
@@ -261,19 +304,28 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         int4 cur[PB];
 #pragma unroll
         for (int j = 0; j < PB; j++) cur[j] = nxt[j];
+#ifdef DC_PK_PF2
+#pragma unroll
+        for (int j = 0; j < PB; j++) nxt[j] = nx2[j];
+        if (k + 2 < VPT) load_batch(nx2, S.pk + S.pk_ptr[chunk + 2 * WAVES] + lane, 0);
+#else
         if (k + 1 < VPT) load_batch(nxt, S.pk + S.pk_ptr[chunk + WAVES] + lane, 0);
-        const float2 pxy = ((const float2 *) lp)[i];
-        const float pz = lp[2 * NP + i];
+#endif
+        float2 pxy; float pz;
+        if constexpr (H16) { const h4 q = lh[i]; pxy = make_float2((float) q.x, (float) q.y); pz = (float) q.z; }
+        else { pxy = ((const float2 *) lp)[i]; pz = lp[2 * NP + i]; }
         float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
         const int base = i - 512;
-        consume<NP>(cur, lp, base, ax, ay, az);
+        unsigned rowbase = lh_addr + 8u * (unsigned) base;
+        asm volatile("" : "+v"(rowbase));      // opaque: one register per row, not (row + delta) * 8 + LDS base per non-zero
+        if constexpr (H16) consume_h(cur, rowbase, ax, ay, az); else consume<NP>(cur, lp, base, ax, ay, az);
         for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
           load_batch(cur, row, s0);
-          consume<NP>(cur, lp, base, ax, ay, az);
+          if constexpr (H16) consume_h(cur, rowbase, ax, ay, az); else consume<NP>(cur, lp, base, ax, ay, az);
         }
         ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
         part2 += pxy.x * ax + pxy.y * ay + pz * az;
-        if (with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];      // seeded pass only (uniform branch)
+        if (H16 || with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];      // fp32 planes: seeded pass only (uniform branch)
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -325,11 +377,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       // and the relative stopping rule (against the right-hand side) is met several iterations earlier.
       bool seed = A.cg_seed && iter > 0;
       if (seed) {
+        if constexpr (H16) hs = half_scale(dnorm);      // |d_prev|_2 from the update loop of the previous PD iteration
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
           const int i = tq + k * THREADS, ic = min(i, N - 1);
           const float okf = i < N ? 1.f : 0.f;
-          ((float2 *) lp)[i] = make_float2(dprev[ic] * okf, dprev[N + ic] * okf); lp[2 * NP + i] = dprev[2 * N + ic] * okf;
+          if constexpr (H16) lh[i] = pack_h4(dprev[ic] * (okf * hs), dprev[N + ic] * (okf * hs), dprev[2 * N + ic] * (okf * hs));
+          else { ((float2 *) lp)[i] = make_float2(dprev[ic] * okf, dprev[N + ic] * okf); lp[2 * NP + i] = dprev[2 * N + ic] * okf; }
         }
       }
       for (int it = 0; it < A.cg_max;) {
@@ -340,17 +394,21 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         const int wz = wv + zs, tz = tid + zs;
         spmv(wz, part2, seed, part3);
         PH(2)
-        const double pAp = block_sum_f<THREADS>(part2, red);
-        double pr = rz;
-        if (seed) pr = block_sum_f<THREADS>(part3, red);
+        double pAp, pr = rz;
+        if constexpr (H16) block_sum2_f<THREADS>(part2, part3, red2, pAp, pr);      // exact line search along the rounded direction
+        else {
+          pAp = block_sum_f<THREADS>(part2, red);
+          if (seed) pr = block_sum_f<THREADS>(part3, red);
+        }
         PH(3)
         const float alpha = pAp > 1e-300 ? (float) (pr / pAp) : 0.f;
         part2 = 0.f;
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
           const int i = tz + k * THREADS;
-          const float2 pxy = ((const float2 *) lp)[i];
-          const float pv[3] = {pxy.x, pxy.y, lp[2 * NP + i]};
+          float pv[3];
+          if constexpr (H16) { const h4 q = lh[i]; pv[0] = (float) q.x; pv[1] = (float) q.y; pv[2] = (float) q.z; }
+          else { const float2 pxy = ((const float2 *) lp)[i]; pv[0] = pxy.x; pv[1] = pxy.y; pv[2] = lp[2 * NP + i]; }
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             if (k < XR) xx[k < XR ? k : 0][c] = fmaf(alpha, pv[c], xx[k < XR ? k : 0][c]);
@@ -365,12 +423,25 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         const float beta = seed ? 0.f : (float) (rz_new / rz);
         seed = false;
         rz = rz_new;
+        if constexpr (H16) {
+          // d_new = r + beta d_old in true units; in LDS units: hs_new r + (beta hs_new / hs_old) d~_old, entries bounded by |r|_2 + beta * bound_old
+          pn = sqrtf((float) rz_new) + beta * pn;
+          const float hs_new = half_scale(pn), c2 = beta * hs_new / hs;
+          hs = hs_new;
+#pragma unroll
+          for (int k = 0; k < VPT; k++) {
+            const int i = tz + k * THREADS;
+            const h4 q = lh[i];
+            lh[i] = pack_h4(fmaf(c2, (float) q.x, rr[k][0] * hs), fmaf(c2, (float) q.y, rr[k][1] * hs), fmaf(c2, (float) q.z, rr[k][2] * hs));
+          }
+        } else {
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
           const int i = tz + k * THREADS;
           const float2 pxy = ((const float2 *) lp)[i];
           ((float2 *) lp)[i] = make_float2(fmaf(beta, pxy.x, rr[k][0]), fmaf(beta, pxy.y, rr[k][1]));
           lp[2 * NP + i] = fmaf(beta, lp[2 * NP + i], rr[k][2]);
+        }
         }
         PH(4)
       }
@@ -379,6 +450,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     // rows in groups of 4: loads (clamped index, no divergence), arithmetic, stores; delta v replaces A p in its
     // registers and stays there for the best-iterate bookkeeping below
     part = 0.f;
+    float partd = 0.f;
 #pragma unroll
     for (int k0 = 0; k0 < VPT; k0 += 4) {
       float vq[4][3], sq[4];
@@ -400,12 +472,18 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           for (int c = 0; c < 3; c++) {
             const float xs = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tq];
             ap[k][c] = xs * sq[j];             // delta v (A p is dead here)
-            if (i < N) { vnow[c * N + i] = vq[j][c] + ap[k][c]; part = fmaf(ap[k][c], ap[k][c], part); if (A.cg_seed) dprev[c * N + i] = xs; }
+            if (i < N) { vnow[c * N + i] = vq[j][c] + ap[k][c]; part = fmaf(ap[k][c], ap[k][c], part); if (A.cg_seed) dprev[c * N + i] = xs; if constexpr (H16) partd = fmaf(xs, xs, partd); }
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (H16) {
+      double sp, sd;
+      block_sum2_f<THREADS>(part, partd, red2, sp, sd);
+      xdiff = (double) h * sqrt(sp) / (double) N;
+      dnorm = sqrtf((float) sd);
+    } else
     xdiff = (double) h * sqrt(block_sum<THREADS>((double) part, red)) / (double) N;
     PH(5)
     iters = iter + 1;
@@ -446,9 +524,9 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   }   // step
 }
 
-template <int THREADS, int VPT, int XL, bool DETECT, bool DENSE>
+template <int THREADS, int VPT, int XL, bool DETECT, bool DENSE, bool H16 = false>
 static void launch_pk_inst(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
-  size_t lds = (size_t) 3 * THREADS * (VPT + XL) * sizeof(float);
+  size_t lds = (size_t) THREADS * ((H16 ? 2 : 3) * VPT + 3 * XL) * sizeof(float);
   if (DENSE) lds += sizeof(float) * (size_t) dense_lds_floats(S.dense_ld, THREADS / 64);
   if (S.win_ok) lds = std::max(lds, (size_t) S.win_lds_bytes);
   if (A.inline_detect) lds = std::max(lds, sizeof(int) * (size_t) kSelfDetectLdsInts);
@@ -457,10 +535,10 @@ static void launch_pk_inst(const DevSystem &S, const DevWork &W, const FwdArgs &
   (void) hipGetDevice(&dev);
   size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
   if (lds > done || dev >= kMaxDevices) {
-    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute((const void *) k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     done = lds;
   }
-  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_pd_step_pk<THREADS, VPT, XL, DETECT, DENSE, H16>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
 
 template <int THREADS, int VPT, int XL>
@@ -475,10 +553,23 @@ static void launch_pk(const DevSystem &S, const DevWork &W, const FwdArgs &A, in
   if (A.inline_detect) launch_pk_inst<THREADS, VPT, XL, true, false>(S, W, A, B, st);
   else launch_pk_inst<THREADS, VPT, XL, false, false>(S, W, A, B, st);
 }
+// the half-precision-direction variant (needs the element windows): XL = rows of the iterate in the LDS the 8-byte direction rows free
+template <int THREADS, int VPT, int XL>
+static void launch_pk_h16(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
+  if (A.inline_detect) launch_pk_inst<THREADS, VPT, XL, true, false, true>(S, W, A, B, st);
+  else launch_pk_inst<THREADS, VPT, XL, false, false, true>(S, W, A, B, st);
+}
 
-// 512 threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).
+// 512 (or 768) threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).
 bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   if (!S.pk_ok) return false;
+  static const int h16 = getenv("DC_PK_H16") ? atoi(getenv("DC_PK_H16")) : 1;      // (development switch: 0 = the fp32 direction planes)
+  if (S.pk_threads == 768) {
+    if (S.pk_vpt != 14) return false;
+    if (h16 && S.win_ok) launch_pk_h16<768, 14, 7>(S, W, A, B, st);
+    else launch_pk<768, 14, 3>(S, W, A, B, st);
+    return true;
+  }
 #ifdef DC_PK_ONLY20      // development builds: only the 10 000-vertex variant (compile time)
   if (S.pk_vpt != 20) return false;
   launch_pk<512, 20, 6>(S, W, A, B, st);
@@ -494,7 +585,10 @@ bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &
     case 10: launch_pk<512, 10, 0>(S, W, A, B, st); break;
     case 12: launch_pk<512, 12, 0>(S, W, A, B, st); break;
     case 16: launch_pk<512, 16, 2>(S, W, A, B, st); break;
-    case 20: launch_pk<512, 20, 6>(S, W, A, B, st); break;
+    case 20:
+      if (h16 && S.win_ok) launch_pk_h16<512, 20, 12>(S, W, A, B, st);
+      else launch_pk<512, 20, 6>(S, W, A, B, st);
+      break;
     default: return false;
   }
   return true;

@@ -6,6 +6,8 @@
 
 namespace dc {
 
+static const bool kDefault768 = false;      // (measured default)
+
 bool HostPackets::build(const HostSystem &H) {
   static const int allowed[] = {1, 2, 3, 4, 6, 8, 10, 12, 16, 20};      // instantiated rows-per-thread of k_pd_step_pk
   const int need = (H.N + 511) / 512;
@@ -16,6 +18,15 @@ bool HostPackets::build(const HostSystem &H) {
     for (int r = 0; r < H.N; r++)
       for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++) bandwidth = std::max(bandwidth, std::abs(H.P_col[k] - r));
     return false;
+  }
+  // meshes of 9 217 ... 10 752 rows: 768 threads x 14 rows (12 waves = 3 per SIMD at 168 registers) instead of 512 x 20 (2 per SIMD):
+  // the resident PCG and the element windows are latency-bound, a third wave per SIMD hides more of it (DC_PK_THREADS=512 / 768 forces)
+  static const char *envt = getenv("DC_PK_THREADS");
+  const bool want768 = envt ? atoi(envt) == 768 : kDefault768;
+  if (want768 && H.N > 768 * 12 && H.N <= 768 * 14) {
+    if (!build_rows(H, 768 * 14)) return false;
+    vpt = 14; threads = 768;
+    return true;
   }
   if (!build_rows(H, 512 * v)) return false;
   vpt = v;

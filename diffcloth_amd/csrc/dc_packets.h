@@ -11,7 +11,8 @@ namespace dc {
 
 struct HostPackets {
   bool ok = false;
-  int vpt = 0;                    // rows per thread of the 512-thread kernel the tables are padded for (512 * vpt rows)
+  int vpt = 0;                    // rows per thread of the kernel the tables are padded for (threads * vpt rows)
+  int threads = 512;              // threads of that kernel: 512, or 768 for the largest meshes (3 waves per SIMD, dc_forward_pk.hip)
   int bandwidth = 0;              // max |column - row| of P
   std::vector<int> pk;            // 4 ints per packet
   std::vector<int> pk_ptr, pk_n;  // per 64-row chunk

@@ -57,6 +57,75 @@ __device__ __forceinline__ void consume_p(const int4 (&e)[PB], const float2 *lxy
     ax = fmaf(a2, q2.x, ax); ay = fmaf(a2, q2.y, ay); az = fmaf(a2, z2, az);
   }
 }
+// The same with the search direction held as four halves per row (x, y, z, unused: 8 bytes, ONE ds_read_b64 per non-zero instead of a
+// b64 + a b32, and a third less LDS): the products are v_fma_mix_f32 (half operand converted inside the FMA).
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// (v_fma_mix_f32 written out: left to itself the compiler converts x and y with two v_cvt_f32_f16 and pairs them in a v_pk_fma_f32 —
+// 7.5 instructions per non-zero where this is 6: bit-field extract, shift-add onto the row's LDS byte address, ds_read_b64, three FMAs
+// that take the half operand as it is)
+__device__ __forceinline__ void fma3_h(float a, int lo, int hi, float &ax, float &ay, float &az) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(ax) : "v"(a), "v"(lo));
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(ay) : "v"(a), "v"(lo));
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(az) : "v"(a), "v"(hi));
+}
+typedef int pk_v2i __attribute__((ext_vector_type(2)));
+typedef const pk_v2i __attribute__((address_space(3))) *lds_int2p;
+// rowbase = LDS byte address of the direction's row (i - 512): column c of the row's packets sits at rowbase + 8 (c - i + 512)
+__device__ __forceinline__ void consume_h(const int4 (&e)[PB], unsigned rowbase, float &ax, float &ay, float &az) {
+  // all gathers of the batch are issued before the first product: 12 ds_read_b64 in flight (24 registers) instead of 3
+  pk_v2i q[PB][3];
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    const unsigned w = (unsigned) e[j].w;
+    unsigned d0, d1, d2;      // (opaque extracts: the compiler otherwise rewrites extract-and-scale as shift + mask and needs a third instruction to add)
+    asm("v_bfe_u32 %0, %1, 0, 10" : "=v"(d0) : "v"(w));
+    asm("v_bfe_u32 %0, %1, 10, 10" : "=v"(d1) : "v"(w));
+    asm("v_bfe_u32 %0, %1, 20, 10" : "=v"(d2) : "v"(w));
+    q[j][0] = *(lds_int2p) (size_t) (rowbase + (d0 << 3));
+    q[j][1] = *(lds_int2p) (size_t) (rowbase + (d1 << 3));
+    q[j][2] = *(lds_int2p) (size_t) (rowbase + (d2 << 3));
+  }
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    fma3_h(__int_as_float(e[j].x), q[j][0].x, q[j][0].y, ax, ay, az);
+    fma3_h(__int_as_float(e[j].y), q[j][1].x, q[j][1].y, ax, ay, az);
+    fma3_h(__int_as_float(e[j].z), q[j][2].x, q[j][2].y, ax, ay, az);
+  }
+}
+__device__ __forceinline__ unsigned lds_byte_address(const void *p) {
+  return (unsigned) (size_t) (const __attribute__((address_space(3))) char *) p;
+}
+__device__ __forceinline__ h4 pack_h4(float x, float y, float z) {
+  typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+  const hp2 a = __builtin_amdgcn_cvt_pkrtz(x, y), b = __builtin_amdgcn_cvt_pkrtz(z, 0.f);
+  int2 bits;
+  __builtin_memcpy(&bits.x, &a, 4); __builtin_memcpy(&bits.y, &b, 4);
+  h4 q;
+  __builtin_memcpy(&q, &bits, 8);
+  return q;
+}
+// power of two s with bound * s in [4096, 8192): scale of a vector whose entries are bounded by `bound` before it is rounded to halves
+__device__ __forceinline__ float half_scale(float bound) {
+  if (!(bound > 1e-30f) || !(bound < 1e30f)) return 1.f;
+  int e;
+  (void) frexpf(bound, &e);            // bound = m 2^e, m in [0.5, 1)
+  return ldexpf(1.f, 13 - e);
+}
+// two block sums in one pass (fp32 inside a wave, fp64 across the waves)
+template <int THREADS>
+__device__ __forceinline__ void block_sum2_f(float &a, float &b, double *red, double &sa, double &sb) {
+  a = wave_sum_f(a); b = wave_sum_f(b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  constexpr int NW = THREADS / 64;
+  __syncthreads();
+  if (l == 0) { red[w] = (double) a; red[NW + w] = (double) b; }
+  __syncthreads();
+  sa = 0; sb = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { sa += red[k]; sb += red[NW + k]; }
+}
+
 template <int NP>
 __device__ __forceinline__ void consume(const int4 (&e)[PB], const float *lp, int base, float &ax, float &ay, float &az) {
   consume_p(e, (const float2 *) lp, lp + 2 * NP, base, ax, ay, az);
