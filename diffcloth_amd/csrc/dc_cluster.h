@@ -88,8 +88,7 @@ struct In2Sc1 {       // input loader of element_windows_t (stage1 / in2) for a 
 };
 
 // ---- exchange state of one workgroup ----
-constexpr int kXchWaves = 32;          // sum granules per (part, parity): one per wave of the publishing workgroup (<= 1024 threads), or three per
-                                       // wave of a 512-thread workgroup for the four-double sums of the single-exchange CG (xch_publish_sums4d)
+constexpr int kXchWaves = 16;          // sum granules per (part, parity): one per wave of the publishing workgroup (<= 1024 threads)
 struct Xch {
   __amdgpu_buffer_rsrc_t rs;    // the rollout's exchange area
   unsigned seq;                 // sequence number of the current exchange (tag); starts at 0 = "nothing yet"
@@ -115,12 +114,11 @@ __device__ __forceinline__ Xch xch_init(const DevCluster &CL, int lb, int part, 
   const size_t per = (size_t) CL.K * 2 * CL.xch_stride;
   X.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (CL.xch + (size_t) lb * per), 0, (int) (per * 16), 0x00020000);
   X.seq = 0; X.site = 0; X.same_xcd = false; X.part = part; X.K = CL.K; X.HB = CL.HB; X.stride = CL.xch_stride;
-  X.lsum = lds_tail; X.ldead = (int *) (lds_tail + 32); X.err = CL.err; X.limit = CL.spin_limit;
+  X.lsum = lds_tail; X.ldead = (int *) (lds_tail + 8); X.err = CL.err; X.limit = CL.spin_limit;
   if (threadIdx.x == 0) *X.ldead = 0;
   return X;
 }
-constexpr int kXchLdsFloats = 36;      // tail of the dynamic LDS the exchange uses: lsum[2][4] + the fp32 / fp64 slots of xch_allsum_d (floats 0 .. 11),
-                                       // the 2 x 4 doubles of xch_finish4d (floats 16 .. 31), ldead (32), padding
+constexpr int kXchLdsFloats = 16;      // tail of the dynamic LDS the exchange uses (lsum[2][4], ldead, padding)
 
 __device__ __forceinline__ int xch_off(const Xch &X, int part, int g) { return ((part * 2 + (int) (X.seq & 1u)) * X.stride + g) * 16; }
 
@@ -275,65 +273,6 @@ __device__ __forceinline__ bool xch_allsum_d(Xch &X, double a, float c, double &
   if (!ok) *X.ldead = 1;
   __syncthreads();
   sa = slot[0]; sc = (double) *cslot;
-  return *X.ldead == 0;
-}
-
-// ---- four fp64 sums in ONE exchange (the single-exchange CG of dc_forward_cl.hip). Every wave reduces its lanes' doubles and publishes
-// three granules {a.lo, a.hi, b.lo | b.hi, c.lo, c.hi | d.lo, d.hi, 0} in its slots 3 w .. 3 w + 2; lane j of the consumer's wave 0 polls the
-// three granules of wave j % NW of part j / NW (K NW <= 64), and the totals are summed over the lanes in a fixed order: bitwise the
-// same on every part. xch_finish4d is xch_finish with these sums: one workgroup barrier, the neighbours' boundary rows in hv.
-template <int THREADS>
-__device__ __forceinline__ void xch_publish_sums4d(const Xch &X, double a, double b, double c, double d) {
-  static_assert(3 * (THREADS / 64) <= kXchWaves, "three sum granules per wave");
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); d += __shfl_down(d, o, 64); }
-  if ((threadIdx.x & 63) == 0) {
-    const int w = (int) (threadIdx.x >> 6);
-    const v4i g0 = {__double2loint(a), __double2hiint(a), __double2loint(b), (int) X.seq};
-    const v4i g1 = {__double2hiint(b), __double2loint(c), __double2hiint(c), (int) X.seq};
-    const v4i g2 = {__double2loint(d), __double2hiint(d), 0, (int) X.seq};
-    xch_store(X, g0, xch_off(X, X.part, 3 * w)); xch_store(X, g1, xch_off(X, X.part, 3 * w + 1)); xch_store(X, g2, xch_off(X, X.part, 3 * w + 2));
-  }
-}
-template <int THREADS, int HPT, bool HALO>
-__device__ __forceinline__ bool xch_finish4d(const Xch &X, double (&sums)[4], f3 (&hv)[HPT]) {
-  constexpr int NW = THREADS / 64;
-  const int tid = threadIdx.x;
-  bool ok = true;
-  double *slot = (double *) (X.lsum + 16) + 4 * (int) (X.seq & 1u);
-  if (tid < 64) {
-    double a = 0, b = 0, c = 0, d = 0;
-    if (tid < X.K * NW) {
-      v4i g0, g1, g2;
-      const int src = tid / NW, w = tid % NW;
-      ok = xch_poll(X, xch_off(X, src, 3 * w), g0) && ok;
-      ok = xch_poll(X, xch_off(X, src, 3 * w + 1), g1) && ok;
-      ok = xch_poll(X, xch_off(X, src, 3 * w + 2), g2) && ok;
-      a = __hiloint2double(g0.y, g0.x); b = __hiloint2double(g1.x, g0.z); c = __hiloint2double(g1.z, g1.y); d = __hiloint2double(g2.y, g2.x);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); d += __shfl_down(d, o, 64); }
-    if (tid == 0) { slot[0] = a; slot[1] = b; slot[2] = c; slot[3] = d; }
-  }
-  if constexpr (HALO) {
-#pragma unroll
-    for (int q = 0; q < HPT; q++) {
-      const int j = tid + q * THREADS;
-      hv[q] = mk(0, 0, 0);
-      if (j < 2 * X.HB) {
-        const bool lower = j < X.HB;
-        const int src = lower ? X.part - 1 : X.part + 1;
-        if (src >= 0 && src < X.K) {
-          v4i g;
-          ok = xch_poll(X, xch_off(X, src, kXchWaves + (lower ? X.HB + j : j - X.HB)), g) && ok;
-          hv[q] = mk(__int_as_float(g.x), __int_as_float(g.y), __int_as_float(g.z));
-        }
-      }
-    }
-  }
-  if (!ok) *X.ldead = 1;
-  __syncthreads();
-  sums[0] = slot[0]; sums[1] = slot[1]; sums[2] = slot[2]; sums[3] = slot[3];
   return *X.ldead == 0;
 }
 

@@ -303,7 +303,7 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
     if (v == 0) continue;                                // more rows per part than the kernel holds in registers: more windows do not help
     if (!HW.build_own(H, own_w)) continue;
     const int win_floats = (int) (HW.lds_bytes / 4);
-    const int fwd = std::max(std::max(3 * (Rc + 2 * HB) + 6 * HB, win_floats), kSelfDetectLdsInts);      // (gather array of the direction + the neighbours' residual rows)
+    const int fwd = std::max(std::max((v <= 6 ? 6 : 3) * (Rc + 2 * HB), win_floats), kSelfDetectLdsInts);      // (<= 6 rows per thread: pipelined CG, two gather arrays)
     const int bwd = (win_floats + 3) / 4 * 4 + 6 * HB;
     if (fwd + 4 > lds_cap || bwd + 4 > lds_cap) continue;
     // the element reach of every window must stay inside the boundary rows its part receives

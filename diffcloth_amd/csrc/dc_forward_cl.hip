@@ -4,12 +4,9 @@
 // A p / iterate in registers, element windows in LDS); what is new is what crosses the parts:
 //   * PD level: the velocity iterate v is written and read write-through (sc1), its hand-over flag is the exchange that carries
 //     the convergence norm; per time step the tape state changes hands under an agent-scope release / acquire pair;
-//   * PCG level, ONE exchange per iteration (round 4; two before): [p.Ap, r.Ap, Ap.Ap (and p.r in the seeded pass) as fp64 partial sums +
-//     the HB boundary rows of A p]. With those three products the new residual norm needs no reduction of its own, |r - a Ap|^2 =
-//     |r|^2 - 2 a r.Ap + a^2 Ap.Ap (in fp64 from exactly accumulated fp32 products: the recurrence carries the initial norm's absolute
-//     error, so the sums must be good to far below the stopping threshold 1e-8 |r0|^2), and with the neighbours' boundary rows of A p
-//     every part updates its copy of their boundary RESIDUAL rows itself (r_halo -= a Ap_halo, the same fma as the owner's: bitwise the
-//     same values) and from them its copy of their direction rows (p_halo = r_halo + beta p_halo): neither r nor p ever travels;
+//   * PCG level, two exchanges per iteration: [p.Ap partials] and [r.r partial + the HB boundary rows of the new residual]; every
+//     part keeps the neighbours' boundary rows of the search direction in its LDS gather array and updates them itself
+//     (p_halo = r_halo + beta p_halo), so the direction never travels;
 //   * self contacts couple arbitrary vertices: detection + layering and the layered friction pass of an iteration run on part 0
 //     over the rollout's global arrays, bracketed by fence barriers.
 // All parts take identical control-flow decisions: every scalar that steers a loop is a sum over the parts in part order.
@@ -34,7 +31,8 @@ namespace dc {
 #define CPH_PRINT
 #endif
 
-template <int THREADS, int VPT, bool DETECT>
+// PIPE: the inner solve is the pipelined CG of Ghysels & Vanroose (one exchange per iteration instead of two), see the loop
+template <int THREADS, int VPT, bool DETECT, bool PIPE>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
                                                         FwdArgs A, int b0, int nb_real, int tail_off, int fric_floats) {
   const DevSystem &S = *Sp;
@@ -54,8 +52,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   if (!xch_hello<THREADS>(X)) return;
   float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
   float *gz = lds + 2 * GL;
-  float2 *rhxy = (float2 *) (lds + 3 * GL);   // the neighbours' boundary rows of the RESIDUAL, [0, HB) from part - 1, [HB, 2 HB) from part + 1
-  float *rhz = lds + 3 * GL + 4 * HB;
+  float2 *gxy1 = (float2 *) (lds + 3 * GL);   // PIPE: second gather array (the iterations alternate between the two)
+  float *gz1 = lds + 5 * GL;
   const int N = S.N;
   const int r0 = part * R, r1 = min(N, r0 + R);
   const int nch = R >> 6, cbase = r0 >> 6;
@@ -157,11 +155,11 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       return (f + r - v * m) * CL.sq_dinv[i];       // scaled residual D^-1/2 rhs
     };
     // ---- local step + vertex pass through this part's element windows ----
-    double psum = 0.0;                             // |rhs|^2 of the own rows, products and sum exact in fp64 (see the header: single-exchange CG)
+    float psum = 0.f;
     auto vert = [&](int i, f3 sum, f3) {
       f3 rhs = vertex_body(i, sum);
       st3(scr, i, N, rhs);
-      psum += (double) rhs.x * rhs.x + (double) rhs.y * rhs.y + (double) rhs.z * rhs.z;
+      psum += dot(rhs, rhs);
     };
     element_windows_t<THREADS, kFwdOpsPrecise>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
     __syncthreads();
@@ -173,11 +171,11 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
       }
       if (!xch_barrier<THREADS>(X)) return;
-      psum = 0.0;
+      psum = 0.f;
       for (int i = r0 + tid; i < r1; i += THREADS) {
         f3 rhs = (ld3c(rfb, i) + ld3c(rrb, i) - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i];
         st3(scr, i, N, rhs);
-        psum += (double) rhs.x * rhs.x + (double) rhs.y * rhs.y + (double) rhs.z * rhs.z;
+        psum += dot(rhs, rhs);
       }
       __syncthreads();
     }
@@ -202,20 +200,15 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     }
     double rz;
     {
-      double s4[4];
-      xch_publish_sums4d<THREADS>(X, psum, 0.0, 0.0, 0.0);
+      xch_publish_sums(X, psum, 0.f, 0.f);
       f3 hv[HPT];
-      if (!xch_finish4d<THREADS, HPT, true>(X, s4, hv)) return;
+      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
 #pragma unroll
       for (int q = 0; q < HPT; q++) {
         const int j = tid + q * THREADS;
-        if (j < 2 * HB) {
-          const int li = j < HB ? j : R + j;
-          gxy[li] = make_float2(hv[q].x, hv[q].y); gz[li] = hv[q].z;
-          rhxy[j] = make_float2(hv[q].x, hv[q].y); rhz[j] = hv[q].z;
-        }
+        if (j < 2 * HB) { const int li = j < HB ? j : R + j; gxy[li] = make_float2(hv[q].x, hv[q].y); gz[li] = hv[q].z; }
       }
-      rz = s4[0];
+      rz = sums[0];
     }
     // With few rows per thread the first packet batch of every row (16 registers per row) stays in registers for the whole solve:
     // the matrix is the same in all ~25 iterations, and a part that is only a few rows deep cannot hide the L2 latency of
@@ -227,9 +220,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
 #pragma unroll
       for (int k = 0; k < VPT; k++) load_batch(mat[k], CL.pk + CL.pk_ptr[cbase + min(wv + k * WAVES, nch - 1)] + lane, 0);
     }
-    // ap = Ahat p on the own rows (p incl. halo in the gather array); the thread's shares of p.Ap, r.Ap, Ap.Ap (and p.r in the seeded pass)
-    // accumulated in fp64 from exact products
-    auto spmv = [&](int wz, const float2 *vxy, const float *vz, double &s_pap, double &s_rap, double &s_apap, bool with_pr, double &s_pr) {
+    // ap = Ahat p on the own rows (p incl. halo in the gather array), part2 += <p, ap>
+    auto spmv = [&](int wz, const float2 *vxy, const float *vz, float &part2, bool with_pr, float &part3) {
       int4 nxt[PB];
       if constexpr (!MATREG) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
 #pragma unroll
@@ -259,19 +251,91 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           load_batch(cur, row, s0);
           consume_p(cur, vxy, vz, base, ax, ay, az);
         }
-        ax *= onf; ay *= onf; az *= onf;
-        ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
-        const double dax = ax, day = ay, daz = az;
-        s_pap += (double) pxy.x * dax + (double) pxy.y * day + (double) pz * daz;
-        s_rap += (double) rr[k][0] * dax + (double) rr[k][1] * day + (double) rr[k][2] * daz;
-        s_apap += dax * dax + day * day + daz * daz;
-        if (with_pr) s_pr += ((double) pxy.x * rr[k][0] + (double) pxy.y * rr[k][1] + (double) pz * rr[k][2]) * (double) onf;     // seeded pass only (uniform branch)
+        ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
+        part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;
+        if (with_pr) part3 += (pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2]) * onf;     // seeded pass only (uniform branch)
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     __syncthreads();
     CPH(2)
     // ---- global step: CG on the scaled system = Jacobi PCG on P dv = rhs ----
+    if constexpr (PIPE) {
+      // Pipelined CG (Ghysels & Vanroose 2014, unpreconditioned form — the system is already scaled): besides x, r, p it carries
+      // w = A r, s = A p, z = A s by recurrence, so that both inner products of an iteration, (r, r) and (w, r), are available
+      // BEFORE its one matrix product q = A w. They travel in the same exchange as the boundary rows of w that product needs:
+      // ONE exchange per iteration instead of two, one more product per solve, three more axpys per iteration. Same iterates
+      // as CG in exact arithmetic; in fp32 the recurrences cost about a digit of attainable accuracy, far below cg_rel_tol.
+      if (rz > 1e-300) {
+        const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
+        float ww[VPT][3], pp[VPT][3], ss[VPT][3], zz[VPT][3];
+        {
+          int zs;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+          float unused = 0.f;
+          spmv(wv + zs, gxy, gz, unused, false, unused);            // w = A r (r and its halo are in the first gather array)
+        }
+#pragma unroll
+        for (int k = 0; k < VPT; k++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) { ww[k][c] = ap[k][c]; pp[k][c] = 0.f; ss[k][c] = 0.f; zz[k][c] = 0.f; }
+        float alpha_old = 1.f;
+        double gamma_old = 1.0;
+        for (int it = 0;;) {
+          int zs;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+          const int wz = wv + zs, tz = tid + zs;
+          float2 *cxy = (it & 1) ? gxy : gxy1;        // this iteration's gather array for w (the other one may still be read)
+          float *cz = (it & 1) ? gz : gz1;
+          float pg = 0.f, pd = 0.f;
+          X.site = 6;
+          xch_begin(X);
+#pragma unroll
+          for (int k = 0; k < VPT; k++) {
+            const int l = tz + k * THREADS;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { pg = fmaf(rr[k][c], rr[k][c], pg); pd = fmaf(ww[k][c], rr[k][c], pd); }
+            if (l < R) {
+              cxy[HB + l] = make_float2(ww[k][0], ww[k][1]); cz[HB + l] = ww[k][2];
+              xch_publish_boundary(X, l, R, ww[k][0], ww[k][1], ww[k][2]);
+            }
+          }
+          xch_publish_sums(X, pg, pd, 0.f);
+          f3 hv[HPT];
+          if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+          const double gamma = sums[0], delta = sums[1];
+          if (!(gamma > stop) || it >= A.cg_max) break;
+          float beta = 0.f, alpha;
+          if (it == 0) alpha = (float) (gamma / delta);
+          else {
+            beta = (float) (gamma / gamma_old);
+            alpha = (float) (gamma / (delta - (double) beta * gamma / (double) alpha_old));
+          }
+          if (!(alpha > 0.f) || !isfinite(alpha)) break;        // breakdown: keep the iterate reached so far
+#pragma unroll
+          for (int q = 0; q < HPT; q++) {
+            const int j = tid + q * THREADS;
+            if (j < 2 * HB) { const int li = j < HB ? j : R + j; cxy[li] = make_float2(hv[q].x, hv[q].y); cz[li] = hv[q].z; }
+          }
+          __syncthreads();
+          float unused = 0.f;
+          spmv(wz, cxy, cz, unused, false, unused);                  // q = A w
+#pragma unroll
+          for (int k = 0; k < VPT; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              zz[k][c] = fmaf(beta, zz[k][c], ap[k][c]);
+              ss[k][c] = fmaf(beta, ss[k][c], ww[k][c]);
+              pp[k][c] = fmaf(beta, pp[k][c], rr[k][c]);
+              xx[k][c] = fmaf(alpha, pp[k][c], xx[k][c]);
+              rr[k][c] = fmaf(-alpha, ss[k][c], rr[k][c]);
+              ww[k][c] = fmaf(-alpha, zz[k][c], ww[k][c]);
+            }
+          gamma_old = gamma; alpha_old = alpha;
+          it++; cg_total++;
+        }
+      }
+    } else
     if (rz > 1e-300) {
       const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
       // Recycled first direction (A.cg_seed, see dc_forward_pk.hip): the previous PD iteration's correction d, read back with its
@@ -289,28 +353,20 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         __syncthreads();
       }
       for (int it = 0; it < A.cg_max;) {
-        double s_pap = 0, s_rap = 0, s_apap = 0, s_pr = 0;
+        float part2 = 0.f, part3 = 0.f;
         int zs;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
         const int wz = wv + zs, tz = tid + zs;
-        spmv(wz, gxy, gz, s_pap, s_rap, s_apap, seed, s_pr);
+        spmv(wz, gxy, gz, part2, seed, part3);
         CPH(3)
-        // the iteration's ONE exchange: boundary rows of A p + the four sums
         X.site = 6;
+        if (!xch_allsum<THREADS>(X, part2, part3, 0.f, sums)) return;
+        CPH(4)
+        const double pr = seed ? sums[1] : rz;
+        const float alpha = sums[0] > 1e-300 ? (float) (pr / sums[0]) : 0.f;
+        part2 = 0.f;
+        X.site = 7;
         xch_begin(X);
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int l = tz + k * THREADS;
-          if (l < R) xch_publish_boundary(X, l, R, ap[k][0], ap[k][1], ap[k][2]);
-        }
-        xch_publish_sums4d<THREADS>(X, s_pap, s_rap, s_apap, s_pr);
-        CPH(5)
-        double s4[4];
-        f3 hv[HPT];
-        if (!xch_finish4d<THREADS, HPT, true>(X, s4, hv)) return;
-        CPH(6)
-        const double pr = seed ? s4[3] : rz;
-        const float alpha = s4[0] > 1e-300 ? (float) (pr / s4[0]) : 0.f;
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
           const int l = tz + k * THREADS;
@@ -321,11 +377,16 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           for (int c = 0; c < 3; c++) {
             xx[k][c] = fmaf(alpha, pv[c], xx[k][c]);
             rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
+            part2 = fmaf(rr[k][c], rr[k][c], part2);
           }
+          if (l < R) xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
         }
-        // |r - alpha A p|^2 without a reduction of its own (alpha = the fp32 value the update used)
-        const double ad = (double) alpha;
-        const double rz_new = fmax(rz - 2.0 * ad * s4[1] + ad * ad * s4[2], 0.0);
+        xch_publish_sums(X, part2, 0.f, 0.f);
+        CPH(5)
+        f3 hv[HPT];
+        if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+        CPH(6)
+        const double rz_new = sums[0];
         it++; cg_total++;
         if (!(rz_new > stop)) break;
         const float beta = seed ? 0.f : (float) (rz_new / rz);
@@ -341,23 +402,20 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           }
         }
 #pragma unroll
-        for (int q = 0; q < HPT; q++) {         // the neighbours' boundary rows: their residual from their A p rows, their direction from that
+        for (int q = 0; q < HPT; q++) {         // the neighbours' boundary rows of p, updated here from their residual rows
           const int j = tid + q * THREADS;
           if (j < 2 * HB) {
             const int li = j < HB ? j : R + j;
-            const float2 rxy = rhxy[j];
-            const f3 rn = mk(fmaf(-alpha, hv[q].x, rxy.x), fmaf(-alpha, hv[q].y, rxy.y), fmaf(-alpha, hv[q].z, rhz[j]));
-            rhxy[j] = make_float2(rn.x, rn.y); rhz[j] = rn.z;
             const float2 pxy = gxy[li];
-            gxy[li] = make_float2(fmaf(beta, pxy.x, rn.x), fmaf(beta, pxy.y, rn.y));
-            gz[li] = fmaf(beta, gz[li], rn.z);
+            gxy[li] = make_float2(fmaf(beta, pxy.x, hv[q].x), fmaf(beta, pxy.y, hv[q].y));
+            gz[li] = fmaf(beta, gz[li], hv[q].z);
           }
         }
         __syncthreads();
       }
     }
     // ---- update + convergence (Simulation.cpp:1268, 1310-1373); delta v replaces A p in its registers ----
-    float psumf = 0.f;
+    psum = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
       const int l = tq + k * THREADS, i = r0 + l;
@@ -369,12 +427,12 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       if (on) {
         if (A.cg_seed) st3c(dpb, i, mk(xx[k][0], xx[k][1], xx[k][2]));
         st3c(vnb, i, mk(vq.x + ap[k][0], vq.y + ap[k][1], vq.z + ap[k][2]));
-        psumf = fmaf(ap[k][0], ap[k][0], psumf); psumf = fmaf(ap[k][1], ap[k][1], psumf); psumf = fmaf(ap[k][2], ap[k][2], psumf);
+        psum = fmaf(ap[k][0], ap[k][0], psum); psum = fmaf(ap[k][1], ap[k][1], psum); psum = fmaf(ap[k][2], ap[k][2], psum);
       }
     }
     X.site = 8;
     xch_drain();                                  // the new v must have left the CU before the norm (= its hand-over flag) is published
-    if (!xch_allsum<THREADS>(X, psumf, 0.f, 0.f, sums)) return;
+    if (!xch_allsum<THREADS>(X, psum, 0.f, 0.f, sums)) return;
     xdiff = (double) h * sqrt(sums[0]) / (double) N;
     CPH(7)
     iters = iter + 1;
@@ -418,19 +476,19 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   }   // step
 }
 
-template <int VPT, bool DETECT>
+template <int VPT, bool DETECT, bool PIPE>
 static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
   constexpr int THREADS = 512;
   const int GL = CL.R + 2 * CL.HB;
-  int floats = std::max(3 * GL + 6 * CL.HB, CL.win_lds_bytes / 4);      // gather array of the direction + the neighbours' residual rows
+  int floats = std::max((PIPE ? 6 : 3) * GL, CL.win_lds_bytes / 4);
   const int fric_floats = floats;      // LDS offered to the layered friction pass: the same with and without the inlined detection
   if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
   const int tail_off = (floats + 3) / 4 * 4;
   const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
   if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+  hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, tail_off, fric_floats);
+  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT, PIPE>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, tail_off, fric_floats);
   return hipGetLastError();
 }
 
@@ -438,11 +496,14 @@ static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const
 // rounded up to a multiple of 8 rollouts: with the observed round-robin placement (block b on XCD b % 8) the K parts of a rollout
 // then land on ONE XCD whatever nb is (cluster_map), which lets their exchanges stay in that XCD's L2; the padding workgroups
 // exit at once. Correctness does not depend on the placement (xch_hello checks it at run time).
-// (A pipelined CG — Ghysels & Vanroose, one exchange per iteration through recurrences for A r, A p, A s — was an opt-in variant in
-// rounds 2-3: +8 %, but its recurrences drift in fp32 and it failed the position bound at N = 16 384. Round 4's single-exchange CG gets
-// the same exchange count from the standard recurrences, see the header.)
 hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
-#define DC_CL_CASE(V) case V: return A.inline_detect ? launch_cl_inst<V, true>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false>(S, CL, W, A, b0, nb, st);
+  // Pipelined CG (one exchange per iteration, needs <= 6 rows per thread for its seven row vectors) is OFF unless DC_PIPECG=1
+  // (development switch). Measured r02v, C4 at 32 rollouts x 8 workgroups: forward 8.77 -> 7.99 ms per step (+8 % rollout-steps/s),
+  // same PD / CG iteration counts — but its recurrences for A r, A p, A s drift in fp32: at N = 16 384 (36 iterations per solve)
+  // the converged positions moved by 7e-5 against the fp64 oracle (bound 4.5e-5; the two-exchange CG: 1.2e-7). Parity first.
+  static const bool pipe_ok = getenv("DC_PIPECG") && getenv("DC_PIPECG")[0] == '1';
+#define DC_CL_CASE(V) case V: if (pipe_ok && V <= 6) return A.inline_detect ? launch_cl_inst<V, true, (V <= 6)>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, (V <= 6)>(S, CL, W, A, b0, nb, st); \
+                              return A.inline_detect ? launch_cl_inst<V, true, false>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, false>(S, CL, W, A, b0, nb, st);
   switch (CL.pk_vpt) {
     DC_CL_CASE(1) DC_CL_CASE(2) DC_CL_CASE(3) DC_CL_CASE(4) DC_CL_CASE(6) DC_CL_CASE(8) DC_CL_CASE(12)
     default: return hipErrorInvalidValue;
