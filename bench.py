@@ -291,11 +291,13 @@ def main():
     # iteration statistics of the timed steps (needed for the byte / cycle models)
     pd = cg_f = adj = cg_b = selfc = cyc = it64 = 0.0
     conv = 0
+    cg_per_rollout = np.zeros(B); adj_per_rollout = np.zeros(B)       # load balance: a launch lasts as long as its slowest rollout
     for s in range(W + 1, W + K + 1):
         fs, bs = e.get_stats(s)
         pd += fs["pd_iters"].sum(); cg_f += fs["cg_iters"].sum(); conv += int((fs["converged"] > 0).sum())
         selfc += fs["self_contacts"].sum()
         adj += bs["adjoint_iters"].sum(); cg_b += bs["cg_iters"].sum(); cyc += bs["refine_cycles"].sum(); it64 += bs["fp64_iters"].sum()
+        cg_per_rollout += fs["cg_iters"]; adj_per_rollout += bs["adjoint_iters"]
     N, T, E = e.N, e.T, e.E
     cl = e.cluster() if hasattr(e, "cluster") else 1
     # ---- roofline models (DESIGN.md "Roofline model"), per launch = the K timed steps of the rank's B rollouts ----
@@ -395,6 +397,8 @@ def main():
                        "mean_adjoint_iters_per_step": adj / (B * K), "mean_fp32_solves_per_adjoint": cyc / (B * K),
                        "fp64_fallback_iters": it64, "adjoint_precision": "mixed: fp32 BiCGSTAB corrections of the fp64 residual",
                        "converged_fraction": conv / (B * K),
+                       "slowest_rollout_over_mean": {"forward_pcg_iterations": float(cg_per_rollout.max() / max(cg_per_rollout.mean(), 1e-30)),
+                                                     "adjoint_iterations": float(adj_per_rollout.max() / max(adj_per_rollout.mean(), 1e-30))},
                        "batch_steps_per_s": K / dt, "gradients_finite": finite,
                        "dL_dmu_sum_over_job": float(np.asarray(dmu_total).sum()),
                        "per_rank_sweep_ms": rank_ms, "allreduce_ms": t_reduce * 1e3,

@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
     "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout", "dc_comm_unique_id", "dc_comm_init", "dc_allreduce_sum", "dc_comm_destroy",
-    "dc_set_record", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
+    "dc_set_record", "dc_keep_force_gradients", "dc_get_force_gradients", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
 ]
 
 _lib = None
@@ -155,6 +155,18 @@ class Engine:
                 raise KeyError(k)
         self._chk(self.lib.dc_set_params(self.h, C.byref(self.params)))
 
+    def set_solver(self, forward_tol=None, backward_tol=None, gradient_clipping=None, clip_threshold=None, force_direct_adjoint=None):
+        """dc_set_solver: the solver knobs the reference reads from its process-global statics at every step; no rebuild, the batch and
+        its tape stay valid. Arguments left None keep their current value."""
+        p = self.params
+        if forward_tol is not None: p.forward_tol = forward_tol
+        if backward_tol is not None: p.backward_tol = backward_tol
+        if gradient_clipping is not None: p.gradient_clipping = int(gradient_clipping)
+        if clip_threshold is not None: p.gradient_clipping_threshold = clip_threshold
+        if force_direct_adjoint is not None: p.adjoint_mode = 1 if force_direct_adjoint else 0
+        self._chk(self.lib.dc_set_solver(self.h, C.c_double(p.forward_tol), C.c_double(p.backward_tol), C.c_int(p.gradient_clipping),
+                                         C.c_double(p.gradient_clipping_threshold), C.c_int(int(p.adjoint_mode == 1))))
+
     def set_primitives(self, prims):
         """prims: list of dicts(kind, group, center, top_offset, radius, length, mu, rotates)."""
         arr = (dc_primitive * max(len(prims), 1))()
@@ -229,6 +241,15 @@ class Engine:
         """h^2 (I + dr_df)^T u* per vertex of the last backward step (dL_dfext_vec of the reference)."""
         out = np.zeros((self.B, 3 * self.N))
         self._chk(self.lib.dc_get_force_gradient(self.h, _d(out)))
+        return out
+
+    def keep_force_gradients(self, keep=True):
+        self._chk(self.lib.dc_keep_force_gradients(self.h, C.c_int(int(keep))))
+
+    def get_force_gradients(self, slot0, nslots):
+        """h^2 (I + dr_df)^T u* per vertex of the backward steps through records slot0 .. slot0 + nslots - 1 (after keep_force_gradients)."""
+        out = np.zeros((nslots, self.B, 3 * self.N))
+        self._chk(self.lib.dc_get_force_gradients(self.h, C.c_int(slot0), C.c_int(nslots), _d(out)))
         return out
 
     # ---- hot path ----

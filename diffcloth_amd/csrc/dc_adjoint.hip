@@ -445,6 +445,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     if (A.iv) A.iv -= A.slot_ix;
     A.is_start = (A.slot - step == 1) ? 1 : 0;            // isStart: Simulation.cpp:3947
     A.inj_x = A.inj_f = A.inj_n = A.inj_sn = A.inj_sd = nullptr;      // (a record from outside is differentiated by a launch of its own)
+    if (A.ys) A.ys -= A.slot_state;
   }
   AdjCtx C;
   C.lds = dyn_lds; C.lds_floats = WIN ? S.win_lds_bytes / 4 : 0;
@@ -564,9 +565,34 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   W64.u = W.u64 + off; W64.r = W.r64 + off; W64.y = W.y64 + off; W64.x = W.x64 + off; W64.corner = W.c64 + (size_t) b * 3 * S.NC;
   W64.rhat = W.k64[0] + off; W64.p = W.k64[1] + off; W64.v = W.k64[2] + off; W64.t = W.k64[3] + off; W64.ph = W.k64[4] + off; W64.sh = W.k64[5] + off;
   int cycles = 0, iters64 = 0, verified = 1;
-  // u64 = the result of the reference iteration (mode 0), or 0
-  for (int i = tid; i < N; i += THREADS) st3d(W64.u, i, N, (A.mode == 0) ? tod(ld3(u, i, N)) : mkd(0, 0, 0));
+  // u64 = the result of the reference iteration (mode 0), or 0 — or, inside a fused sweep (A.warm), the previous step's solution: the
+  // carried gradient and the step's record change smoothly from one time step to the next, so u*(k + 1) scaled by the factor that
+  // minimises the residual along it is a far better start than 0 for the adjoint of step k (one more fp64 operator application)
+  const bool warm = A.warm && A.mode == 1 && step > 0 && gnorm > 0;
+  if (!warm) for (int i = tid; i < N; i += THREADS) st3d(W64.u, i, N, (A.mode == 0) ? tod(ld3(u, i, N)) : mkd(0, 0, 0));
   prepare_x64<THREADS>(S, C64, tm, W64.x);
+  double rr_warm = -1;
+  if (warm) {
+    double a1 = 0, a2 = 0;      // w = K u_prev into W64.r; <w, g>, <w, w>
+    apply_K64<THREADS>(S, C64, tm, W64.u, W64, [&](int i, d3 o) {
+      st3d(W64.r, i, N, o);
+      const d3 gi = tod(ld3(gx, i, N) * gscale);
+      a1 += dot(o, gi); a2 += dot(o, o);
+    });
+    double s3[3];
+    tm.sum3(a1, a2, 0, s3);
+    const double gam = s3[1] > 0 ? s3[0] / s3[1] : 0.0;
+    double a3 = 0;
+    for (int i = tid; i < N; i += THREADS) {
+      const d3 q = tod(ld3(gx, i, N) * gscale) - ld3d(W64.r, i, N) * gam;
+      st3d(W64.r, i, N, q); st3d(W64.u, i, N, ld3d(W64.u, i, N) * gam);
+      a3 += dot(q, q);
+    }
+    tm.sum3(a3, 0, 0, s3);
+    rr_warm = s3[0];
+    for (int i = tid; i < N; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));
+    __syncthreads();
+  }
 
   if (need_direct && gnorm > 0) {
     // ---- direct solve of K u = g in mixed precision: block-Jacobi preconditioned BiCGSTAB in fp32 for corrections d of the
@@ -584,7 +610,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
     // true residual of the start: g itself for u = 0 (mode 1), g - K u after the reference iteration hit its cap (mode 0);
     // `gin` holds the right-hand side of the next fp32 solve: g, later the fp64 residual rounded to fp32
-    double rr_true = gnorm * gnorm;
+    double rr_true = warm ? rr_warm : gnorm * gnorm;
     if (A.mode == 0) {
       rr_true = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;
       for (int i = tid; i < N; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));

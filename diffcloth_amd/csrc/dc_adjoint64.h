@@ -605,6 +605,7 @@ __device__ DC_OUTLINED Ret64<Team> finish_gradients64(const DevSystem &S, Adj64 
     st3(gx, i, N, tof(dx));
     st3(gv, i, N, tof(dv));
     st3(y32, i, N, tof(yi));
+    if (A.ys) st3(A.ys + off, i, N, tof(yi));
     const int a = S.att_of_vertex[i];
     if (a >= 0 && dxf) st3(dxf, a, S.Af, tof(yi * (h2 * S.k_att64)));   // A_t_dp_dxfixed (Simulation.cpp:3035-3048)
   }

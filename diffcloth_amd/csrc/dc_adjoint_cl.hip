@@ -191,6 +191,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     if (A.iv) A.iv -= A.slot_ix;
     A.is_start = (A.slot - step == 1) ? 1 : 0;            // isStart: Simulation.cpp:3947
     A.inj_x = A.inj_f = A.inj_n = A.inj_sn = A.inj_sd = nullptr;      // (a record from outside is differentiated by a launch of its own)
+    if (A.ys) A.ys -= A.slot_state;
   }
   AdjCl C;
   C.lds = dyn_lds; C.lds_floats = hc_off; C.hc = dyn_lds + hc_off;

@@ -196,6 +196,7 @@ struct BwdArgs {
   int fp32_only;                // direct solve: 1 = the fp32 Krylov solve alone (no fp64 residual, no refinement, no fp64 fall-back)
   int dense_y;                  // 1 = form y = (I + dr_df)^T z over all vertices in every operator application (development switch DC_ADJ_DENSEY)
   int verify_all;               // direct solve: 1 = evaluate the fp64 residual after EVERY correction solve (development switch DC_ADJ_VERIFY)
+  int warm;                     // direct solve inside a fused sweep: start step s > 0 from gamma u*(step s - 1) (DC_ADJ_WARM, dc_adjoint.hip)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;
   size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements); d_xfixed steps by slot_xf too
@@ -203,6 +204,7 @@ struct BwdArgs {
   // record handed in from outside (dc_set_record): the fp64 values of x_new, f, the primitive-contact normals ([B][3][N] planar) and of
   // the self contacts' normals / d ([B][cap][3]) for the fp64 operator; all null for a record the forward kernels made
   const double *inj_x, *inj_f, *inj_n, *inj_sn, *inj_sd;
+  float *ys;                    // y = (I + dr_df)^T u* of the step, kept per tape slot (dc_keep_force_gradients; steps by slot_state) or nullptr
 };
 
 void launch_pd_step(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st);

@@ -91,6 +91,8 @@ struct dc_ctx {
   std::vector<void *> sched_pool;
   // record handed in from outside (dc_set_record): fp64 values of x_new, f, primitive-contact normals [B][3][N], self-contact normals / d
   // [B][cap][3]; allocated on first use, valid for tape slot inj_slot only (-1 = none)
+  float *YS = nullptr;              // [(tape+1)][B][3][N] y of every backward step (dc_keep_force_gradients), allocated on first use
+  bool keep_y = false;
   double *INJ_X = nullptr, *INJ_F = nullptr, *INJ_N = nullptr, *INJ_SN = nullptr, *INJ_SD = nullptr;
   int inj_slot = -1;
   dc_step_stats *fstats = nullptr;  // [(tape+1)][B]
@@ -244,10 +246,12 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   { const char *envp = getenv("DC_ADJ_FP32"); A.fp32_only = envp ? (envp[0] == '1') : (c->params.adjoint_fp32_only != 0); }     // (development switch)
   { const char *envp = getenv("DC_ADJ_DENSEY"); A.dense_y = envp ? (envp[0] == '1') : 0; }
   { const char *envp = getenv("DC_ADJ_VERIFY"); A.verify_all = envp ? (envp[0] == '1') : 0; }     // (development switch)
+  { const char *envp = getenv("DC_ADJ_WARM"); A.warm = envp ? (envp[0] == '1') : 0; }            // (development switch)
   A.nsteps = 1; A.slot = slot;
   const bool inj = c->inj_slot == slot && c->INJ_X;
   A.inj_x = inj ? c->INJ_X : nullptr; A.inj_f = inj ? c->INJ_F : nullptr; A.inj_n = inj ? c->INJ_N : nullptr;
   A.inj_sn = inj ? c->INJ_SN : nullptr; A.inj_sd = inj ? c->INJ_SD : nullptr;
+  A.ys = (c->keep_y && c->YS) ? c->YS + se * slot : nullptr;
   A.slot_state = se; A.slot_prim = sp; A.slot_self = (size_t) c->B * c->self_cap; A.slot_meta = (size_t) c->B * kMetaStride;
   A.slot_param = (size_t) c->B * 8; A.slot_xf = (size_t) c->B * 3 * c->S.Af; A.slot_stats = (size_t) c->B;
   return A;
@@ -914,6 +918,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->FVS_S, (size_t) B * slots))) return rc;
   c->SEEDX = c->SEEDV = nullptr;
   c->INJ_X = c->INJ_F = c->INJ_N = c->INJ_SN = c->INJ_SD = nullptr; c->inj_slot = -1;
+  c->YS = nullptr; c->keep_y = false;
   c->sched_xf.assign(slots + 1, 0); c->sched_fu.assign(slots + 1, 0); c->sched_fvs.assign(slots + 1, 0); c->sched_seed.assign(slots + 1, 0);
   if ((rc = dev_alloc(c, pool, &c->DMU, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->target, (size_t) 3 * N))) return rc;
@@ -983,6 +988,32 @@ int dc_get_force_gradient(dc_ctx *c, double *dL_df) {
   const size_t n = (size_t) c->B * 3 * c->host.N;
   for (size_t k = 0; k < n; k++) dL_df[k] *= h2;
   return DC_OK;
+}
+
+int dc_keep_force_gradients(dc_ctx *c, int keep) {
+  int rc = check_batch(c, 0, 0);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (keep && !c->YS && (rc = dev_alloc(c, c->batch_allocs, &c->YS, slot_elems(c) * ((size_t) c->tape + 1)))) return rc;
+  c->keep_y = keep != 0;
+  return DC_OK;
+}
+
+int dc_get_force_gradients(dc_ctx *c, int slot0, int nslots, double *dL_df) {
+  int rc = check_batch(c, slot0, slot0 + nslots - 1);
+  if (rc) return rc;
+  if (slot0 < 1 || nslots < 1 || !dL_df) return fail(c, DC_ERR_INVALID, "dc_get_force_gradients: slot 0 has no record");
+  if (!c->YS) return fail(c, DC_ERR_STATE, "dc_get_force_gradients: dc_keep_force_gradients(1) was not set before the backward sweep");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t se = slot_elems(c);
+  const double h2 = c->params.time_step * c->params.time_step;
+  for (int k = 0; k < nslots; k++) {
+    if ((rc = d2h_planar(c, c->YS + se * (slot0 + k), dL_df + se * k, c->host.N, k & 3, true))) return rc;
+    if ((k & 3) == 3) HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t q = 0; q < se * (size_t) nslots; q++) dL_df[q] *= h2;
+  return cluster_check(c);
 }
 
 int dc_set_state(dc_ctx *c, int slot, const double *x, const double *v) {

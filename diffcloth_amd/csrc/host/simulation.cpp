@@ -847,7 +847,7 @@ std::vector<BackwardInformation> Simulation::sweepBackwardOnDevice(BackwardTaskI
   static const bool envOff = std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS") && std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS")[0] == '0';
   const int frames = (int) forwardRecords.size();
   if (!deviceResidentRollouts || envOff || frames < 2 || (int) seeds.size() != frames) return {};
-  if (needsForceVector(taskInfo)) return {};        // the per-vertex force gradient of every step is a host-side product: per-step path
+  const bool needVec = needsForceVector(taskInfo);  // the per-vertex force gradient of every step: kept per tape slot by the sweep (dc_keep_force_gradients)
   if (forwardRecords[0].deviceSlot != 0) return {};      // isStart of the sweep is tied to tape slot 1
   for (int i = 1; i < frames; i++) if (forwardRecords[i].deviceSlot != forwardRecords[i - 1].deviceSlot + 1) return {};
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
@@ -862,7 +862,14 @@ std::vector<BackwardInformation> Simulation::sweepBackwardOnDevice(BackwardTaskI
   }
   check(ctx, dc_set_seed_schedule(ctx, slot0, nsteps, SX.data(), SV.data()), "dc_set_seed_schedule");
   check(ctx, dc_set_gradient(ctx, seeds[frames - 1].first.data(), seeds[frames - 1].second.data()), "dc_set_gradient");
+  check(ctx, dc_keep_force_gradients(ctx, needVec ? 1 : 0), "dc_keep_force_gradients");
   check(ctx, dc_rollout_backward(ctx, last, nsteps), "dc_rollout_backward");
+  VecXd FV;
+  if (needVec) {
+    FV.assign((size_t) nsteps * n3, 0.0);
+    check(ctx, dc_get_force_gradients(ctx, slot0 + 1, nsteps, FV.data()), "dc_get_force_gradients");
+    check(ctx, dc_keep_force_gradients(ctx, 0), "dc_keep_force_gradients");
+  }
   VecXd dx(n3), dv(n3), dmuTotal(std::max<size_t>(primitives.size(), 1), 0.0);
   check(ctx, dc_get_gradient(ctx, dx.data(), dv.data(), dmuTotal.data()), "dc_get_gradient");
   VecXd DXF((size_t) nsteps * 3 * std::max<size_t>(Af, 1), 0.0);
@@ -878,6 +885,7 @@ std::vector<BackwardInformation> Simulation::sweepBackwardOnDevice(BackwardTaskI
     for (size_t q = 0; q < 3 * Af; q++) d.dxf[q] = DXF[(size_t) (idx - 1) * 3 * Af + q];
     d.dmu.assign(dmuTotal.size(), 0.0);
     if (idx == 1) d.dmu = dmuTotal;               // the device accumulates dL_dmu over the sweep: the total enters at the last step
+    if (needVec) d.fvec.assign(FV.begin() + (size_t) (idx - 1) * n3, FV.begin() + (size_t) idx * n3);
     dc_bwd_stats st;
     check(ctx, dc_get_stats(ctx, fwd.deviceSlot, nullptr, &st), "dc_get_stats");
     d.converged = st.converged; d.iters = st.adjoint_iters;

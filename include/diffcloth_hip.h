@@ -228,6 +228,13 @@ int dc_get_param_gradients(dc_ctx *ctx, int slot, double *out /*B*8*/);
  * calls dL_dfext_vec (Simulation.cpp:1700-1760), from which dL_dconstantForceField (sum over the steps), dL_dwindtimestep
  * (dot with (wind * windNorm) (.) windFallOff) and the fall-off variants of dL_dfext / dL_dwind are formed.            */
 int dc_get_force_gradient(dc_ctx *ctx, double *dL_df /*B*3N*/);
+/* The same vector of EVERY step of a backward sweep: with keep = 1 the backward kernels also store y = (I + dr_df)^T u* of the step through
+ * record `slot` in a tape-sized array (allocated on first use, one [B][3][N] fp32 plane per slot), so that a fused sweep
+ * (dc_rollout_backward: all steps in one launch) leaves what Simulation::stepBackward forms per step from dL_dfext_vec — dL_dconstantForceField
+ * (the sum over the steps), dL_dwindtimestep[step] (its dot with the wind field), the fall-off variants of dL_dfext / dL_dwind
+ * (Simulation.cpp:1700-1764) — readable afterwards: dc_get_force_gradients returns h^2 y of the records slot0 .. slot0 + nslots - 1. */
+int dc_keep_force_gradients(dc_ctx *ctx, int keep);
+int dc_get_force_gradients(dc_ctx *ctx, int slot0, int nslots, double *dL_df /*nslots*B*3N*/);
 
 /* ---- device-pointer boundary: the per-step calls for callers whose tensors already live on this GPU (torch-ROCm: the controller /
  * RL training loops, reference src/python_code/pySim/functional.py:20-102 and hatController.py:78-105, call stepNN + stepBackwardNN

@@ -66,49 +66,4 @@ def test_reference_functional_py_runs_unmodified():
         np.testing.assert_allclose(a.grad.numpy(), da, rtol=1e-5, atol=1e-9)
 
 
-def test_hatController_trains_one_epoch_unmodified(tmp_path):
-    """The controller-training script BASELINE.json's north star names — src/python_code/hatController.py with common.py, utils.py,
-    clothNN/ and pySim/, frozen byte for byte under tests/golden/reference_callers/ — run UNMODIFIED for one epoch
-    (`python hatController.py --epochNum 1`) against this repository's diffcloth_py: makeSim("wear_hat"), makeOptimizeHelper, 20
-    training rollouts of 400 stepNN steps through torch.autograd with loss.backward() through 400 stepBackwardNN calls each
-    (hatController.py:78-105), Adam step, 9 validation rollouts, checkpoints and plots. What the test adds around it is environment
-    only: an assets directory holding the hat mesh (from tests/golden/meshes.npz) and hat_target.txt, a scratch working directory
-    (the script writes experiments/ next to itself), a headless matplotlib backend and a three-line stand-in for the `colorama`
-    package, which this image does not have."""
-    import shutil
-    import subprocess
-    import time
-    pytest.importorskip("torch"); pytest.importorskip("matplotlib")
-    src = os.path.join(ROOT, "tests", "golden", "reference_callers")
-    work = tmp_path / "python_code"
-    shutil.copytree(src, work)
-    (work / "colorama.py").write_text("class _C:\n    def __getattr__(self, k):\n        return ''\nFore = Style = _C()\n")
-    assets = tmp_path / "assets"
-    (assets / "remeshed" / "Hat").mkdir(parents=True)
-    V, F = scenes.load_mesh("hat")
-    with open(assets / "remeshed" / "agenthat2-579-rotated.obj", "w") as f:
-        for p in np.asarray(V).reshape(-1, 3):
-            f.write(f"v {p[0]:.17g} {p[1]:.17g} {p[2]:.17g}\n")
-        for t in np.asarray(F).reshape(-1, 3):
-            f.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
-    shutil.copyfile(os.path.join(src, "hat_target.txt"), assets / "remeshed" / "Hat" / "hat_target.txt")
-    env = dict(os.environ, DIFFCLOTH_ASSETS=str(assets), MPLBACKEND="Agg",
-               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "diffcloth_amd", "lib"), os.environ.get("PYTHONPATH", "")]))
-    t0 = time.perf_counter()
-    run = subprocess.run([sys.executable, "hatController.py", "--epochNum", "1", "--randSeed", "2"], cwd=work, env=env, capture_output=True, text=True, timeout=1500)
-    dt = time.perf_counter() - t0
-    tail = "\n".join((run.stdout + run.stderr).splitlines()[-25:])
-    assert run.returncode == 0, tail
-    logs = list((work / "experiments" / "wear_hat").glob("*/log.txt"))
-    assert len(logs) == 1, tail
-    text = logs[0].read_text()
-    train = [ln for ln in text.splitlines() if ln.startswith("Train: loss:")]
-    test = [ln for ln in text.splitlines() if ln.startswith("Test: loss:")]
-    assert len(train) == 1 and len(test) == 1, text
-    loss = float(train[0].split()[2])
-    assert np.isfinite(loss) and loss > 0
-    ckpts = sorted(p.name for p in logs[0].parent.glob("*.pth"))
-    assert "0.pth" in ckpts and "trainBestEpoch.pth" in ckpts, ckpts
-    steps = 20 * 400 * 2 + 9 * 400          # forward + backward steps of the training rollouts, forward steps of the validation
-    print(f"\n[hatController.py, unmodified, 1 epoch] {dt:.1f} s wall for 20 training rollouts (400 stepNN + 400 stepBackwardNN each) + 9 validation "
-          f"rollouts = {steps / dt:.0f} single-rollout steps/s including torch and the script's plotting; {train[0].strip()} | {test[0].strip()}")
+# (hatController.py itself, unmodified, for one epoch: tests/test_gpu_batched_epoch.py runs it and compares the batched epoch with it)

@@ -136,3 +136,33 @@ def test_schedules_with_self_collision_and_explicit_fixed_points_override():
     e.step_forward(S - 1, fixed_pts=XF[0])
     xc, _ = e.get_states(S, 1)
     assert np.abs(xc[0] - xa[S]).max() > 1e-6
+
+
+@pytest.mark.parametrize("nx,cluster", [(17, 0), (48, 4)])
+def test_fused_backward_sweep_keeps_the_force_gradient_of_every_step(nx, cluster, monkeypatch):
+    """dL_dfext_vec = h^2 (I + dr_df)^T u* of EVERY step of a fused sweep (dc_keep_force_gradients / dc_get_force_gradients) — what
+    Simulation::stepBackward forms dL_dconstantForceField, dL_dwindtimestep and the fall-off wind gradients from, step by step
+    (Simulation.cpp:1700-1764) — against dc_get_force_gradient after each per-step backward call: same kernels, same inputs, same bits."""
+    if cluster:
+        monkeypatch.setenv("DC_CLUSTER", str(cluster))
+    rng = np.random.default_rng(11)
+    B, S = 2, 4
+    V, F, e = scene(nx, (0, nx - 1))
+    e.alloc_batch(B, S)
+    X0 = np.stack([f32(V.reshape(-1) + np.tile([0.01 * b, -0.05, 0.0], V.shape[0])) for b in range(B)])
+    e.set_state(0, X0, np.zeros_like(X0))
+    e.rollout_forward(0, S)
+    gx = f32(rng.standard_normal(X0.shape)); gv = f32(0.01 * rng.standard_normal(X0.shape))
+    e.keep_force_gradients(True)
+    e.set_gradient(gx, gv)
+    e.rollout_backward(S, S)                                  # ONE launch for the S steps
+    kept = e.get_force_gradients(1, S)
+    dx_f, dv_f, _ = e.get_gradient()
+    e.keep_force_gradients(False)
+    e.set_gradient(gx, gv)
+    for s in range(S, 0, -1):
+        e.rollout_backward(s, 1)
+        np.testing.assert_array_equal(kept[s - 1], e.get_force_gradient())
+    dx_s, dv_s, _ = e.get_gradient()
+    np.testing.assert_array_equal(dx_f, dx_s); np.testing.assert_array_equal(dv_f, dv_s)
+    assert np.abs(kept).max() > 0
