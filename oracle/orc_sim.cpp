@@ -991,9 +991,11 @@ BackwardOut Sim::stepBackward(const Record &rec, const double *dL_dxnew_in, cons
 
   std::vector<double> u(n3, 0.0), u_prev(n3, 0.0), dU, rhs(n3);
   auto solveDirect = [&]() {   // (P - dP^T) u = g  via right-preconditioned restarted GMRES
-    // restart length and restart count sized for the worst system of the test suite (the squashed 7 742-vertex dress: K indefinite,
-    // cond 3e7 — GMRES(80) x 40 stagnated at 1e-3 there and nothing noticed); the achieved residual is reported (directResidual)
-    const int m = n3 > 6000 ? 200 : 80;
+    // restart length 80, doubled (up to 640) whenever a restart cycle fails to halve the residual: the squashed 7 742-vertex dress (K indefinite,
+    // cond 3e7) stagnates at 1e-3 under GMRES(80) — round 3 ran 40 such restarts and nobody noticed; the achieved residual is now
+    // reported (directResidual), and tests that need that system solved use a sparse LU (tests/orc.py::step_backward_lu)
+    int m = 80;
+    double beta_prev = -1;
     std::vector<double> x(n3, 0.0);
     auto applyOp = [&](const std::vector<double> &z, std::vector<double> &Az) {   // Az = (P - dP^T) P^{-1} z
       std::vector<double> pz, Ppz, d;
@@ -1011,6 +1013,8 @@ BackwardOut Sim::stepBackward(const Record &rec, const double *dL_dxnew_in, cons
       beta = std::sqrt(beta);
       out.directResidual = beta / bnorm;
       if (beta <= 1e-13 * bnorm) break;
+      if (beta_prev > 0 && beta > 0.5 * beta_prev && m < 640) m *= 2;
+      beta_prev = beta;
       std::vector<std::vector<double>> V(1, r0);
       for (double &v : V[0]) v /= beta;
       std::vector<std::vector<double>> H(m + 1, std::vector<double>(m, 0.0));
