@@ -32,7 +32,7 @@ class dc_params(C.Structure):
                 ("gradient_clipping_threshold", C.c_double), ("pd_iter_cap", C.c_int), ("adjoint_iter_cap", C.c_int),
                 ("cg_rel_tol", C.c_double), ("cg_max_iter", C.c_int), ("stall_window", C.c_int),
                 ("adjoint_mode", C.c_int), ("adjoint_rel_tol", C.c_double), ("adjoint_block_precond", C.c_int), ("adjoint_fp32_only", C.c_int),
-                ("max_self_contacts", C.c_int)]
+                ("max_self_contacts", C.c_int), ("forward_deflation", C.c_int)]
 
 
 class dc_step_stats(C.Structure):
@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
     "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout", "dc_comm_unique_id", "dc_comm_init", "dc_allreduce_sum", "dc_comm_destroy",
-    "dc_set_record", "dc_keep_force_gradients", "dc_get_force_gradients", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
+    "dc_get_deflation", "dc_set_record", "dc_keep_force_gradients", "dc_get_force_gradients", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
 ]
 
 _lib = None
@@ -461,6 +461,12 @@ class Engine:
         c = _i32(np.zeros(6))
         self._chk(self.lib.dc_get_layout(self.h, _i(c)))
         return dict(renumbered=bool(c[0]), bandwidth=int(c[1]), packet_kernel=bool(c[2]), element_windows=bool(c[3]), windows=int(c[4]), dense_inverse=bool(c[5]))
+
+    def deflation(self):
+        """(vectors, probe iterations): the deflation space dc_build chose for the forward solve (dc_get_deflation)"""
+        k = C.c_int(); pi = C.c_int()
+        self._chk(self.lib.dc_get_deflation(self.h, C.byref(k), C.byref(pi)))
+        return k.value, pi.value
 
     def cluster(self):
         """workgroups per rollout the engine chose for this batch (dc_get_cluster); 1 = one workgroup per rollout"""

@@ -69,6 +69,10 @@ struct DevSystem {
   const float DC_G *sq_dinv;         // [pk_threads * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
   int pk_threads, pad3;         // threads of the packet kernel the tables are padded for (512 or 768)
+  // spectral deflation of the forward solve (dc_deflate.h): 16 lowest eigenvectors of the scaled matrix, [pk rows][16] row-major; null = none
+  const float DC_G *defl_u;
+  const float DC_G *defl_au;         // Ahat U, same layout
+  const float DC_C *defl_g;          // [16][16] (U^T Ahat U)^-1
   // explicit inverse of the scaled matrix for small meshes (dc_dense.h): [N + pad][dense_ld] fp32, null = not built
   const float DC_G *dense_inv;
   int dense_ld;

@@ -23,6 +23,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include "dc_windows.h"
 #include "dc_packets.h"
 #include "dc_dense.h"
+#include "dc_deflate.h"
 #include "dc_selftmp.h"
 #include "dc_cluster.h"
 
@@ -105,6 +106,7 @@ struct dc_ctx {
   ClusterSet cl;
   int cus = 0;                      // compute units of the device
   int bandwidth = 0;                // of the scalar system matrix in device numbering
+  int defl_k = 0, defl_probe = 0;   // deflation space of the forward solve (dc_deflate.h)
 };
 
 namespace {
@@ -462,6 +464,7 @@ void dc_default_params(dc_params *p) {
   p->pd_iter_cap = -1; p->adjoint_iter_cap = 400; p->cg_rel_tol = 1e-4; p->cg_max_iter = 500; p->stall_window = 0;
   p->adjoint_mode = 0; p->adjoint_rel_tol = 1e-6; p->adjoint_block_precond = 1; p->adjoint_fp32_only = 0;
   p->max_self_contacts = 0;      /* sized from the mesh in dc_build */
+  p->forward_deflation = -1;     /* decided in dc_build by a probe solve */
 }
 
 int dc_create(int device_id, dc_ctx **out) {
@@ -590,6 +593,11 @@ int dc_build(dc_ctx *c) {
     c->S.win_ok = HW.build(H, (size_t) 150 * 1024) ? 1 : 0;
     c->S.pk_ok = HP.build(H) ? 1 : 0;
     c->S.nwin = HW.nwin; c->S.pk_vpt = HP.vpt; c->S.pk_threads = HP.threads;
+    {
+      HostDeflation HD;
+      c->defl_k = 0; c->defl_probe = 0;
+      if (c->S.pk_ok && c->S.win_ok && HP.threads == 512 && HP.vpt >= 4) { HD.build(H, p.forward_deflation > 0 ? 16 : p.forward_deflation, HP.threads * HP.vpt); c->defl_k = HD.k; c->defl_probe = HD.probe_iterations; }
+    }
     c->built = true;
     return DC_OK;
   }
@@ -743,6 +751,20 @@ int dc_build(dc_ctx *c) {
       if ((rc = upload<float>(c, &S.sq_dinv, HP.sq_dinv))) return rc;
       S.pk_vpt = HP.vpt; S.pk_threads = HP.threads; S.pk_ok = 1;
     }
+  }
+  {  // irregular garments: the 16 lowest eigenvectors of the scaled matrix as a deflation space of the forward solve (dc_deflate.h)
+    HostDeflation HD;
+    S.defl_u = nullptr; S.defl_au = nullptr; S.defl_g = nullptr; c->defl_k = 0; c->defl_probe = 0;
+    static const char *envd = getenv("DC_DEFLATION");      // development switch: 0 = off, 1 = always
+    const int want = envd ? (atoi(envd) > 0 ? 16 : 0) : (p.forward_deflation > 0 ? 16 : p.forward_deflation);
+    // (the deflated kernels exist for 512 threads x >= 4 rows: meshes of more than 1536 vertices, dc_forward_pk_defl.hip)
+    if (S.pk_ok && S.win_ok && S.pk_threads == 512 && S.pk_vpt >= 4 && HD.build(H, want, S.pk_threads * S.pk_vpt)) {
+      if ((rc = upload<float>(c, &S.defl_u, HD.U))) return rc;
+      if ((rc = upload<float>(c, &S.defl_au, HD.AU))) return rc;
+      if ((rc = upload<float>(c, &S.defl_g, HD.G))) return rc;
+      c->defl_k = HD.k;
+    }
+    c->defl_probe = HD.probe_iterations;
   }
   {  // small meshes: explicit inverse of the scaled matrix (dc_dense.h) for the forward global step
     HostDense HD;
@@ -1581,6 +1603,14 @@ int dc_sync(dc_ctx *c) {
   if (c->host_only) return DC_OK;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return cluster_check(c);
+}
+
+int dc_get_deflation(const dc_ctx *c, int *vectors, int *probe_iterations) {
+  if (!c) return DC_ERR_INVALID;
+  if (!c->built) return DC_ERR_STATE;
+  if (vectors) *vectors = c->defl_k;
+  if (probe_iterations) *probe_iterations = c->defl_probe;
+  return DC_OK;
 }
 
 int dc_get_layout(const dc_ctx *c, int *out6) {

@@ -90,6 +90,12 @@ typedef struct dc_params {
   int adjoint_fp32_only;
   int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: sized from the mesh,
                                        max(2048, N) pairs (at most 16000); overflow is reported, never silent: dc_step_stats */
+  /* forward solve, spectral deflation for irregular garments (csrc/dc_deflate.h): < 0 (default) = decided in dc_build by a probe solve
+   * (16 eigenvectors of the scaled system matrix when Jacobi-PCG needs more than 80 iterations on a smooth right-hand side: the
+   * reference's 7 742-vertex dress needs 337, the cloth / T-shirt / sock / dress-3634 meshes 15 ... 37 and get none), 0 = never, > 0 = always.
+   * Every solve of the one-workgroup forward kernel then starts with a Galerkin projection onto those vectors (after its recycled first
+   * direction); the stopping rule and what the solve converges to are unchanged.                                                       */
+  int forward_deflation;
 } dc_params;
 
 /* Per-rollout statistics of one forward step (ForwardInformation::converged/convergeIter). */
@@ -305,6 +311,9 @@ int dc_get_cluster(const dc_ctx *ctx, int *workgroups_per_rollout, int *rollouts
  * LDS element windows usable, number of element windows, explicit-inverse solve (small meshes)}. A mesh that fails the packet /
  * window conditions runs on the global-memory fallback kernels — correct, but several times slower. */
 int dc_get_layout(const dc_ctx *ctx, int *out6);
+/* Deflation space of the forward solve dc_build chose (works on a host-only context): number of vectors (0 = none) and the iteration
+ * count of the probe solve that decided (Jacobi-PCG to 1e-4 on a smooth right-hand side).                                            */
+int dc_get_deflation(const dc_ctx *ctx, int *vectors, int *probe_iterations);
 
 /* ---- collective for C++ callers: one context (= one GPU) per rank; the optimiser sums [loss, dL/dtheta] over the ranks once per
  * evaluation, the only exchange of the rollout-sharded job. RCCL is bound at run time when these are first used.

@@ -383,3 +383,59 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
           f"(fp64 fall-back {gt['fp64_iters'][0]} iterations, residual {gt['last_udiff'][0]:.1e})")
     assert gt["converged"][0] == 1
     assert ea <= 1e-4 and et <= 1e-4
+
+
+def test_dress_7742_forward_solve_with_spectral_deflation(monkeypatch):
+    """Jacobi-PCG needs ~260 iterations per PD iteration on the reference's fine dress (smooth, almost mass-only
+    modes of the hanging garment: cond 5e4 after scaling). dc_build finds that with a probe solve and hands the one-workgroup forward kernel
+    the 16 lowest eigenvectors of the scaled matrix; every solve starts with a Galerkin projection onto them (csrc/dc_deflate.h). Same step,
+    same stopping rules: positions, contact set and PD iteration count must still be the oracle's, with a fraction of the PCG iterations.
+    (One workgroup per rollout is forced: the split kernels do not have the projection.)"""
+    monkeypatch.setenv("DC_CLUSTER", "1")
+    V, F = scenes.load_mesh("dress7k")
+    cfg = dict(h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
+    P, rmin, rmax = scenes.normalise_model(V, "FRONT", 8.0)
+    P = f32(P)
+    top = np.argsort(-P[:, 1])[:6].tolist()
+    rng = np.random.default_rng(8)
+    X = P.copy()
+    X[:, 2] *= 0.9
+    vel = np.zeros_like(X)
+    vel[:, 2] = -0.1 * np.sign(P[:, 2])
+    B = 1        # (the squashed pose of test_dress_7742_vertices_forward_step_and_adjoint_fallback: 434 PD iterations)
+    X0 = np.stack([f32((X + 0.0005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
+    V0 = np.stack([f32((vel + 0.005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
+    XF = np.stack([f32(X[top].reshape(-1)) for _ in range(B)])
+    out = {}
+    for want in (-1, 0):
+        e = capi.Engine(0)
+        e.set_mesh(P, F); e.set_attachments(top)
+        e.set_params(time_step=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], forward_tol=1e-8, backward_tol=1e-9,
+                     cg_rel_tol=1e-6, cg_max_iter=3000, gradient_clipping=0, selfcollision_enabled=1, adjoint_mode=1, adjoint_rel_tol=1e-7,
+                     forward_deflation=want)
+        e.set_primitives([]); e.build()
+        k, probe = e.deflation()
+        assert (k, probe > 200) == ((16, True) if want < 0 else (0, False)), (want, k, probe)      # (switched off: no probe solve either)
+        e.alloc_batch(B, 1)
+        assert e.cluster() == 1
+        e.set_state(0, X0, V0)
+        e.timer_start()
+        st = e.step_forward(0, fixed_pts=XF)
+        ms = e.timer_stop()
+        out[want] = dict(st=st, x=e.get_state(1)[0], ms=ms)
+    o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-8, bwd_tol=1e-9,
+                   attachments=top, selfcollision=True, contact=True, gradient_clipping=False, threads=min(os.cpu_count() or 1, 32))
+    o.build()
+    a, b = out[-1], out[0]
+    per_pd = [float(r["st"]["cg_iters"].mean() / r["st"]["pd_iters"].mean()) for r in (a, b)]
+    for q in range(B):
+        ref = o.step(X0[q], V0[q], XF[q])
+        dx = np.abs(a["x"][q] - ref["x"]).max()
+        print(f"\n[dress 7742, deflated forward solve] rollout {q}: PD iterations {a['st']['pd_iters'][q]} (without: {b['st']['pd_iters'][q]}, oracle {ref['iters']}), "
+              f"self contacts {a['st']['self_contacts'][q]} / {ref['nself']}, max|dx| vs oracle {dx:.2e}, vs the undeflated run {np.abs(a['x'][q] - b['x'][q]).max():.2e}")
+        assert a["st"]["converged"][q] == 1 and ref["converged"]
+        assert a["st"]["self_contacts"][q] == ref["nself"] and abs(int(a["st"]["pd_iters"][q]) - ref["iters"]) <= 2
+        assert dx <= 8e-5
+    print(f"[dress 7742, deflated forward solve] PCG iterations per PD iteration {per_pd[0]:.0f} with the 16-vector deflation space, {per_pd[1]:.0f} without; "
+          f"step time for {B} rollouts {a['ms']:.0f} ms / {b['ms']:.0f} ms")
+    assert per_pd[0] <= 0.45 * per_pd[1]

@@ -110,3 +110,29 @@ def test_shipped_garments_get_the_resident_kernel_set(mesh, orient, dim, max_bw)
     lg = g.layout()
     assert not lg["renumbered"] and lg["packet_kernel"] and lg["element_windows"] and lg["windows"] == 10, lg
 
+
+
+def test_deflation_space_is_built_for_the_irregular_garment_only():
+    """dc_get_deflation on a host-only context: the probe solve (Jacobi-PCG to 1e-4 on a smooth right-hand side) decides — the reference's
+    7 742-vertex dress needs > 300 iterations and gets its 16 lowest eigenvectors, the 3 634-vertex dress, the T-shirt and the bench cloth need
+    15 ... 40 and get none; forward_deflation = 0 switches it off, > 0 forces it (csrc/dc_deflate.h)."""
+    import scenes
+    got = {}
+    for mesh, orient, dim in (("dress7k", "FRONT", 8.0), ("dress", "FRONT", 8.0), ("tshirt", "BACK", 6.0)):
+        V, F = scenes.load_mesh(mesh)
+        P, _, _ = scenes.normalise_model(V, orient, dim)
+        top = np.argsort(-P[:, 1])[:6].tolist()
+        e = capi.Engine(-1)
+        e.set_mesh(P, F); e.set_attachments(top)
+        e.set_params(time_step=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
+        e.set_primitives([]); e.build()
+        got[mesh] = e.deflation()
+    print(got)
+    assert got["dress7k"][0] == 16 and got["dress7k"][1] > 200
+    assert got["dress"][0] == 0 and got["dress"][1] <= 80 and got["tshirt"][0] == 0 and got["tshirt"][1] <= 80
+    V2, F2 = meshes.grid_cloth(100, 100, 4.5, 4.5, "DOWN")
+    for want, expect in ((-1, 0), (1, 16)):
+        g = capi.Engine(-1)
+        g.set_mesh(V2, F2); g.set_attachments([]); g.set_params(time_step=1.0 / 180, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_deflation=want)
+        g.set_primitives([]); g.build()
+        assert g.deflation()[0] == expect and g.deflation()[1] <= 40
