@@ -11,486 +11,11 @@
 //     over the rollout's global arrays, bracketed by fence barriers.
 // All parts take identical control-flow decisions: every scalar that steers a loop is a sum over the parts in part order.
 #define DC_KERNEL_TU
-#include "dc_devlib.h"
-#include "dc_winlib.h"
-#include "dc_selflib.h"
-#include "dc_pklib.h"
-#include "dc_cluster.h"
-#include <algorithm>
-#include <cstdlib>
+#include "dc_forward_cl_kernel.h"
 
 namespace dc {
 
-#ifdef DC_PROFILE_PHASES
-#define CPH_DECL long long cph_t = clock64(); long long cph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define CPH(k) { long long n_ = clock64(); cph[k] += n_ - cph_t; cph_t = n_; }
-#define CPH_PRINT if (b == b0 && tid == 0) printf("[phases cl part %d] pd %d cg %d | per PD iter: windows %lld self %lld rhs-exch %lld update+exch %lld | per CG iter: spmv %lld exch-pAp %lld upd+publish %lld exch-rr+halo %lld p-update %lld cycles\n", part, iters, cg_total, cph[0] / iters, cph[1] / iters, cph[2] / iters, cph[7] / iters, cph[3] / max(cg_total, 1), cph[4] / max(cg_total, 1), cph[5] / max(cg_total, 1), cph[6] / max(cg_total, 1), 0ll);
-#else
-#define CPH_DECL
-#define CPH(k)
-#define CPH_PRINT
-#endif
-
-// PIPE: the inner solve is the pipelined CG of Ghysels & Vanroose (one exchange per iteration instead of two), see the loop
-template <int THREADS, int VPT, bool DETECT, bool PIPE>
-__global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
-                                                        FwdArgs A, int b0, int nb_real, int tail_off, int fric_floats) {
-  const DevSystem &S = *Sp;
-  const DevCluster &CL = *Cp;
-  constexpr int WAVES = THREADS / 64;
-  constexpr int HPT = (1024 + THREADS - 1) / THREADS;      // halo rows per thread: 2 HB <= 1024
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int K = CL.K, R = CL.R, HB = CL.HB, GL = R + 2 * HB;
-  int lb, part;
-  cluster_map(K, lb, part);
-  if (lb >= nb_real) return;       // padding workgroups: the launch is rounded up to a multiple of 8 rollouts (see the launcher)
-  if (CL.test_drop && lb == 0 && part == K - 1) return;      // test hook: a part that never arrives (tests/test_gpu_cluster.py)
-  const int b = b0 + lb;
-  Xch X = xch_init(CL, lb, part, lds + tail_off);
-  if (!xch_hello<THREADS>(X)) return;
-  float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
-  float *gz = lds + 2 * GL;
-  float2 *gxy1 = (float2 *) (lds + 3 * GL);   // PIPE: second gather array (the iterations alternate between the two)
-  float *gz1 = lds + 5 * GL;
-  const int N = S.N;
-  const int r0 = part * R, r1 = min(N, r0 + R);
-  const int nch = R >> 6, cbase = r0 >> 6;
-  const size_t off = (size_t) b * 3 * N;
-  float *g = W.g + off, *vnow = W.vnow + off, *vbest = W.vbest + off, *scr = W.cg_r + off;
-  const BufVec vnb = buf_vec(vnow, N, X.same_xcd);
-  const BufVec dpb = buf_vec(W.cg_x + off, N, X.same_xcd);    // scaled correction of the previous PD iteration (seed of the next solve)
-  const int w0 = part * CL.wpp, w1 = min(CL.nwin, w0 + CL.wpp);
-
-  for (int step = 0; step < A.nsteps; step++) {
-  // the previous step's state (written by every part with plain stores) changes hands
-  X.site = 1;
-  if (step > 0) {   // (with the inlined detection part 0 then reads the whole state through plain loads: acquire)
-    if constexpr (DETECT) { if (!xch_fence_barrier<THREADS>(X)) return; }
-    else { if (!xch_barrier<THREADS>(X)) return; }
-  }
-  const size_t so = (size_t) step * A.slot_state;
-  // this step's fixed-point targets and external forces (constant over the launch, or one set per step: dc_set_*_schedule)
-  const float *xfix = A.x_fixed + (size_t) step * A.slot_xfix + (size_t) b * 3 * S.Af;
-  const float *fu_s = A.fu ? A.fu + (size_t) step * A.slot_fu : nullptr;
-  const float *fvs_s = A.fv_scale ? A.fv_scale + (size_t) step * A.slot_fvs : nullptr;
-  // the tape state and f / r are read across parts: write-through stores, L1-bypassing loads (xnb, vinb, rfb, rrb, xob, vob)
-  const BufVec xnb = buf_vec(A.x_in + off + so, N, X.same_xcd), vinb = buf_vec(A.v_in + off + so, N, X.same_xcd);
-  const BufVec rfb = buf_vec(A.rec_f + off + so, N, X.same_xcd), rrb = buf_vec(A.rec_r + off + so, N, X.same_xcd);
-  float *rec_n = A.rec_n + off + so;
-  int *rec_prim = A.rec_prim + (size_t) b * N + (size_t) step * A.slot_prim;
-  SelfRec srec = A.self;
-  srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
-  srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
-  if constexpr (DETECT) {                     // detection + layering of this step: part 0, then the lists change hands
-    X.site = 2;
-    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lds); __syncthreads(); }
-  }
-  // number of self contacts of this step: part 0 knows it (its own detection, or the stand-alone detection kernel's record) and
-  // hands it to the others inside an exchange, so that no part ever has to read it from memory another part wrote
-  int nself = 0;
-  {
-    double ns[3];
-    float mine = 0.f;
-    if (part == 0 && tid == 0 && S.contact_enabled && S.self_enabled) mine = (float) srec.meta[(size_t) b * kMetaStride];
-    if (!xch_allsum<THREADS>(X, mine, 0.f, 0.f, ns)) return;     // (the others wait here for part 0's detection)
-    nself = (int) (ns[0] + 0.5);
-  }
-  const float *mu = A.mu + (size_t) b * S.ngroups;
-  const float h = S.h;
-  const f3 grav = mk(S.gx, S.gy, S.gz);
-  const f3 fu = fu_s ? mk(fu_s[3 * b], fu_s[3 * b + 1], fu_s[3 * b + 2]) : mk(0, 0, 0);
-  const float fvs = fvs_s ? fvs_s[b] : 1.f;
-
-  // ---- step set-up on the own rows: s_n, initial guess, contact detection (Simulation.cpp:1097-1160, :1254-1256) ----
-  float part_s = 0.f;
-  int ncontact = 0;
-  for (int i = r0 + tid; i < r1; i += THREADS) {
-    const float m = S.mass[i];
-    f3 v = ld3c(vinb, i);
-    f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
-    if (A.fv) fext = fext + ld3(A.fv + off, i, N) * fvs;
-    f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
-    st3c(vnb, i, v0);
-    st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h
-    part_s += dot(v0, v0);
-    int prim = -1;
-    f3 nrm = mk(0, 0, 0);
-    if (S.contact_enabled) prim = detect_primitive(S, ld3c(xnb, i), v0, nrm);
-    rec_prim[i] = prim;
-    st3(rec_n, i, N, nrm);
-    ncontact += (prim >= 0);
-  }
-  xch_drain();                                    // v is read by the neighbours' windows: its stores must have left the CU
-  double sums[3];
-  X.site = 3;
-  if (!xch_allsum<THREADS>(X, part_s, (float) ncontact, 0.f, sums)) return;
-  double min_xdiff = (double) h * sqrt(sums[0]) / (double) N;
-  const int total_contacts = (int) (sums[1] + 0.5);
-  bool improved = false, converged = false, stalled = false, best_is_current = false;
-  int iters = 0, cg_total = 0, since_progress = 0;
-  double xdiff = 0;
-
-  CPH_DECL
-  for (int iter = 0; iter < A.pd_cap; iter++) {
-    int zp;                                       // opaque zero against LICM of the unrolled row indices (dc_forward_pk.hip)
-    asm volatile("s_mov_b32 %0, 0" : "=s"(zp));
-    const int tq = tid + zp;
-    auto vertex_body = [&](int i, f3 fint) -> f3 {
-      f3 f = ld3(g, i, N) + fint;
-      f3 v = ld3c(vnb, i);
-      const int a = S.att_of_vertex[i];
-      if (a >= 0) f = f + ((ld3(xfix, a, S.Af) - ld3c(xnb, i)) - v * h) * (h * S.k_att);   // AttachmentSpring.cpp:25-29
-      const float m = S.mass[i];
-      f3 r = mk(0, 0, 0);
-      const int prim = rec_prim[i];
-      if (prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
-        f3 n = ld3(rec_n, i, N);
-        f3 d = f - prim_vout(S.prims[prim], n) * m;
-        r = dry_friction(n, d, mu[S.prims[prim].group]);
-      }
-      st3c(rfb, i, f);
-      st3c(rrb, i, r);
-      return (f + r - v * m) * CL.sq_dinv[i];       // scaled residual D^-1/2 rhs
-    };
-    // ---- local step + vertex pass through this part's element windows ----
-    float psum = 0.f;
-    auto vert = [&](int i, f3 sum, f3) {
-      f3 rhs = vertex_body(i, sum);
-      st3(scr, i, N, rhs);
-      psum += dot(rhs, rhs);
-    };
-    element_windows_t<THREADS, kFwdOpsPrecise>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
-    __syncthreads();
-    CPH(0)
-    X.site = 4;
-    if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) on part 0 over the rollout's f / r, then the right-hand side again
-      if (!xch_barrier<THREADS>(X)) return;
-      if (part == 0) {
-        if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
-      }
-      if (!xch_barrier<THREADS>(X)) return;
-      psum = 0.f;
-      for (int i = r0 + tid; i < r1; i += THREADS) {
-        f3 rhs = (ld3c(rfb, i) + ld3c(rrb, i) - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i];
-        st3(scr, i, N, rhs);
-        psum += dot(rhs, rhs);
-      }
-      __syncthreads();
-    }
-    CPH(1)
-    // ---- residual into registers, search direction p0 = r0 into the gather array, boundary rows to the neighbours ----
-    float rr[VPT][3], ap[VPT][3], xx[VPT][3];
-    X.site = 5;
-    xch_begin(X);
-#pragma unroll
-    for (int k = 0; k < VPT; k++) {
-      const int l = tq + k * THREADS, i = r0 + l;
-      const bool on = l < R && i < N;
-      const int ic = on ? i : r0;
-      const float okf = on ? 1.f : 0.f;
-      rr[k][0] = scr[ic] * okf; rr[k][1] = scr[N + ic] * okf; rr[k][2] = scr[2 * N + ic] * okf;
-#pragma unroll
-      for (int c = 0; c < 3; c++) xx[k][c] = 0.f;
-      if (l < R) {
-        gxy[HB + l] = make_float2(rr[k][0], rr[k][1]); gz[HB + l] = rr[k][2];
-        xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
-      }
-    }
-    double rz;
-    {
-      xch_publish_sums(X, psum, 0.f, 0.f);
-      f3 hv[HPT];
-      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
-#pragma unroll
-      for (int q = 0; q < HPT; q++) {
-        const int j = tid + q * THREADS;
-        if (j < 2 * HB) { const int li = j < HB ? j : R + j; gxy[li] = make_float2(hv[q].x, hv[q].y); gz[li] = hv[q].z; }
-      }
-      rz = sums[0];
-    }
-    // With few rows per thread the first packet batch of every row (16 registers per row) stays in registers for the whole solve:
-    // the matrix is the same in all ~25 iterations, and a part that is only a few rows deep cannot hide the L2 latency of
-    // re-reading it behind its own arithmetic (measured r02w: 4.9 k cycles per product of 3 rows, 1.6 x the per-row cost of the
-    // 20-row kernel).
-    constexpr bool MATREG = VPT <= 4;
-    int4 mat[MATREG ? VPT : 1][PB];
-    if constexpr (MATREG) {
-#pragma unroll
-      for (int k = 0; k < VPT; k++) load_batch(mat[k], CL.pk + CL.pk_ptr[cbase + min(wv + k * WAVES, nch - 1)] + lane, 0);
-    }
-    // ap = Ahat p on the own rows (p incl. halo in the gather array), part2 += <p, ap>
-    auto spmv = [&](int wz, const float2 *vxy, const float *vz, float &part2, bool with_pr, float &part3) {
-      int4 nxt[PB];
-      if constexpr (!MATREG) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(wz, nch - 1)] + lane, 0);
-#pragma unroll
-      for (int k = 0; k < VPT; k++) {
-        const int lc = wz + k * WAVES;          // wave-uniform local chunk
-        const int lcc = min(lc, nch - 1);
-        const float onf = lc < nch ? 1.f : 0.f;
-        const int chunk = cbase + lcc;
-        const int np = CL.pk_n[chunk];
-        const int4 *row = CL.pk + CL.pk_ptr[chunk] + lane;
-        int4 cur[PB];
-        if constexpr (MATREG) {
-#pragma unroll
-          for (int j = 0; j < PB; j++) cur[j] = mat[k][j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < PB; j++) cur[j] = nxt[j];
-          if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
-        }
-        const int li = HB + lcc * 64 + lane;
-        const float2 pxy = vxy[li];
-        const float pz = vz[li];
-        float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
-        const int base = li - 512;
-        consume_p(cur, vxy, vz, base, ax, ay, az);
-        for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
-          load_batch(cur, row, s0);
-          consume_p(cur, vxy, vz, base, ax, ay, az);
-        }
-        ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
-        part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;
-        if (with_pr) part3 += (pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2]) * onf;     // seeded pass only (uniform branch)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    __syncthreads();
-    CPH(2)
-    // ---- global step: CG on the scaled system = Jacobi PCG on P dv = rhs ----
-    if constexpr (PIPE) {
-      // Pipelined CG (Ghysels & Vanroose 2014, unpreconditioned form — the system is already scaled): besides x, r, p it carries
-      // w = A r, s = A p, z = A s by recurrence, so that both inner products of an iteration, (r, r) and (w, r), are available
-      // BEFORE its one matrix product q = A w. They travel in the same exchange as the boundary rows of w that product needs:
-      // ONE exchange per iteration instead of two, one more product per solve, three more axpys per iteration. Same iterates
-      // as CG in exact arithmetic; in fp32 the recurrences cost about a digit of attainable accuracy, far below cg_rel_tol.
-      if (rz > 1e-300) {
-        const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
-        float ww[VPT][3], pp[VPT][3], ss[VPT][3], zz[VPT][3];
-        {
-          int zs;
-          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-          float unused = 0.f;
-          spmv(wv + zs, gxy, gz, unused, false, unused);            // w = A r (r and its halo are in the first gather array)
-        }
-#pragma unroll
-        for (int k = 0; k < VPT; k++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) { ww[k][c] = ap[k][c]; pp[k][c] = 0.f; ss[k][c] = 0.f; zz[k][c] = 0.f; }
-        float alpha_old = 1.f;
-        double gamma_old = 1.0;
-        for (int it = 0;;) {
-          int zs;
-          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-          const int wz = wv + zs, tz = tid + zs;
-          float2 *cxy = (it & 1) ? gxy : gxy1;        // this iteration's gather array for w (the other one may still be read)
-          float *cz = (it & 1) ? gz : gz1;
-          float pg = 0.f, pd = 0.f;
-          X.site = 6;
-          xch_begin(X);
-#pragma unroll
-          for (int k = 0; k < VPT; k++) {
-            const int l = tz + k * THREADS;
-#pragma unroll
-            for (int c = 0; c < 3; c++) { pg = fmaf(rr[k][c], rr[k][c], pg); pd = fmaf(ww[k][c], rr[k][c], pd); }
-            if (l < R) {
-              cxy[HB + l] = make_float2(ww[k][0], ww[k][1]); cz[HB + l] = ww[k][2];
-              xch_publish_boundary(X, l, R, ww[k][0], ww[k][1], ww[k][2]);
-            }
-          }
-          xch_publish_sums(X, pg, pd, 0.f);
-          f3 hv[HPT];
-          if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
-          const double gamma = sums[0], delta = sums[1];
-          if (!(gamma > stop) || it >= A.cg_max) break;
-          float beta = 0.f, alpha;
-          if (it == 0) alpha = (float) (gamma / delta);
-          else {
-            beta = (float) (gamma / gamma_old);
-            alpha = (float) (gamma / (delta - (double) beta * gamma / (double) alpha_old));
-          }
-          if (!(alpha > 0.f) || !isfinite(alpha)) break;        // breakdown: keep the iterate reached so far
-#pragma unroll
-          for (int q = 0; q < HPT; q++) {
-            const int j = tid + q * THREADS;
-            if (j < 2 * HB) { const int li = j < HB ? j : R + j; cxy[li] = make_float2(hv[q].x, hv[q].y); cz[li] = hv[q].z; }
-          }
-          __syncthreads();
-          float unused = 0.f;
-          spmv(wz, cxy, cz, unused, false, unused);                  // q = A w
-#pragma unroll
-          for (int k = 0; k < VPT; k++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              zz[k][c] = fmaf(beta, zz[k][c], ap[k][c]);
-              ss[k][c] = fmaf(beta, ss[k][c], ww[k][c]);
-              pp[k][c] = fmaf(beta, pp[k][c], rr[k][c]);
-              xx[k][c] = fmaf(alpha, pp[k][c], xx[k][c]);
-              rr[k][c] = fmaf(-alpha, ss[k][c], rr[k][c]);
-              ww[k][c] = fmaf(-alpha, zz[k][c], ww[k][c]);
-            }
-          gamma_old = gamma; alpha_old = alpha;
-          it++; cg_total++;
-        }
-      }
-    } else
-    if (rz > 1e-300) {
-      const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
-      // Recycled first direction (A.cg_seed, see dc_forward_pk.hip): the previous PD iteration's correction d, read back with its
-      // boundary rows from the array every part stored its rows to before the exchange of the update; x = <d, r> / <d, A d> d,
-      // then CG restarted from the new residual. Saves exchanges as well as products.
-      bool seed = A.cg_seed && iter > 0;
-      if (seed) {
-        for (int j = tid; j < R + 2 * HB; j += THREADS) {
-          const int i = r0 - HB + j;                      // gather index j <-> global row i
-          const bool on = i >= 0 && i < N && (j < HB || j >= HB + R || i < r1);
-          f3 d = mk(0, 0, 0);
-          if (on) d = ld3c(dpb, i);
-          gxy[j] = make_float2(d.x, d.y); gz[j] = d.z;
-        }
-        __syncthreads();
-      }
-      for (int it = 0; it < A.cg_max;) {
-        float part2 = 0.f, part3 = 0.f;
-        int zs;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-        const int wz = wv + zs, tz = tid + zs;
-        spmv(wz, gxy, gz, part2, seed, part3);
-        CPH(3)
-        X.site = 6;
-        if (!xch_allsum<THREADS>(X, part2, part3, 0.f, sums)) return;
-        CPH(4)
-        const double pr = seed ? sums[1] : rz;
-        const float alpha = sums[0] > 1e-300 ? (float) (pr / sums[0]) : 0.f;
-        part2 = 0.f;
-        X.site = 7;
-        xch_begin(X);
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int l = tz + k * THREADS;
-          const int lc = min(l, R - 1);
-          const float2 pxy = gxy[HB + lc];
-          const float pv[3] = {pxy.x, pxy.y, gz[HB + lc]};
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            xx[k][c] = fmaf(alpha, pv[c], xx[k][c]);
-            rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
-            part2 = fmaf(rr[k][c], rr[k][c], part2);
-          }
-          if (l < R) xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
-        }
-        xch_publish_sums(X, part2, 0.f, 0.f);
-        CPH(5)
-        f3 hv[HPT];
-        if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
-        CPH(6)
-        const double rz_new = sums[0];
-        it++; cg_total++;
-        if (!(rz_new > stop)) break;
-        const float beta = seed ? 0.f : (float) (rz_new / rz);
-        seed = false;
-        rz = rz_new;
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int l = tz + k * THREADS;
-          if (l < R) {
-            const float2 pxy = gxy[HB + l];
-            gxy[HB + l] = make_float2(fmaf(beta, pxy.x, rr[k][0]), fmaf(beta, pxy.y, rr[k][1]));
-            gz[HB + l] = fmaf(beta, gz[HB + l], rr[k][2]);
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < HPT; q++) {         // the neighbours' boundary rows of p, updated here from their residual rows
-          const int j = tid + q * THREADS;
-          if (j < 2 * HB) {
-            const int li = j < HB ? j : R + j;
-            const float2 pxy = gxy[li];
-            gxy[li] = make_float2(fmaf(beta, pxy.x, hv[q].x), fmaf(beta, pxy.y, hv[q].y));
-            gz[li] = fmaf(beta, gz[li], hv[q].z);
-          }
-        }
-        __syncthreads();
-      }
-    }
-    // ---- update + convergence (Simulation.cpp:1268, 1310-1373); delta v replaces A p in its registers ----
-    psum = 0.f;
-#pragma unroll
-    for (int k = 0; k < VPT; k++) {
-      const int l = tq + k * THREADS, i = r0 + l;
-      const bool on = l < R && i < N;
-      const int ic = on ? i : r0;
-      const float sq = CL.sq_dinv[ic];
-      const f3 vq = ld3c(vnb, ic);
-      ap[k][0] = xx[k][0] * sq; ap[k][1] = xx[k][1] * sq; ap[k][2] = xx[k][2] * sq;
-      if (on) {
-        if (A.cg_seed) st3c(dpb, i, mk(xx[k][0], xx[k][1], xx[k][2]));
-        st3c(vnb, i, mk(vq.x + ap[k][0], vq.y + ap[k][1], vq.z + ap[k][2]));
-        psum = fmaf(ap[k][0], ap[k][0], psum); psum = fmaf(ap[k][1], ap[k][1], psum); psum = fmaf(ap[k][2], ap[k][2], psum);
-      }
-    }
-    X.site = 8;
-    xch_drain();                                  // the new v must have left the CU before the norm (= its hand-over flag) is published
-    if (!xch_allsum<THREADS>(X, psum, 0.f, 0.f, sums)) return;
-    xdiff = (double) h * sqrt(sums[0]) / (double) N;
-    CPH(7)
-    iters = iter + 1;
-    converged = xdiff < (double) A.fwd_tol;
-    if (xdiff < min_xdiff) {
-      since_progress = 0;
-      min_xdiff = xdiff;
-      improved = true;
-      best_is_current = true;
-    } else if (best_is_current) {
-      // first non-improving iteration after a minimum: the best iterate is the previous one = v - delta (delta is still in registers)
-      best_is_current = false;
-#pragma unroll
-      for (int k = 0; k < VPT; k++) {
-        const int l = tq + k * THREADS, i = r0 + l;
-        if (l < R && i < N) {
-          const f3 v = ld3c(vnb, i);
-          vbest[i] = v.x - ap[k][0]; vbest[N + i] = v.y - ap[k][1]; vbest[2 * N + i] = v.z - ap[k][2];
-        }
-      }
-    }
-    if (converged) break;
-    if (++since_progress >= A.stall_window) { stalled = true; break; }
-  }
-  // ---- write the new state of the own rows (revert to the best iterate when the cap was hit, Simulation.cpp:1357-1367) ----
-  const BufVec xob = buf_vec(A.x_out + off + so, N, X.same_xcd), vob = buf_vec(A.v_out + off + so, N, X.same_xcd);
-  for (int i = r0 + tid; i < r1; i += THREADS) {
-    f3 x = ld3c(xnb, i);
-    if (converged) { f3 v = ld3c(vnb, i); st3c(vob, i, v); st3c(xob, i, x + v * h); }
-    else if (improved) { f3 v = best_is_current ? ld3c(vnb, i) : ld3(vbest, i, N); st3c(vob, i, v); st3c(xob, i, x + v * h); }
-    else { st3c(vob, i, ld3c(vinb, i)); st3c(xob, i, x); }
-  }
-  if (tid == 0 && part == 0) {
-    dc_step_stats s;
-    s.converged = converged ? 1 : (stalled ? 2 : 0); s.pd_iters = iters; s.cg_iters = cg_total; s.prim_contacts = total_contacts;
-    s.self_contacts = nself; s.last_xdiff = (float) xdiff;
-    s.self_overflow = (S.contact_enabled && S.self_enabled) ? srec.meta[(size_t) b * kMetaStride + kMetaStride - 2] : 0;
-    A.stats[b + (size_t) step * A.slot_stats] = s;
-  }
-  CPH_PRINT
-  }   // step
-}
-
-template <int VPT, bool DETECT, bool PIPE>
-static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
-  constexpr int THREADS = 512;
-  const int GL = CL.R + 2 * CL.HB;
-  int floats = std::max((PIPE ? 6 : 3) * GL, CL.win_lds_bytes / 4);
-  const int fric_floats = floats;      // LDS offered to the layered friction pass: the same with and without the inlined detection
-  if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
-  const int tail_off = (floats + 3) / 4 * 4;
-  const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
-  if (lds > 160 * 1024 - 256) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute((const void *) k_pd_step_cl<THREADS, VPT, DETECT, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_pd_step_cl<THREADS, VPT, DETECT, PIPE>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, tail_off, fric_floats);
-  return hipGetLastError();
-}
+hipError_t launch_pd_step_cluster_deflated(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st);      // dc_forward_cl_defl.hip
 
 // nb rollouts starting at b0, K workgroups each; the caller has zeroed the exchange area and made sure K nb <= CUs. The grid is
 // rounded up to a multiple of 8 rollouts: with the observed round-robin placement (block b on XCD b % 8) the K parts of a rollout
@@ -501,6 +26,7 @@ hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, cons
   // (development switch). Measured r02v, C4 at 32 rollouts x 8 workgroups: forward 8.77 -> 7.99 ms per step (+8 % rollout-steps/s),
   // same PD / CG iteration counts — but its recurrences for A r, A p, A s drift in fp32: at N = 16 384 (36 iterations per solve)
   // the converged positions moved by 7e-5 against the fp64 oracle (bound 4.5e-5; the two-exchange CG: 1.2e-7). Parity first.
+  if (S.defl_u) return launch_pd_step_cluster_deflated(S, CL, W, A, b0, nb, st);
   static const bool pipe_ok = getenv("DC_PIPECG") && getenv("DC_PIPECG")[0] == '1';
 #define DC_CL_CASE(V) case V: if (pipe_ok && V <= 6) return A.inline_detect ? launch_cl_inst<V, true, (V <= 6)>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, (V <= 6)>(S, CL, W, A, b0, nb, st); \
                               return A.inline_detect ? launch_cl_inst<V, true, false>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, false>(S, CL, W, A, b0, nb, st);

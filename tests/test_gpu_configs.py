@@ -385,13 +385,16 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
     assert ea <= 1e-4 and et <= 1e-4
 
 
-def test_dress_7742_forward_solve_with_spectral_deflation(monkeypatch):
+@pytest.mark.parametrize("split", [False, True])
+def test_dress_7742_forward_solve_with_spectral_deflation(monkeypatch, split):
     """Jacobi-PCG needs ~260 iterations per PD iteration on the reference's fine dress (smooth, almost mass-only
     modes of the hanging garment: cond 5e4 after scaling). dc_build finds that with a probe solve and hands the one-workgroup forward kernel
     the 16 lowest eigenvectors of the scaled matrix; every solve starts with a Galerkin projection onto them (csrc/dc_deflate.h). Same step,
     same stopping rules: positions, contact set and PD iteration count must still be the oracle's, with a fraction of the PCG iterations.
-    (One workgroup per rollout is forced: the split kernels do not have the projection.)"""
-    monkeypatch.setenv("DC_CLUSTER", "1")
+    Both executions: one workgroup per rollout (what a batch of 256 gets) and the rollout split over 8 workgroups (what one rollout gets;
+    there U^T r is a sum over the parts: sixteen small exchanges per solve, dc_forward_cl_kernel.h)."""
+    if not split:
+        monkeypatch.setenv("DC_CLUSTER", "1")
     V, F = scenes.load_mesh("dress7k")
     cfg = dict(h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
     P, rmin, rmax = scenes.normalise_model(V, "FRONT", 8.0)
@@ -417,7 +420,7 @@ def test_dress_7742_forward_solve_with_spectral_deflation(monkeypatch):
         k, probe = e.deflation()
         assert (k, probe > 200) == ((16, True) if want < 0 else (0, False)), (want, k, probe)      # (switched off: no probe solve either)
         e.alloc_batch(B, 1)
-        assert e.cluster() == 1
+        assert e.cluster() == (8 if split else 1)
         e.set_state(0, X0, V0)
         e.timer_start()
         st = e.step_forward(0, fixed_pts=XF)
@@ -436,6 +439,6 @@ def test_dress_7742_forward_solve_with_spectral_deflation(monkeypatch):
         assert a["st"]["converged"][q] == 1 and ref["converged"]
         assert a["st"]["self_contacts"][q] == ref["nself"] and abs(int(a["st"]["pd_iters"][q]) - ref["iters"]) <= 2
         assert dx <= 8e-5
-    print(f"[dress 7742, deflated forward solve] PCG iterations per PD iteration {per_pd[0]:.0f} with the 16-vector deflation space, {per_pd[1]:.0f} without; "
+    print(f"[dress 7742, deflated forward solve, {8 if split else 1} workgroup(s)] PCG iterations per PD iteration {per_pd[0]:.0f} with the 16-vector deflation space, {per_pd[1]:.0f} without; "
           f"step time for {B} rollouts {a['ms']:.0f} ms / {b['ms']:.0f} ms")
     assert per_pd[0] <= 0.45 * per_pd[1]

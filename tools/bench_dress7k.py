@@ -57,6 +57,10 @@ def main():
     pd = np.mean([a["pd_iters"].mean() for a, _ in st]); cg = np.mean([a["cg_iters"].mean() for a, _ in st])
     sc = np.mean([a["self_contacts"].mean() for a, _ in st]); adj = np.mean([b["adjoint_iters"].mean() for _, b in st])
     conv = np.mean([(a["converged"] != 0).mean() for a, _ in st])
+    f64 = np.mean([b["fp64_iters"].mean() for _, b in st]); f64n = np.mean([(b["fp64_iters"] > 0).mean() for _, b in st])
+    cyc = np.mean([b["refine_cycles"].mean() for _, b in st]); bconv = np.mean([(b["converged"] != 0).mean() for _, b in st])
+    print(f"adjoint: fp32 BiCGSTAB {adj:.0f} iterations in {cyc:.1f} solves, fp64 fall-back in {f64n:.2f} of the solves ({f64:.0f} iterations on average), converged {bconv:.2f}; "
+          f"deflation {e.deflation()}")
     sc0 = e.get_self_contacts(S, 0, cap=16000)
     dx, dv, _ = e.get_gradient()
     print(f"dress7k twirl: N={e.N} T={e.T} rim {len(att)} vertices, B={B} x {e.cluster()} workgroups, steps {W}+{K}: {B * K / dt:.0f} rollout-steps/s, "
