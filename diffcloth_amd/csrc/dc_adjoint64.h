@@ -93,6 +93,8 @@ struct TeamOne {
     s[0] = sa; s[1] = sb; s[2] = sc;
     return true;
   }
+  // all-parts sums of n values every part holds in LDS (in place; `gather`: LDS for parts() x n values); ends with a barrier
+  __device__ __forceinline__ bool allsum_lds(double *, int, double *) { __syncthreads(); return true; }
   // access to y (plain: the workgroup's own L1 / L2 path)
   struct YV {
     double *p;
@@ -413,6 +415,73 @@ __device__ __forceinline__ d3 block_pre_d(const float *__restrict__ minv, int i,
              (double) minv[6 * N + i] * r.x + (double) minv[7 * N + i] * r.y + (double) minv[8 * N + i] * r.z);
 }
 
+// Preconditioner of the fall-back, dst = M^-1 src on the Team's rows: the inverted 3 x 3 diagonal blocks of K and — where the engine built a
+// deflation space for the forward solve (irregular garments, dc_deflate.h: the 16 lowest eigenvectors U of D^-1/2 P D^-1/2) — an additive
+// coarse correction over Z = D^-1/2 U per coordinate,  M^-1 = B^-1 + Z (Z^T P Z)^-1 Z^T : the smooth, mass-dominated modes that make P
+// ill-conditioned on those meshes are nearly the same for K = P - dP^T (dP acts on strain, those modes carry almost none). Offline on the
+// squashed dress-7742 step (scipy, fp64, 1e-7): 3 795 -> 624 BiCGSTAB iterations; the Galerkin operator of K itself instead of P's: 618.
+// Z^T src (48 values) is a sum over the Team: block sums in LDS, then ONE exchange of 48 fp64 granules per part (Team::allsum_lds). It has to
+// be fp64: the sums are differences of large terms and G multiplies them by 1 / lambda (1.6e4) — with fp32 partial sums the preconditioner
+// changed from application to application by ~1e-3 and BiCGSTAB (not a flexible method) went astray (NaN after 3 557 iterations, measured).
+// `lds`: kCoarseLdsFloats of scratch (the element windows' LDS, idle between operator applications).
+constexpr int kCoarseVectors = 16;
+constexpr int kCoarseLdsFloats = 2 * (16 * 3 * kCoarseVectors + 3 * kCoarseVectors);      // scratch of precondition64 in floats (16 = waves or parts, at most)
+template <int THREADS, class Team>
+__device__ __forceinline__ bool precondition64(const DevSystem &S, Team &tm, const float *__restrict__ minv, const double *src, double *dst, float *lds) {
+  const int N = S.N, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int DK = kCoarseVectors, NV = 3 * DK, NW = THREADS / 64;
+  double *red = (double *) lds;              // [NW][NV] wave sums; afterwards the Team's gather area [parts][NV]
+  double *vals = red + 16 * NV;              // [NV] Z^T src, then c = G Z^T src
+  const float4 DC_G *U4 = (const float4 DC_G *) S.defl_u;
+  __syncthreads();                           // (the scratch is the element windows' LDS: whoever used it last is done)
+  for (int j4 = 0; j4 < DK / 4; j4++) {
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+      const float4 u = U4[(size_t) i * (DK / 4) + j4];
+      const d3 q = ld3d(src, i, N) * (double) S.sq_dinv[i];
+      acc[0] += u.x * q.x; acc[1] += u.x * q.y; acc[2] += u.x * q.z;
+      acc[3] += u.y * q.x; acc[4] += u.y * q.y; acc[5] += u.y * q.z;
+      acc[6] += u.z * q.x; acc[7] += u.z * q.y; acc[8] += u.z * q.z;
+      acc[9] += u.w * q.x; acc[10] += u.w * q.y; acc[11] += u.w * q.z;
+    }
+#pragma unroll
+    for (int m = 0; m < 12; m++) {
+      double v = acc[m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) red[wv * NV + j4 * 12 + m] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < NV) {
+    double v = 0;
+    for (int w = 0; w < NW; w++) v += red[w * NV + tid];
+    vals[tid] = v;                           // entry (vector j, coordinate c) at 3 j + c
+  }
+  if (!tm.allsum_lds(vals, NV, red)) return false;      // fp64 across the parts: Z^T src is a difference of large terms and G amplifies it by 1 / lambda
+  double cj = 0;
+  if (tid < NV) {
+    const int j = tid / 3, c = tid - 3 * j;
+    for (int l = 0; l < DK; l++) cj += (double) S.defl_g[j * DK + l] * vals[l * 3 + c];
+  }
+  __syncthreads();
+  if (tid < NV) vals[tid] = cj;
+  __syncthreads();
+  for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
+    d3 z = mkd(0, 0, 0);
+    for (int j4 = 0; j4 < DK / 4; j4++) {
+      const float4 u = U4[(size_t) i * (DK / 4) + j4];
+      const double *c = vals + j4 * 12;
+      z.x += u.x * c[0] + u.y * c[3] + u.z * c[6] + u.w * c[9];
+      z.y += u.x * c[1] + u.y * c[4] + u.z * c[7] + u.w * c[10];
+      z.z += u.x * c[2] + u.y * c[5] + u.z * c[8] + u.w * c[11];
+    }
+    st3d(dst, i, N, block_pre_d(minv, i, N, ld3d(src, i, N)) + z * (double) S.sq_dinv[i]);
+  }
+  __syncthreads();       // (the scratch goes back to the operator)
+  return true;
+}
+
 // Fall-back: right-preconditioned BiCGSTAB in fp64 on K u = g, continuing from (W.u, W.r = g - K u, rr = |r|^2). Preconditioner:
 // the inverted 3 x 3 diagonal blocks of K in `minv` (dc_adjprecond.h; fp32 storage, applied in fp64). A breakdown (rho, omega or
 // rhat.v vanishing) restarts the recurrence from the current residual. Returns 1 when |r|^2 <= stop2 by the recurrence (the caller
@@ -434,10 +503,13 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
   double s3[3];
   double rho = rr;
   int restarts = 0;
+  const bool coarse = S.defl_u != nullptr && S.adj_coarse && C.lds_floats >= kCoarseLdsFloats;      // two-level preconditioner (precondition64)
   for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
     const d3 q = ld3d(W.r, i, N);
-    st3d(W.rhat, i, N, q); st3d(W.p, i, N, q); st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
+    st3d(W.rhat, i, N, q); st3d(W.p, i, N, q);
+    if (!coarse) st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
   }
+  if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1);
   if (!tm.barrier()) return ret(-1);
   for (int k = 0; k < kcap; k++) {
     if (rr <= stop2) return ret(1);
@@ -455,10 +527,15 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
       double ss = 0;
       for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
         const d3 s = ld3d(W.r, i, N) - ld3d(W.v, i, N) * alpha;
-        st3d(W.r, i, N, s); st3d(W.sh, i, N, block_pre_d(minv, i, N, s));
+        st3d(W.r, i, N, s);
+        if (!coarse) st3d(W.sh, i, N, block_pre_d(minv, i, N, s));
         ss += dot(s, s);
       }
       if (!tm.sum3(ss, 0, 0, s3)) return ret(-1);
+      if (coarse && s3[0] > stop2) {      // (the exchange of the sum above fenced sh in the plain case; here it is formed after it)
+        if (!precondition64<THREADS>(S, tm, minv, W.r, W.sh, C.lds)) return ret(-1);
+        if (!tm.barrier()) return ret(-1);
+      }
       iters++;
       if (s3[0] <= stop2) {
         for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) st3d(W.u, i, N, ld3d(W.u, i, N) + ld3d(W.ph, i, N) * alpha);
@@ -488,16 +565,20 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
         rho = rho_new;
         for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
           const d3 pn = ld3d(W.r, i, N) + (ld3d(W.p, i, N) - ld3d(W.v, i, N) * omega) * beta;
-          st3d(W.p, i, N, pn); st3d(W.ph, i, N, block_pre_d(minv, i, N, pn));
+          st3d(W.p, i, N, pn);
+          if (!coarse) st3d(W.ph, i, N, block_pre_d(minv, i, N, pn));
         }
+        if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1);
       }
     }
     if (restart) {
       if (++restarts > 50 || !isfinite(rr)) return ret(0);
       for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
         const d3 q = ld3d(W.r, i, N);
-        st3d(W.rhat, i, N, q); st3d(W.p, i, N, q); st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
+        st3d(W.rhat, i, N, q); st3d(W.p, i, N, q);
+        if (!coarse) st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
       }
+      if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1);
       rho = rr;
     }
     if (!tm.barrier()) return ret(-1);

@@ -56,6 +56,34 @@ struct TeamParts {
     s[0] = sa; s[1] = sb; s[2] = sc;
     return true;
   }
+  // all-parts sums of n <= 2 HB fp64 values every part holds in LDS (in place), ONE exchange: part p publishes value j as the 64 bits of a
+  // granule in its boundary-row slot j (no halo is in flight during the preconditioner), thread (p, j) of every part fetches it into
+  // `gather` [K][n] and the first n threads add the parts up in part order — identical totals everywhere. Needs n K <= THREADS.
+  __device__ __forceinline__ bool allsum_lds(double *vals, int n, double *gather) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    xch_begin(X);
+    if (tid < n) {
+      const double v = vals[tid];
+      v4i g = {__double2loint(v), __double2hiint(v), 0, (int) X.seq};
+      xch_store(X, g, xch_off(X, X.part, kXchWaves + tid));
+    }
+    bool ok = true;
+    if (tid < n * K_) {
+      v4i g;
+      ok = xch_poll(X, xch_off(X, tid / n, kXchWaves + tid % n), g);
+      gather[tid] = __hiloint2double(g.y, g.x);
+    }
+    if (!ok) *X.ldead = 1;
+    __syncthreads();
+    if (tid < n) {
+      double t = 0;
+      for (int p = 0; p < K_; p++) t += gather[p * n + tid];
+      vals[tid] = t;
+    }
+    __syncthreads();
+    return *X.ldead == 0;
+  }
   struct YV {
     __amdgpu_buffer_rsrc_t rs;
     bool same;

@@ -68,7 +68,8 @@ struct DevSystem {
   const int DC_C *pk_n;
   const float DC_G *sq_dinv;         // [pk_threads * pk_vpt] sqrt(1 / P_ii), 0 for padding rows
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
-  int pk_threads, pad3;         // threads of the packet kernel the tables are padded for (512 or 768)
+  int pk_threads;               // threads of the packet kernel the tables are padded for (512 or 768)
+  int adj_coarse;               // the adjoint's fp64 fall-back adds the coarse correction over the deflation space (dc_adjoint64.h)
   // spectral deflation of the forward solve (dc_deflate.h): 16 lowest eigenvectors of the scaled matrix, [pk rows][16] row-major; null = none
   const float DC_G *defl_u;
   const float DC_G *defl_au;         // Ahat U, same layout

@@ -764,6 +764,8 @@ int dc_build(dc_ctx *c) {
       if ((rc = upload<float>(c, &S.defl_g, HD.G))) return rc;
       c->defl_k = HD.k;
     }
+    static const char *envc = getenv("DC_ADJ_COARSE");      // development switch: 0 = block preconditioner only in the adjoint's fall-back
+    S.adj_coarse = (S.defl_u && !(envc && atoi(envc) == 0)) ? 1 : 0;
     c->defl_probe = HD.probe_iterations;
   }
   {  // small meshes: explicit inverse of the scaled matrix (dc_dense.h) for the forward global step

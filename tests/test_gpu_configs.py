@@ -367,6 +367,9 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
           f"{gb['fp64_iters'][0]} iterations, true relative residual {gb['last_udiff'][0]:.1e}; gradient rel err dx {rel(gb['dL_dx'][0], rb['dL_dx']):.2e} dv "
           f"{rel(gb['dL_dv'][0], rb['dL_dv']):.2e}; share of the difference in its 30 largest vertices {share:.3f}, rel err outside them {err_rest:.2e}")
     assert gb["converged"][0] == 1 and gb["fp64_iters"][0] > 0          # solved — by the fp64 fall-back
+    # ... whose preconditioner has the coarse correction over the forward solve's deflation space on this mesh (dc_adjoint64.h precondition64):
+    # 615 iterations where the 3 x 3 blocks alone need 4 635 (r04g, same build, DC_ADJ_COARSE=0; scipy on the oracle's K: 3 795 -> 624)
+    assert e.deflation()[0] == 16 and gb["fp64_iters"][0] <= 1500
     assert gb["last_udiff"][0] <= 1e-7                                   # the caller's tolerance (engine_for), on the residual evaluated in fp64
     assert np.isfinite(gb["dL_dx"]).all() and np.isfinite(gb["dL_dv"]).all()
     assert rel(gb["dL_dx"][0], rb["dL_dx"]) <= 1e-4 and rel(gb["dL_dv"][0], rb["dL_dv"]) <= 1e-4 and rel(gb["dL_dxfixed"][0], rb["dL_dxfixed"]) <= 1e-4

@@ -33,7 +33,9 @@ def main():
     S = W + K
     e.alloc_batch(B, S + 1)
     rng = np.random.default_rng(0)
-    X = np.stack([f32(P.reshape(-1) + 0.001 * rng.standard_normal(P.size)) for _ in range(B)])
+    # (1e-5: the fine regions of this garment hold ~380 non-connected vertex pairs inside the collision radii at rest; a perturbation of 1e-3 pushes
+    #  some of them through each other and the step of such a rollout explodes — in the fp64 oracle as well, it is the reference's algorithm)
+    X = np.stack([f32(P.reshape(-1) + 1e-5 * rng.standard_normal(P.size)) for _ in range(B)])
     e.set_state(0, X, np.zeros_like(X))
     # twirl: rim targets of step s = rest rim rotated by 0.02 (s + 1) rad about the vertical axis through the bounding-box mid point
     mid = 0.5 * (rmin + rmax)
@@ -57,6 +59,8 @@ def main():
     pd = np.mean([a["pd_iters"].mean() for a, _ in st]); cg = np.mean([a["cg_iters"].mean() for a, _ in st])
     sc = np.mean([a["self_contacts"].mean() for a, _ in st]); adj = np.mean([b["adjoint_iters"].mean() for _, b in st])
     conv = np.mean([(a["converged"] != 0).mean() for a, _ in st])
+    xs, vs = e.get_state(S)
+    print(f"largest |v| at the last step {np.abs(vs).max():.2f}, PD iterations per rollout at the last step {st[-1][0]['pd_iters']}")
     f64 = np.mean([b["fp64_iters"].mean() for _, b in st]); f64n = np.mean([(b["fp64_iters"] > 0).mean() for _, b in st])
     cyc = np.mean([b["refine_cycles"].mean() for _, b in st]); bconv = np.mean([(b["converged"] != 0).mean() for _, b in st])
     print(f"adjoint: fp32 BiCGSTAB {adj:.0f} iterations in {cyc:.1f} solves, fp64 fall-back in {f64n:.2f} of the solves ({f64:.0f} iterations on average), converged {bconv:.2f}; "
