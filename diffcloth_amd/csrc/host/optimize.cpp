@@ -148,7 +148,7 @@ void Simulation::resetSystemWithParams(BackwardTaskInformation &task, ParamInfo 
   if (task.dL_dmu && !primitives.empty()) {
     VecXd mu(primitives.size());
     for (size_t k = 0; k < primitives.size(); k++) mu[k] = primitives[k].mu;
-    if (dc_set_mu(ctx, mu.data()) != DC_OK) throw std::runtime_error(std::string("dc_set_mu: ") + dc_last_error(ctx));
+    forEachContext([&](dc_ctx *c) { if (dc_set_mu(c, mu.data()) != DC_OK) throw std::runtime_error(std::string("dc_set_mu: ") + dc_last_error(c)); });
   }
   resetSystem();
   if (task.dL_dx0 && param.x0.size() == 3 * (size_t) N) {

@@ -218,7 +218,10 @@ PYBIND11_MODULE(diffcloth_py, m) {
       // evaluation carry x, v, fixed points and statistics, loadRecordDetails(i) fetches f, r and the contact lists of record i
       .def_readwrite("deviceResidentRollouts", &Simulation::deviceResidentRollouts)
       .def("loadRecordDetails", &Simulation::loadRecordDetails)
-      .def_readwrite("controlPointSplines", &Simulation::controlPointSplines)    // sysMat[0].controlPointSplines of the reference
+      .def_readwrite("controlPointSplines", &Simulation::controlPointSplines)    // sysMat[0].controlPointSplines of the reference (the ACTIVE set's here)
+      .def_property_readonly("attachmentSetCount", &Simulation::attachmentSetCount)
+      .def_property_readonly("currentAttachmentSet", &Simulation::currentAttachmentSet)
+      .def_property_readonly("attachmentSetStartFrames", &Simulation::attachmentSetStartFrames)
       .def("resetSystemWithSplines", [](Simulation &s, const std::vector<Spline> &c) { s.resetSystem(c); })
       .def_readwrite("gradientClippingThreshold", &Simulation::gradientClippingThreshold)
       .def_readwrite("backwardGradientForceDirectSolver", &Simulation::backwardGradientForceDirectSolver)
@@ -324,10 +327,16 @@ PYBIND11_MODULE(diffcloth_py, m) {
   }, "read the v / f records of an OBJ file (flat xyz array, flat 0-based triangle array)", py::arg("file"));
   m.def("makeSim", &makeSim, "initialize a simulation instance", py::arg("exampleName"), py::arg("runBackward") = true);
   m.def("makeSimFromMesh",
-        [](const std::string &sceneName, const NpArr &verts, const std::vector<int> &tris, bool runBackward) {
-          return Simulation::createSystemFromMesh(sceneByName(sceneName), toVec(verts), tris, runBackward);
-        }, "additive: build a scene from an in-memory mesh (raw file coordinates) instead of an asset path",
-        py::arg("sceneName"), py::arg("verts"), py::arg("tris"), py::arg("runBackward") = true);
+        [](const std::string &sceneName, const NpArr &verts, const std::vector<int> &tris, bool runBackward,
+           const std::vector<std::pair<double, std::vector<int>>> &attachmentSets, int stepNum) {
+          SceneConfiguration cfg = sceneByName(sceneName);
+          if (!attachmentSets.empty()) { cfg.attachmentPoints = CUSTOM_ARRAY; cfg.customAttachmentVertexIdx = attachmentSets; }
+          if (stepNum > 0) cfg.stepNum = stepNum;
+          return Simulation::createSystemFromMesh(cfg, toVec(verts), tris, runBackward);
+        }, "additive: build a scene from an in-memory mesh (raw file coordinates) instead of an asset path; attachmentSets replaces the scene's "
+           "customAttachmentVertexIdx ((start fraction of the rollout, vertex indices) per set — the C++-only SceneConfiguration field of the reference)",
+        py::arg("sceneName"), py::arg("verts"), py::arg("tris"), py::arg("runBackward") = true,
+        py::arg("attachmentSets") = std::vector<std::pair<double, std::vector<int>>>(), py::arg("stepNum") = 0);
   m.def("makeOptimizeHelper", &makeOptimizeHelper, "initialize an optimize helper", py::arg("exampleName"));
   m.def("makeOptimizeHelperWithSim", &makeOptimizeHelperWithSim, "initialize an optimize helper", py::arg("exampleName"), py::arg("sim"));
   m.def("enableOpenMP", [](int n_threads) { (void) n_threads; std::printf("diffcloth_py (MI355X): host threads are not used by the GPU stepper\n"); },

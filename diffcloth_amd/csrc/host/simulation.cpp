@@ -78,7 +78,44 @@ void loadObj(const std::string &path, VecXd &verts, std::vector<int> &tris) {
 }  // namespace
 
 Simulation::~Simulation() {
-  if (ctx) dc_destroy(ctx);
+  forEachContext([](dc_ctx *c) { if (c) dc_destroy(c); });
+}
+
+// The active set's data live in the plain members (everything written for one set keeps working); switching stores them back and loads
+// the other set's. The contexts are NOT touched here: the caller hands the state over (selectSetForStep).
+void Simulation::activateSet(int i) {
+  if (i == currentSysmatId || i < 0 || i >= (int) attachmentSets.size()) return;
+  AttachmentSet &o = attachmentSets[currentSysmatId];
+  o.vertices = attachmentVertices; o.fixedRest = fixedPointRest; o.fixedCur = fixedPointCur; o.splines = controlPointSplines; o.ctx = ctx;
+  const AttachmentSet &n = attachmentSets[i];
+  attachmentVertices = n.vertices; fixedPointRest = n.fixedRest; fixedPointCur = n.fixedCur; controlPointSplines = n.splines; ctx = n.ctx;
+  currentSysmatId = i;
+  paramsFwdTol = paramsBwdTol = -1;        // the solver knobs of this context may be stale: pushParams sends them again
+}
+
+// Simulation::step, Simulation.cpp:1053-1068: the last set whose start frame has been reached (counted in records, the initial one
+// included) is the one this step runs with. The state the step starts from is handed to that set's context at the same tape slot.
+void Simulation::selectSetForStep() {
+  if (attachmentSets.size() < 2) return;
+  for (int i = (int) attachmentSets.size() - 1; i >= 0; i--)
+    if ((int) forwardRecords.size() >= attachmentSets[i].startFrameNum) {
+      if (i != currentSysmatId) {
+        activateSet(i);
+        const ForwardInformation &prev = forwardRecords.back();
+        check(ctx, dc_set_state(ctx, prev.deviceSlot, prev.x.data(), prev.v.data()), "dc_set_state (attachment set hand-over)");
+      }
+      break;
+    }
+}
+
+// createAttachments, Simulation.cpp:2389-2393: one spline per fixed point, start = end = its rest position
+std::vector<Spline> Simulation::restSplines(const std::vector<int> &vertices) const {
+  std::vector<Spline> r;
+  for (size_t a = 0; a < vertices.size(); a++) {
+    const Vec3d q = {rest[3 * (size_t) vertices[a]], rest[3 * (size_t) vertices[a] + 1], rest[3 * (size_t) vertices[a] + 2]};
+    r.emplace_back(q, q, 10, (int) a);
+  }
+  return r;
 }
 
 // rotatePointsAccordingToConfig + rotatePointsAroundCenter (Simulation.h:641-671, Simulation.cpp:2151-2168)
@@ -188,6 +225,24 @@ void Simulation::buildFromMesh(VecXd pts, const std::vector<int> &tr, bool isMod
   for (int a : attachmentVertices) for (int d = 0; d < 3; d++) fixedPointRest.push_back(rest[3 * a + d]);
   fixedPointCur = fixedPointRest;
   initScene();
+  // the reference's sysMat vector: one entry per attachment set (one for every configuration but CUSTOM_ARRAY with several entries)
+  attachmentSets.clear();
+  currentSysmatId = 0;
+  const size_t nsets = sceneConfig.attachmentPoints == CUSTOM_ARRAY ? std::max<size_t>(sceneConfig.customAttachmentVertexIdx.size(), 1) : 1;
+  attachmentSets.resize(nsets);
+  for (size_t si = 1; si < nsets; si++) {
+    AttachmentSet &a = attachmentSets[si];
+    const auto &cfgSet = sceneConfig.customAttachmentVertexIdx[si];
+    a.startFrameNum = (int) (cfgSet.first * sceneConfig.stepNum);
+    a.vertices = cfgSet.second;
+    for (int v : a.vertices) {
+      if (v < 0 || v >= N) throw std::runtime_error("customAttachmentVertexIdx: vertex index out of range");
+      for (int d = 0; d < 3; d++) a.fixedRest.push_back(rest[3 * (size_t) v + d]);
+    }
+    a.fixedCur = a.fixedRest;
+    a.splines = restSplines(a.vertices);
+  }
+  if (nsets > 1) attachmentSets[0].startFrameNum = (int) (sceneConfig.customAttachmentVertexIdx[0].first * sceneConfig.stepNum);
   configureDevice();
   resetSystem();
 }
@@ -314,9 +369,6 @@ void Simulation::resetSystem(const std::vector<Spline> &controlPoints) {   // Si
 }
 
 void Simulation::configureDevice() {
-  check(nullptr, dc_create(0, &ctx) == DC_OK ? DC_OK : DC_ERR_HIP, "dc_create (no HIP device: the stepper has no CPU path)");
-  check(ctx, dc_set_mesh(ctx, N, rest.data(), (int) tris.size() / 3, tris.data()), "dc_set_mesh");
-  check(ctx, dc_set_attachments(ctx, (int) attachmentVertices.size(), attachmentVertices.data()), "dc_set_attachments");
   std::vector<dc_primitive> flat;
   for (size_t g = 0; g < primitives.size(); g++) {
     const Primitive &p = primitives[g];
@@ -332,7 +384,6 @@ void Simulation::configureDevice() {
       for (const Primitive &q : p.primitives) add(q, {p.center[0] + q.centerInit[0], p.center[1] + q.centerInit[1], p.center[2] + q.centerInit[2]});
     else add(p, p.center);
   }
-  check(ctx, dc_set_primitives(ctx, (int) flat.size(), flat.data()), "dc_set_primitives");
   dc_params prm;
   dc_default_params(&prm);
   prm.time_step = sceneConfig.timeStep;
@@ -343,10 +394,20 @@ void Simulation::configureDevice() {
   prm.gravity_enabled = gravityEnabled; prm.contact_enabled = contactEnabled; prm.selfcollision_enabled = selfcollisionEnabled;
   prm.forward_tol = forwardConvergenceThreshold; prm.backward_tol = backwardConvergenceThreshold;
   prm.gradient_clipping = gradientClipping; prm.gradient_clipping_threshold = gradientClippingThreshold;
-  check(ctx, dc_set_params(ctx, &prm), "dc_set_params");
-  check(ctx, dc_build(ctx), "dc_build");
   tapeSlots = std::max(sceneConfig.stepNum, 1) + 8;
-  check(ctx, dc_alloc_batch(ctx, 1, tapeSlots), "dc_alloc_batch");
+  // one context per attachment set (set 0 = the active members)
+  for (size_t si = 0; si < std::max<size_t>(attachmentSets.size(), 1); si++) {
+    dc_ctx *c = nullptr;
+    check(nullptr, dc_create(0, &c) == DC_OK ? DC_OK : DC_ERR_HIP, "dc_create (no HIP device: the stepper has no CPU path)");
+    const std::vector<int> &att = si == 0 ? attachmentVertices : attachmentSets[si].vertices;
+    if (si == 0) ctx = c; else attachmentSets[si].ctx = c;
+    check(c, dc_set_mesh(c, N, rest.data(), (int) tris.size() / 3, tris.data()), "dc_set_mesh");
+    check(c, dc_set_attachments(c, (int) att.size(), att.data()), "dc_set_attachments");
+    check(c, dc_set_primitives(c, (int) flat.size(), flat.data()), "dc_set_primitives");
+    check(c, dc_set_params(c, &prm), "dc_set_params");
+    check(c, dc_build(c), "dc_build");
+    check(c, dc_alloc_batch(c, 1, tapeSlots), "dc_alloc_batch");
+  }
   paramsFwdTol = prm.forward_tol; paramsBwdTol = prm.backward_tol; paramsClip = gradientClipping;
   paramsClipThr = gradientClippingThreshold; paramsDirect = false;
 }
@@ -366,8 +427,10 @@ void Simulation::rebuildSystem() {
   prm.forward_tol = forwardConvergenceThreshold; prm.backward_tol = backwardConvergenceThreshold;
   prm.gradient_clipping = gradientClipping; prm.gradient_clipping_threshold = gradientClippingThreshold;
   prm.adjoint_mode = backwardGradientForceDirectSolver ? 1 : 0;
-  check(ctx, dc_set_params(ctx, &prm), "dc_set_params");
-  check(ctx, dc_build(ctx), "dc_build");
+  forEachContext([&](dc_ctx *c) {
+    check(c, dc_set_params(c, &prm), "dc_set_params");
+    check(c, dc_build(c), "dc_build");
+  });
   paramsFwdTol = prm.forward_tol; paramsBwdTol = prm.backward_tol; paramsClip = gradientClipping;
   paramsClipThr = gradientClippingThreshold; paramsDirect = backwardGradientForceDirectSolver;
 }
@@ -377,19 +440,22 @@ void Simulation::pushParams() {
   if (paramsFwdTol == forwardConvergenceThreshold && paramsBwdTol == backwardConvergenceThreshold &&
       paramsClip == gradientClipping && paramsClipThr == gradientClippingThreshold && paramsDirect == backwardGradientForceDirectSolver)
     return;
-  check(ctx, dc_set_solver(ctx, forwardConvergenceThreshold, backwardConvergenceThreshold, gradientClipping ? 1 : 0,
+  forEachContext([&](dc_ctx *c) {
+    check(c, dc_set_solver(c, forwardConvergenceThreshold, backwardConvergenceThreshold, gradientClipping ? 1 : 0,
                            gradientClippingThreshold, backwardGradientForceDirectSolver ? 1 : 0), "dc_set_solver");
+  });
   paramsFwdTol = forwardConvergenceThreshold; paramsBwdTol = backwardConvergenceThreshold; paramsClip = gradientClipping;
   paramsClipThr = gradientClippingThreshold; paramsDirect = backwardGradientForceDirectSolver;
 }
 
 void Simulation::setWindAncCollision(bool wind_, bool collision, bool selfCollision, bool) {
   windEnabled = wind_; contactEnabled = collision; selfcollisionEnabled = selfCollision;
-  check(ctx, dc_set_flags(ctx, gravityEnabled ? 1 : 0, contactEnabled ? 1 : 0, selfcollisionEnabled ? 1 : 0), "dc_set_flags");
+  forEachContext([&](dc_ctx *c) { check(c, dc_set_flags(c, gravityEnabled ? 1 : 0, contactEnabled ? 1 : 0, selfcollisionEnabled ? 1 : 0), "dc_set_flags"); });
 }
 
 // Simulation::resetSystem (Simulation.cpp:3490-3584 without the parameter overloads): back to the rest pose.
 void Simulation::resetSystem() {
+  activateSet(0);                      // currentSysmatId = 0 (Simulation.cpp:2841); only set 0's fixed points go back to rest (:2818-2826)
   forwardRecords.clear();
   perStepGradient.clear();
   ForwardInformation r0;
@@ -400,7 +466,7 @@ void Simulation::resetSystem() {
   r0.stepIdx = 0; r0.deviceSlot = 0; r0.t = 0;
   forwardRecords.push_back(r0);
   fixedPointCur = fixedPointRest;
-  check(ctx, dc_clear_schedules(ctx), "dc_clear_schedules");     // per-slot inputs of an earlier device-resident evaluation
+  forEachContext([&](dc_ctx *c) { check(c, dc_clear_schedules(c), "dc_clear_schedules"); });     // per-slot inputs of an earlier device-resident evaluation
   check(ctx, dc_set_state(ctx, 0, r0.x.data(), r0.v.data()), "dc_set_state");
 }
 
@@ -547,11 +613,13 @@ VecXd Simulation::fixedPointTargets(double t) {
 void Simulation::step() {
   if ((int) forwardRecords.size() >= tapeSlots) throw std::runtime_error("Simulation::step: tape exhausted (stepNum + 8 records)");
   const auto tStart = std::chrono::steady_clock::now();
+  selectSetForStep();
   pushParams();
   const ForwardInformation &prev = forwardRecords.back();
   ForwardInformation rec;
   rec.t = prev.t + sceneConfig.timeStep;
   rec.stepIdx = (int) forwardRecords.size();
+  rec.sysMatId = currentSysmatId;
   rec.deviceSlot = prev.deviceSlot + 1;
   rec.x_prev = prev.x; rec.v_prev = prev.v;
   rec.windFactor = windFactorAt(rec.t, rec.stepIdx);       // (the reference indexes perstepWindFactor by forwardRecords.size())
@@ -637,6 +705,13 @@ bool Simulation::needsForceVector(const BackwardTaskInformation &taskInfo) const
 
 BackwardInformation Simulation::stepBackward(BackwardTaskInformation &taskInfo, BackwardInformation &gradient_new,
                                              const ForwardInformation &fwd, bool isStart, const VecXd &dL_dxinit, const VecXd &dL_dvinit) {
+  // the record's own system matrix (SystemMatrix &currentSysMat = sysMat[forwardInfo_new.sysMatId], Simulation.cpp:1482): its context
+  // holds the tape slot of this step; the set active for stepping is restored afterwards
+  struct SetGuard {
+    Simulation *s; int keep;
+    SetGuard(Simulation *s_, int want) : s(s_), keep(s_->currentSysmatId) { s->activateSet(want); }
+    ~SetGuard() { s->activateSet(keep); }
+  } guard(this, fwd.sysMatId);
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
   if (gradient_new.dL_dx.size() != n3 || gradient_new.dL_dv.size() != n3) throw std::runtime_error("stepBackward: gradient size mismatch");
   if (fwd.deviceSlot < 1 || fwd.deviceSlot >= (int) forwardRecords.size() + 1) throw std::runtime_error("stepBackward: record has no device slot");
@@ -685,10 +760,11 @@ BackwardInformation Simulation::accumulateBackward(BackwardTaskInformation &task
       for (size_t k = 0; k < 3 * Af; k++) ret.dL_dxfixed_accum[k] = ret.dL_dxfixed[k] + gradient_new.dL_dxfixed_accum[k];
     // spline parameters (:1658-1669): dL_dspline += (dx_fixed/dparams)^T dL_dx_fixed of the driven point
     ret.dL_dsplines = gradient_new.dL_dsplines;
-    if (ret.dL_dsplines.empty()) ret.dL_dsplines.assign(1, {});
-    if (ret.dL_dsplines[0].size() != controlPointSplines.size()) {
-      ret.dL_dsplines[0].clear();
-      for (const Spline &sp : controlPointSplines) ret.dL_dsplines[0].push_back(VecXd(sp.getParameterNumber(), 0.0));
+    const size_t sid = (size_t) std::max(fwd.sysMatId, 0);      // ret.dL_dsplines[sysMatId][splineIdx] (:1668)
+    if (ret.dL_dsplines.size() <= sid) ret.dL_dsplines.resize(std::max<size_t>(sid + 1, attachmentSets.size()));
+    if (ret.dL_dsplines[sid].size() != controlPointSplines.size()) {
+      ret.dL_dsplines[sid].clear();
+      for (const Spline &sp : controlPointSplines) ret.dL_dsplines[sid].push_back(VecXd(sp.getParameterNumber(), 0.0));
     }
     for (size_t k = 0; k < controlPointSplines.size(); k++) {
       const Spline &sp = controlPointSplines[k];
@@ -696,7 +772,7 @@ BackwardInformation Simulation::accumulateBackward(BackwardTaskInformation &task
       const int np = sp.getParameterNumber();
       std::vector<double> J = sp.dxfixed_dcontrolPoints(fwd.simDurartionFraction);
       for (int q = 0; q < np; q++)
-        for (int dd = 0; dd < 3; dd++) ret.dL_dsplines[0][k][q] += J[(size_t) dd * np + q] * dxf[3 * (size_t) sp.pFixed + dd];
+        for (int dd = 0; dd < 3; dd++) ret.dL_dsplines[sid][k][q] += J[(size_t) dd * np + q] * dxf[3 * (size_t) sp.pFixed + dd];
     }
   }
   ret.dL_ddensity = gradient_new.dL_ddensity;
@@ -752,6 +828,7 @@ bool Simulation::rolloutOnDevice(int nsteps) {
   static const bool envOff = std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS") && std::getenv("DIFFCLOTH_DEVICE_ROLLOUTS")[0] == '0';
   if (!deviceResidentRollouts || envOff || nsteps < 1 || forwardRecords.empty()) return false;
   if (sceneConfig.trajectory == PER_STEP_TRAJECTORY) return false;          // the targets of a step arrive with the step (RL action)
+  if (attachmentSets.size() > 1) return false;                               // the system matrix changes inside the rollout: per-step path
   if ((int) forwardRecords.size() + nsteps > tapeSlots) throw std::runtime_error("Simulation::rolloutOnDevice: tape exhausted (stepNum + 8 records)");
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
   const bool fallOff = windEnabled && windHasFallOff() && windFallOff.size() == n3;
@@ -849,6 +926,7 @@ std::vector<BackwardInformation> Simulation::sweepBackwardOnDevice(BackwardTaskI
   if (!deviceResidentRollouts || envOff || frames < 2 || (int) seeds.size() != frames) return {};
   const bool needVec = needsForceVector(taskInfo);  // the per-vertex force gradient of every step: kept per tape slot by the sweep (dc_keep_force_gradients)
   if (forwardRecords[0].deviceSlot != 0) return {};      // isStart of the sweep is tied to tape slot 1
+  if (attachmentSets.size() > 1) return {};              // several system matrices: the per-step loop picks the context of each record
   for (int i = 1; i < frames; i++) if (forwardRecords[i].deviceSlot != forwardRecords[i - 1].deviceSlot + 1) return {};
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
   const auto tStart = std::chrono::steady_clock::now();

@@ -280,6 +280,11 @@ class Simulation {
   const std::vector<int> &triangles() const { return tris; }
   const std::vector<int> &attachments() const { return attachmentVertices; }
   dc_ctx *context() const { return ctx; }
+  // Several attachment sets (SceneConfiguration::customAttachmentVertexIdx with more than one entry; the reference's sysMat vector,
+  // Simulation.cpp:2371-2393): set i takes over at record startFrameNum_i = (int) (fraction_i * stepNum) (Simulation::step, :1053-1068).
+  int attachmentSetCount() const { return (int) attachmentSets.size(); }
+  int currentAttachmentSet() const { return currentSysmatId; }
+  std::vector<int> attachmentSetStartFrames() const { std::vector<int> r; for (const auto &a : attachmentSets) r.push_back(a.startFrameNum); return r; }
 
  private:
   Simulation() {}
@@ -295,6 +300,26 @@ class Simulation {
   bool needsForceVector(const BackwardTaskInformation &taskInfo) const;
   double windFactorAt(double t, int stepIdx) const;
   bool windHasFallOff() const { return sceneConfig.windConfig == WIND_SIN_AND_FALLOFF || sceneConfig.windConfig == WIND_FACTOR_PER_STEP; }
+
+  // One attachment set = one system matrix of the reference (SystemMatrix: its fixed points, attachment springs, splines, P). Here: one
+  // engine context per set (same mesh, primitives and parameters; its own attachment rows in P, its own tape). The members
+  // attachmentVertices / fixedPointRest / fixedPointCur / controlPointSplines / ctx are the ACTIVE set's; activateSet swaps them.
+  struct AttachmentSet {
+    int startFrameNum = 0;
+    std::vector<int> vertices;
+    VecXd fixedRest, fixedCur;
+    std::vector<Spline> splines;
+    dc_ctx *ctx = nullptr;
+  };
+  std::vector<AttachmentSet> attachmentSets;
+  int currentSysmatId = 0;
+  void activateSet(int i);
+  void selectSetForStep();              // Simulation::step, Simulation.cpp:1053-1068
+  template <class F> void forEachContext(F f) {
+    for (size_t i = 0; i < attachmentSets.size(); i++) f((int) i == currentSysmatId ? ctx : attachmentSets[i].ctx);
+    if (attachmentSets.empty() && ctx) f(ctx);
+  }
+  std::vector<Spline> restSplines(const std::vector<int> &vertices) const;
 
   dc_ctx *ctx = nullptr;
   int N = 0, tapeSlots = 0;

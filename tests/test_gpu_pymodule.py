@@ -306,3 +306,83 @@ def test_device_resident_evaluation_equals_the_per_step_loops(demo, mesh, steps)
     assert a["loss"] == b["loss"] and a["pd"] == b["pd"] and a["iters"] == b["iters"] and a["conv"] == b["conv"]
     assert err <= 1e-6
     np.testing.assert_allclose(a["dx0"], b["dx0"], rtol=1e-6, atol=1e-12 * max(np.abs(b["dx0"]).max(), 1e-30))
+
+
+def test_several_attachment_sets_switch_the_system_matrix():
+    """SceneConfiguration::customAttachmentVertexIdx with more than one entry (a C++-only field of the reference; the shipped scenes have one):
+    one SystemMatrix per set (createAttachments, Simulation.cpp:2371-2393), set i takes over at record (int) (fraction_i * stepNum)
+    (Simulation::step, :1053-1068), its fixed points sit at their REST positions with rest -> rest splines, and stepBackward differentiates a
+    record with the system matrix it was made with (sysMat[forwardInfo_new.sysMatId], :1482; dL_dsplines[sysMatId], :1668). Here: one engine
+    context per set, state handed over at the switch. Checked against two fp64 oracles (one per attachment set) composed the same way."""
+    import diffcloth_py as d
+    V, F = scenes.load_mesh("hat")
+    cfg = scenes.HAT
+    P, rmin, rmax = scenes.normalise_model(V, cfg["orientation"], cfg["cloth_dim"])
+    set0 = list(cfg["attachments"])
+    order = np.argsort(P[:, 1])
+    set1 = [int(order[0]), int(order[len(order) // 2]), int(order[-1])]
+    assert not set(set0) & set(set1)
+    sim = d.makeSimFromMesh("wear_hat", V.reshape(-1), F.reshape(-1).tolist(), True, [(0.0, set0), (0.005, set1)], 600)
+    assert sim.attachmentSetCount == 2 and sim.attachmentSetStartFrames == [0, 3] and sim.currentAttachmentSet == 0
+    helper = d.makeOptimizeHelperWithSim("wear_hat", sim)
+    d.Simulation.forwardConvergenceThreshold = 1e-8
+    d.Simulation.backwardConvergenceThreshold = 1e-9
+    sim.gradientClipping = False
+    sim.backwardGradientForceDirectSolver = True
+    sim.resetSystem()
+    oracles = []
+    for att in (set0, set1):
+        o = orc.Oracle(P, F, h=cfg["h"], density=cfg["density"], k_stretch=cfg["k_stretch"], k_bend=cfg["k_bend"], fwd_tol=1e-8, bwd_tol=1e-9,
+                       attachments=att, selfcollision=False, gradient_clipping=False)
+        o.add_sphere(scenes.hat_head_center(rmin, rmax, cfg["sphere_radius"]), cfg["sphere_radius"], cfg["sphere_mu"])
+        oracles.append(o.build())
+    S = 5
+    rec = sim.getStateInfo()
+    x, v = f32(rec.x), f32(rec.v)
+    refs, used = [], []
+    for s in range(1, S + 1):
+        sim.step()
+        new = sim.getStateInfo()
+        want_set = 0 if s + 0 < 3 else 1                       # records before the step: s; the step runs with set 1 once s >= 3
+        assert new.sysMatId == want_set and sim.currentAttachmentSet == want_set, (s, new.sysMatId)
+        xf = np.asarray(new.x_fixedpoints)
+        assert xf.size == 3 * (2 if want_set == 0 else 3)
+        if want_set == 1:      # rest -> rest splines with yUp = 10 (createAttachments :2391): the new clips sit above their rest positions, on the curve
+            want = np.stack([sp.evalute(new.simDurartionFraction) for sp in sim.controlPointSplines])
+            np.testing.assert_allclose(xf.reshape(-1, 3), want, atol=1e-12)
+            np.testing.assert_allclose(want[:, [0, 2]], P[set1][:, [0, 2]], atol=1e-12)
+            assert (want[:, 1] > P[set1][:, 1]).all()
+        ref = oracles[want_set].step(x, v, xf)                  # teacher-forced on the sim's previous state
+        print(f"step {s}: set {want_set}, PD iterations {new.convergeIter} / {ref['iters']}, converged {new.converged} / {ref['converged']}, max|dx| {np.abs(new.x - ref['x']).max():.2e}")
+        assert new.converged and ref["converged"] and np.abs(new.x - ref["x"]).max() < 6e-5, s
+        refs.append(ref); used.append(want_set)
+        x, v = f32(new.x), f32(new.v)
+    assert used == [0, 0, 1, 1, 1]
+    assert len(sim.controlPointSplines) == 3                    # the active set's
+    # backward sweep: every record with its own system matrix
+    rng = np.random.default_rng(3)
+    gx = f32(rng.standard_normal(x.size) * 1e-2); gv = f32(rng.standard_normal(x.size) * 1e-4)
+    z = np.zeros_like(gx)
+    back = None
+    ogx, ogv = gx, gv
+    for s in range(S, 0, -1):
+        rec = sim.getPastStateInfo(s)
+        back = sim.stepBackwardNN(helper.taskInfo, gx, gv, rec, s == 1, z, z) if back is None else sim.stepBackward(helper.taskInfo, back, rec, s == 1, z, z)
+        rb = oracles[used[s - 1]].step_backward(refs[s - 1]["id"], ogx, ogv, is_start=(s == 1), direct=True)
+        assert back.dL_dxfixed.size == 3 * (2 if used[s - 1] == 0 else 3)
+        for name in ("dL_dx", "dL_dv", "dL_dxfixed"):
+            got, want = np.asarray(getattr(back, name)), rb[name]
+            err = np.linalg.norm(got - want) / np.linalg.norm(want)
+            print(f"backward of step {s} (set {used[s - 1]}): {name} rel err {err:.2e}")
+            assert err <= 1e-4, (s, name, err)
+        ogx, ogv = f32(back.dL_dx), f32(back.dL_dv)             # the oracle continues from the sim's carried gradient (teacher forcing)
+    assert sim.currentAttachmentSet == 1                        # differentiating old records does not change the stepping state
+    ds = back.dL_dsplines
+    assert len(ds) == 2 and len(ds[0]) == 2 and len(ds[1]) == 3
+    assert all(np.linalg.norm(g) > 0 for g in ds[0]) and all(np.linalg.norm(g) > 0 for g in ds[1])
+    # a reset goes back to set 0 (currentSysmatId = 0, Simulation.cpp:2841) and the same steps give the same states
+    sim.resetSystem()
+    assert sim.currentAttachmentSet == 0
+    for s in range(1, S + 1):
+        sim.step()
+    np.testing.assert_array_equal(np.asarray(sim.getStateInfo().x), np.asarray(new.x))
