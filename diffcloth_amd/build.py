@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, "libdiffcloth_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-ENGINE_SOURCES = ["dc_forward.hip", "dc_forward_res.hip", "dc_forward_pk.hip", "dc_forward_pk_defl.hip", "dc_forward_cl.hip", "dc_forward_cl_defl.hip", "dc_adjoint.hip", "dc_adjoint_cl.hip", "dc_selfcontact.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp", "dc_windows.cpp", "dc_packets.cpp", "dc_dense.cpp", "dc_deflate.cpp"]
+ENGINE_SOURCES = ["dc_forward.hip", "dc_forward_res.hip", "dc_forward_pk.hip", "dc_forward_pk_defl.hip", "dc_forward_cl.hip", "dc_forward_cl_defl.hip", "dc_adjoint.hip", "dc_adjoint_cl.hip", "dc_selfcontact.hip", "dc_convert.hip", "dc_engine.hip", "dc_system.cpp", "dc_windows.cpp", "dc_packets.cpp", "dc_dense.cpp", "dc_deflate.cpp", "dc_spheremesh.cpp"]
 
 
 def _stale(target, deps):

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffcloth_hip.so")
 
-DC_PRIM_SPHERE, DC_PRIM_CAPSULE, DC_PRIM_PLANE, DC_PRIM_BOWL = 0, 1, 2, 3
+DC_PRIM_SPHERE, DC_PRIM_CAPSULE, DC_PRIM_PLANE, DC_PRIM_BOWL, DC_PRIM_SPHERE_DISCRETIZED = 0, 1, 2, 3, 4
 
 
 class DcError(RuntimeError):

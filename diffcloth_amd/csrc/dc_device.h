@@ -70,6 +70,8 @@ struct DevSystem {
   int pk_vpt, pk_ok;            // rows per thread of the packet kernel; 0 = tables not usable (bandwidth > 511 or N too large)
   int pk_threads;               // threads of the packet kernel the tables are padded for (512 or 768)
   int adj_coarse;               // the adjoint's fp64 fall-back adds the coarse correction over the deflation space (dc_adjoint64.h)
+  const double DC_G *dsph_tri;  // discretised sphere (DC_PRIM_SPHERE_DISCRETIZED): [dsph_ntri][12] = p0, p1, p2, face normal of its mesh, creation order
+  int dsph_ntri, dsph_pad;
   // spectral deflation of the forward solve (dc_deflate.h): 16 lowest eigenvectors of the scaled matrix, [pk rows][16] row-major; null = none
   const float DC_G *defl_u;
   const float DC_G *defl_au;         // Ahat U, same layout

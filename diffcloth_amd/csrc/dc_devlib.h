@@ -111,7 +111,7 @@ __device__ __forceinline__ f3 dri_dmu(f3 n, f3 d, float mu) {
 __device__ __forceinline__ bool prim_in_contact(const DevPrim &p, f3 pos, f3 &normal) {
   f3 c = mk(p.cx, p.cy, p.cz);
   f3 q = pos - c;
-  if (p.kind == DC_PRIM_SPHERE) {
+  if (p.kind == DC_PRIM_SPHERE || p.kind == DC_PRIM_SPHERE_DISCRETIZED) {      // (discretised: the normal is replaced by detect_primitive)
     float dist = sqrtf(dot(q, q)) - p.radius;
     normal = normalized(q);
     return dist < 0.1f;
@@ -172,6 +172,29 @@ __device__ __forceinline__ bool prim_in_contact(const DevPrim &p, f3 pos, f3 &no
   else { f3 e = q - pr; dist = sqrtf(dot(e, e)) - (p.radius + 0.1f); normal = normalized(e); }
   return dist < 0.1f;
 }
+// Sphere::isInContact, discretized branch (Primitive.cpp:230-253): the contact normal becomes the face normal of the LAST triangle (creation
+// order) of the sphere's own mesh whose prism holds the point (Primitive::pointInsideTriangle, Primitive.h:176-190: all barycentric weights
+// in [0, 1]) and whose "projection" — alpha p1 + beta p2 + gamma p0, the reference's weights on the wrong corners, kept — is closer than the
+// radius (that rules out the antipodal face). Inside / outside is a comparison against 0: done in fp64 like the reference, on the sample point
+// re-formed in fp64 from its fp32 terms. Runs once per contacting vertex and step (3 120 faces at the reference's resolution).
+__device__ __attribute__((noinline)) void sphere_mesh_normal(const DevSystem &S, const DevPrim &p, double qx, double qy, double qz, f3 &normal) {
+  const double DC_G *T = S.dsph_tri;
+  const double r = (double) p.radius;
+  for (int t = 0; t < S.dsph_ntri; t++, T += 12) {
+    const double ax = T[0], ay = T[1], az = T[2];
+    const double abx = T[3] - ax, aby = T[4] - ay, abz = T[5] - az, acx = T[6] - ax, acy = T[7] - ay, acz = T[8] - az;
+    const double nx = aby * acz - abz * acy, ny = abz * acx - abx * acz, nz = abx * acy - aby * acx;
+    const double n2 = nx * nx + ny * ny + nz * nz;
+    const double apx = qx - ax, apy = qy - ay, apz = qz - az;
+    const double alpha = ((aby * apz - abz * apy) * nx + (abz * apx - abx * apz) * ny + (abx * apy - aby * apx) * nz) / n2;
+    const double beta = ((apy * acz - apz * acy) * nx + (apz * acx - apx * acz) * ny + (apx * acy - apy * acx) * nz) / n2;
+    const double gamma = 1.0 - alpha - beta;
+    if (!(alpha >= 0 && beta >= 0 && gamma >= 0 && gamma <= 1 && alpha <= 1 && beta <= 1)) continue;
+    const double px = alpha * T[3] + beta * T[6] + gamma * ax, py = alpha * T[4] + beta * T[7] + gamma * ay, pz = alpha * T[5] + beta * T[8] + gamma * az;
+    const double dx = qx - px, dy = qy - py, dz = qz - pz;
+    if (sqrt(dx * dx + dy * dy + dz * dz) < r) normal = mk((float) T[9], (float) T[10], (float) T[11]);
+  }
+}
 // Simulation::isInContactWithObstacle (Simulation.cpp:153-191): t = 0, h/2, h; first primitive / first sample wins.
 // Children of one LowerLeg share a group and are tested, per sample, in child order (Primitive.cpp:410-418).
 // (not inlined: it runs once per vertex and step, and its plane / capsule branches must not weigh on the register allocation
@@ -184,7 +207,14 @@ __device__ __attribute__((noinline)) int detect_primitive(const DevSystem &S, f3
     for (int k = 0; k < 3; k++) {
       f3 q = pos + vel * (S.h * 0.5f * (float) k);
       for (int p = p0; p < p1; p++)
-        if (prim_in_contact(S.prims[p], q, normal)) return p;
+        if (prim_in_contact(S.prims[p], q, normal)) {
+          if (S.prims[p].kind == DC_PRIM_SPHERE_DISCRETIZED && S.dsph_ntri > 0) {
+            const double ts = S.h64 * (0.5 * (double) k);
+            sphere_mesh_normal(S, S.prims[p], (double) pos.x + (double) vel.x * ts - (double) S.prims[p].cx, (double) pos.y + (double) vel.y * ts - (double) S.prims[p].cy,
+                               (double) pos.z + (double) vel.z * ts - (double) S.prims[p].cz, normal);
+          }
+          return p;
+        }
     }
     p0 = p1;
   }

@@ -24,6 +24,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 #include "dc_packets.h"
 #include "dc_dense.h"
 #include "dc_deflate.h"
+#include "dc_spheremesh.h"
 #include "dc_selftmp.h"
 #include "dc_cluster.h"
 
@@ -559,6 +560,15 @@ int dc_set_params(dc_ctx *c, const dc_params *p) {
 int dc_set_primitives(dc_ctx *c, int count, const dc_primitive *prims) {
   if (!c || count < 0 || count > kMaxPrims) return fail(c, DC_ERR_INVALID, "dc_set_primitives: at most 8 flattened primitives");
   if (count > 0 && !prims) return fail(c, DC_ERR_INVALID, "dc_set_primitives: null primitive array");
+  int discretised = 0;
+  for (int k = 0; k < count; k++) {
+    if (prims[k].kind < DC_PRIM_SPHERE || prims[k].kind > DC_PRIM_SPHERE_DISCRETIZED) return fail(c, DC_ERR_INVALID, "dc_set_primitives: unknown primitive kind");
+    if (prims[k].kind == DC_PRIM_SPHERE_DISCRETIZED) {
+      discretised++;
+      if (!(prims[k].radius > 0) || prims[k].length < 0 || prims[k].length > 512) return fail(c, DC_ERR_INVALID, "dc_set_primitives: discretised sphere needs radius > 0 and a resolution (length) of 0 or 3 ... 512");
+    }
+  }
+  if (discretised > 1) return fail(c, DC_ERR_INVALID, "dc_set_primitives: at most one discretised sphere per context");
   c->prims.assign(prims, prims + count);
   // compact the caller's group ids to 0..ngroups-1 in order of first appearance
   std::vector<int> seen;
@@ -787,8 +797,15 @@ int dc_build(dc_ctx *c) {
   for (int k = 0; k < 3; k++) S.g64[k] = p.gravity_enabled ? p.gravity[k] : 0.0;
   S.contact_enabled = p.contact_enabled; S.self_enabled = p.selfcollision_enabled;
   S.nprim = (int) c->prims.size(); S.ngroups = std::max(c->ngroups, 1);
+  S.dsph_tri = nullptr; S.dsph_ntri = 0; S.dsph_pad = 0;
   for (int k = 0; k < S.nprim; k++) {
     const dc_primitive &q = c->prims[k];
+    if (q.kind == DC_PRIM_SPHERE_DISCRETIZED) {      // the face table of the sphere's own mesh (Sphere::Sphere, Primitive.cpp:133-216)
+      const int res = q.length >= 3 ? (int) q.length : 40;
+      const std::vector<double> tab = sphere_mesh_table(q.radius, res);
+      if ((rc = upload<double>(c, &S.dsph_tri, tab))) return rc;
+      S.dsph_ntri = (int) tab.size() / 12;
+    }
     DevPrim &d = S.prims[k];
     d.kind = q.kind; d.group = c->group_of_prim[k]; d.rotates = q.rotates; d.pad = 0;
     d.cx = (float) q.center[0]; d.cy = (float) q.center[1]; d.cz = (float) q.center[2]; d.radius = (float) q.radius;

@@ -268,6 +268,7 @@ void Simulation::initScene() {
     }
     case BIG_SPHERE: {              // :1905-1912
       Primitive s; s.type = SPHERE; s.radius = 15; s.mu = 0.0; s.center = s.centerInit = {-0.50, -16.00, 0.00};
+      s.discretized = true;         // veryBigSphere.discretized = true (:1910)
       primitives.push_back(s);
       break;
     }
@@ -374,7 +375,7 @@ void Simulation::configureDevice() {
     const Primitive &p = primitives[g];
     auto add = [&](const Primitive &q, const Vec3d &c) {
       dc_primitive d{};
-      d.kind = q.type == CAPSULE ? DC_PRIM_CAPSULE : (q.type == PLANE ? DC_PRIM_PLANE : (q.type == BOWL ? DC_PRIM_BOWL : DC_PRIM_SPHERE));
+      d.kind = q.type == CAPSULE ? DC_PRIM_CAPSULE : (q.type == PLANE ? DC_PRIM_PLANE : (q.type == BOWL ? DC_PRIM_BOWL : (q.discretized ? DC_PRIM_SPHERE_DISCRETIZED : DC_PRIM_SPHERE)));
       d.group = (int) g;
       for (int k = 0; k < 3; k++) { d.center[k] = c[k]; d.top_offset[k] = q.type == PLANE ? q.upperLeft[k] : q.topOffset[k]; d.corner2[k] = q.upperRight[k]; }
       d.radius = q.radius; d.length = q.length; d.mu = p.mu; d.rotates = q.rotates;

@@ -62,6 +62,7 @@ struct Primitive {                // the fields of Primitive.h the Python side r
   Vec3d center = {0, 0, 0}, centerInit = {0, 0, 0};
   double radius = 1, length = 0, mu = 0;
   bool rotates = false, isPrimitiveCollection = false;
+  bool discretized = false;       // Sphere::discretized (Primitive.h:222): face normals of the sphere's mesh as contact normals
   Vec3d topOffset = {0, 0, 0};
   Vec3d upperLeft = {0, 0, 0}, upperRight = {0, 0, 0};   // PLANE: two corners relative to the centre (Primitive.cpp:13-21)
   std::vector<Primitive> primitives;            // children of a LowerLeg

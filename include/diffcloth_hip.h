@@ -29,7 +29,10 @@ typedef struct dc_ctx dc_ctx;
 enum { DC_OK = 0, DC_ERR_INVALID = 1, DC_ERR_HIP = 2, DC_ERR_STATE = 3, DC_ERR_TOPOLOGY = 4, DC_ERR_CAPACITY = 5 };
 
 /* Primitive kinds (Primitive.h PrimitiveType; only the analytic isInContact family is on the hot path). */
-enum { DC_PRIM_SPHERE = 0, DC_PRIM_CAPSULE = 1, DC_PRIM_PLANE = 2, DC_PRIM_BOWL = 3 };
+enum { DC_PRIM_SPHERE = 0, DC_PRIM_CAPSULE = 1, DC_PRIM_PLANE = 2, DC_PRIM_BOWL = 3,
+       DC_PRIM_SPHERE_DISCRETIZED = 4   /* Sphere with discretized = true (Primitive.cpp:230-253; the BIG_SPHERE scene, Simulation.cpp:1905-1911):
+                                           contact normal = face normal of the sphere's own latitude / longitude mesh; `length` = its
+                                           resolution (0 = the reference's 40). At most one per context. */ };
 
 /* One analytic obstacle. A LowerLeg (Primitive.cpp:383-418) is passed as its three children
  * (joint sphere, foot capsule, leg capsule) sharing one `group`; friction uses the group's mu and the

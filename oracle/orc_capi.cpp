@@ -46,6 +46,21 @@ void orc_add_sphere(void *s, const double *center, double radius, double mu, int
   Primitive p; p.kind = PRIM_SPHERE; p.center = V3(center[0], center[1], center[2]); p.radius = radius; p.mu = mu; p.rotates = rotates;
   ((Sim *) s)->prims.push_back(p);
 }
+// Sphere with discretized = true (Simulation.cpp:1905-1911, BIG_SPHERE): face normals of its resolution x resolution mesh (40 in the reference)
+void orc_add_discretized_sphere(void *s, const double *center, double radius, double mu, int resolution) {
+  Primitive p; p.kind = PRIM_SPHERE; p.center = V3(center[0], center[1], center[2]); p.radius = radius; p.mu = mu; p.rotates = false;
+  p.discretized = true; p.mesh = buildSphereMesh(radius, resolution > 0 ? resolution : 40);
+  ((Sim *) s)->prims.push_back(p);
+}
+// diagnostics: the mesh of buildSphereMesh as 12 doubles per triangle (p0, p1, p2, normal); returns the triangle count
+int orc_sphere_mesh(double radius, int resolution, double *out, int cap) {
+  const std::vector<Primitive::Tri> m = buildSphereMesh(radius, resolution);
+  for (int t = 0; t < (int) m.size() && t < cap; t++) {
+    const V3 *v[4] = {&m[t].p0, &m[t].p1, &m[t].p2, &m[t].normal};
+    for (int k = 0; k < 4; k++) for (int d = 0; d < 3; d++) out[12 * t + 3 * k + d] = (*v[k])[d];
+  }
+  return (int) m.size();
+}
 void orc_add_capsule(void *s, const double *center, const double *topOffset, double radius, double length, double mu) {
   Primitive p; p.kind = PRIM_CAPSULE; p.center = V3(center[0], center[1], center[2]);
   p.topOffset = V3(topOffset[0], topOffset[1], topOffset[2]); p.radius = radius; p.length = length; p.mu = mu;

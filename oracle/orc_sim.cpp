@@ -386,7 +386,53 @@ static std::pair<V3, double> projectionOnLine(const V3 &a, const V3 &b, const V3
   return std::make_pair(Pp, t);
 }
 
-// Sphere::isInContact Primitive.cpp:221-261 (eps 0.1; discretized branch not used by shipped demos' hot path),
+// Sphere::Sphere, Primitive.cpp:133-216. Points: the north pole, rows y = 1 .. res - 1 of res points (theta = 180 y / res, phi = 360 x / res;
+// getSpherePos, Primitive.h:144-149, angles in degrees), the south pole. Triangles in the order the constructor creates them; createTriangle
+// (id0, id1, id2) stores Triangle(p0 = id2, p1 = id1, p2 = id0) (:148-153) and the face normal is (p1 - p0) x (p2 - p0) normalised (:205-206).
+std::vector<Primitive::Tri> buildSphereMesh(double radius, int resolution) {
+  const int numX = resolution, numY = resolution;
+  const double d_phi = 360.0 / numX, d_theta = 180.0 / numY;
+  const double rad = 0.01745329251994329576923690768489;      // glm::radians
+  auto spherePos = [&](double phi, double theta) {
+    return V3(radius * std::cos(phi * rad) * std::sin(theta * rad), radius * std::sin(phi * rad) * std::sin(theta * rad), radius * std::cos(theta * rad));
+  };
+  std::vector<V3> pts;
+  std::vector<Primitive::Tri> mesh;
+  auto tri = [&](int id0, int id1, int id2) {
+    Primitive::Tri t;
+    t.p0 = pts[id2]; t.p1 = pts[id1]; t.p2 = pts[id0];
+    t.normal = (t.p1 - t.p0).cross(t.p2 - t.p0).normalized();
+    mesh.push_back(t);
+  };
+  pts.push_back(spherePos(0, 0));
+  for (int y = 1; y < numY; y++) {
+    for (int x = 0; x < numX; x++) {
+      const double theta = d_theta * y, phi = d_phi * x;
+      const int idx = y * numX + x;
+      pts.push_back(spherePos(phi, theta));
+      const int last = (int) pts.size() - 1;
+      if ((y > 1) && (phi > 0) && (idx - numX - 1 >= 0)) {
+        tri(last, last - 1, last - numX);
+        tri(last - 1, last - numX - 1, last - numX);
+      } else if ((y == 1) && (x > 0)) {
+        tri(last, last - 1, 0);
+        if (x == numX - 1) tri(1, last, 0);
+      }
+    }
+    if ((y > 0) && ((int) pts.size() - 1 - numX + 1 - numX >= 0)) {      // close the strip between this row and the previous one
+      const int last = (int) pts.size() - 1;
+      tri(last - numX + 1 - numX, last - numX + 1, last);
+      tri(last, last - numX, last - numX + 1 - numX);
+    }
+  }
+  pts.push_back(spherePos(0, 180));
+  const int lastPointIdx = (int) pts.size() - 1;
+  tri(lastPointIdx, lastPointIdx - 1, lastPointIdx - numX);
+  for (int i = (int) pts.size() - numX; i < lastPointIdx; i++) tri(lastPointIdx, i - 1, i);
+  return mesh;
+}
+
+// Sphere::isInContact Primitive.cpp:221-261 (eps 0.1; with the discretized branch of the BIG_SPHERE scene),
 // Capsule::isInContact Primitive.cpp:570-604, LowerLeg::isInContact Primitive.cpp:410-418, Plane :66-130, Bowl :362-381.
 bool Sim::primInContact(const Primitive &p, const V3 &center_prim, const V3 &pos, const V3 &vel, V3 &normal,
                         double &dist, V3 &v_out) const {
@@ -396,6 +442,19 @@ bool Sim::primInContact(const Primitive &p, const V3 &center_prim, const V3 &pos
       dist = (pos - center_prim).norm() - p.radius;
       normal = (pos - center_prim).normalized();
       bool collides = dist < eps;
+      if (p.discretized && collides) {      // Primitive.cpp:230-253: the LAST mesh triangle (creation order) whose prism holds the point
+        const V3 q = pos - center_prim;     //   and whose "projection" (:188, with its swapped weights) is closer than the radius
+        for (const Primitive::Tri &t : p.mesh) {
+          // Primitive::pointInsideTriangle, Primitive.h:176-190
+          const V3 AB = t.p1 - t.p0, AC = t.p2 - t.p0, n = AB.cross(AC), AP = q - t.p0;
+          const double n2 = n.sqnorm();
+          const double alpha = AB.cross(AP).dot(n) / n2, beta = AP.cross(AC).dot(n) / n2, gamma = 1 - alpha - beta;
+          const bool inside = (alpha >= 0) && (beta >= 0) && (gamma >= 0) && (gamma <= 1) && (alpha <= 1) && (beta <= 1);
+          if (!inside) continue;
+          const V3 proj = t.p1 * alpha + t.p2 * beta + t.p0 * gamma;
+          if ((q - proj).norm() < p.radius) normal = t.normal;
+        }
+      }
       v_out = p.velocity;
       if (p.rotates) v_out += V3(0, 1, 0).cross(normal) * 8;
       return collides;

@@ -44,7 +44,14 @@ struct Primitive {        // Primitive.cpp (isInContact family)
   V3 upperLeft, upperRight;   // plane: two corners relative to the centre; the others are their negatives (Primitive.cpp:13-21)
   V3 velocity;
   std::vector<Primitive> children;  // LowerLeg: joint sphere, foot capsule, leg capsule
+  // Sphere::discretized (Primitive.h:222; set for the BIG_SPHERE scene, Simulation.cpp:1910): the contact normal is a face normal of the
+  // sphere's own render mesh (Primitive.cpp:230-253). `mesh`: its triangles in creation order (buildSphereMesh).
+  bool discretized = false;
+  struct Tri { V3 p0, p1, p2, normal; };
+  std::vector<Tri> mesh;
 };
+// Sphere::Sphere (Primitive.cpp:133-216): the latitude / longitude mesh of a sphere of `radius` around the origin, `resolution` x `resolution`.
+std::vector<Primitive::Tri> buildSphereMesh(double radius, int resolution);
 struct PrimContact {      // Simulation.h:39-51
   int primitiveId = -1, particleId = -1;
   V3 normal, v_out, d, r;

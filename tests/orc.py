@@ -103,6 +103,11 @@ class Oracle:
         self.L.orc_add_sphere(self.h, _d(f64(center)), C.c_double(radius), C.c_double(mu), C.c_int(int(rotates)))
         self.nprim += 1
 
+    def add_discretized_sphere(self, center, radius, mu, resolution=40):
+        """Sphere with discretized = true (the BIG_SPHERE scene, Simulation.cpp:1905-1911)"""
+        self.L.orc_add_discretized_sphere(self.h, _d(f64(center)), C.c_double(radius), C.c_double(mu), C.c_int(int(resolution)))
+        self.nprim += 1
+
     def add_capsule(self, center, top_offset, radius, length, mu):
         self.L.orc_add_capsule(self.h, _d(f64(center)), _d(f64(top_offset)), C.c_double(radius), C.c_double(length), C.c_double(mu))
         self.nprim += 1

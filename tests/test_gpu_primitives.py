@@ -104,3 +104,28 @@ def test_bowl():
     vel = np.zeros_like(X); vel[:, 1] = -0.3
     o, e = pair(X, F, dict(kind=capi.DC_PRIM_BOWL, center=c, radius=R), lambda o: o.add_bowl(c, R, 0.4), 0.4)
     check_step(o, e, f32(X.reshape(-1)), f32(vel.reshape(-1)), seed=22, min_contacts=100, some_free=False)
+
+
+@pytest.mark.parametrize("mu", [0.0, 0.3])
+def test_discretised_sphere(mu):
+    """Sphere with discretized = true (the BIG_SPHERE scene of the reference: radius 15 at (-0.5, -16, 0), mu 0, Simulation.cpp:1905-1911): the
+    contact normal of a vertex is the face normal of the sphere's own 40 x 40 mesh — the last face, in creation order, whose prism holds the
+    sample point (Primitive.cpp:230-253) — piecewise constant instead of radial. A sheet lying on top of the sphere spans a dozen faces."""
+    V, F = meshes.grid_cloth(22, 22, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    R = 15.0
+    c = np.array([-0.5, -16.0, 0.0])
+    X = V.copy()
+    X[:, 0] += c[0] - V[:, 0].mean() + 0.37; X[:, 2] += c[2] - V[:, 2].mean() - 0.21      # (off the mesh's symmetry lines)
+    X[:, 1] = c[1] + np.sqrt(R * R - (X[:, 0] - c[0]) ** 2 - (X[:, 2] - c[2]) ** 2) + 0.02
+    X = f32(X)
+    vel = np.zeros_like(X); vel[:, 1] = -0.3; vel[:, 0] = 0.2
+    o, e = pair(X, F, dict(kind=capi.DC_PRIM_SPHERE_DISCRETIZED, center=c, radius=R), lambda o: o.add_discretized_sphere(c, R, mu), mu)
+    ref = check_step(o, e, f32(X.reshape(-1)), f32(vel.reshape(-1)), seed=23, min_contacts=400, some_free=False)
+    pc = o.prim_contacts(ref["id"])
+    radial = (X[pc["particle"]] - c) / np.linalg.norm(X[pc["particle"]] - c, axis=1)[:, None]
+    faces = np.unique(np.round(pc["normal"], 9), axis=0)
+    print(f"[discretised sphere] {len(pc['particle'])} contacts on {len(faces)} faces, largest angle between face normal and radial direction "
+          f"{np.degrees(np.arccos(np.clip((pc['normal'] * radial).sum(axis=1), -1, 1))).max():.2f} degrees")
+    assert 6 <= len(faces) <= 40 and np.abs(pc["normal"] - radial).max() > 1e-2
+    assert ((pc["normal"] * radial).sum(axis=1) > 0.98).all()           # never the antipodal face
