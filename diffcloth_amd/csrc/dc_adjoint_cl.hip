@@ -276,7 +276,8 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   if (gnorm > 0) {
     // ---- direct solve of K u = g in mixed precision (see dc_adjoint.hip): fp32 BiCGSTAB for corrections of the fp64 residual ----
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
-    const int kcap = A.it_cap > 0 ? 4 * A.it_cap : 1600;
+    // (meshes the engine found ill-conditioned, S.adj_coarse: the fp64 fall-back has the coarse level the fp32 solve lacks — hand over after 400)
+    const int kcap = std::min(A.it_cap > 0 ? 4 * A.it_cap : 1600, S.adj_coarse ? 400 : 1 << 30);
     constexpr int VB = 4;
     bool fallback = false;
     double rr = rr_true;
