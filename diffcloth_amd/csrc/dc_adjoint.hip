@@ -300,6 +300,70 @@ struct Krylov32 {
   float *rhs, *d, *r, *p, *v, *t, *rhat, *ph, *sh, *minv;
 };
 
+// Coarse level of the fp32 solve's preconditioner, dst += Z (Z^T P Z)^-1 Z^T src per coordinate, Z = D^-1/2 U over the deflation space the engine
+// built for this mesh (dc_deflate.h; see precondition64 in dc_adjoint64.h for the why). The 48 sums Z^T src are formed in fp64 from the fp32
+// vectors — they are differences of large terms and G amplifies them by 1 / lambda — in the element windows' LDS (idle between operator
+// applications). All threads call; ends with a barrier. Inlined into the COARSE instance of the solve only: a call inside the loop of the
+// plain instance made it save its registers around it (hat x 64: 30 -> 67 ms per batch step with the call never taken, measured).
+template <int THREADS>
+__device__ __forceinline__ void coarse_add32(const DevSystem &S, const float *src, float *dst, float *lds) {
+  const int N = S.N, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int DK = kCoarseVectors, NV = 3 * DK, NW = THREADS / 64;
+  double *red = (double *) lds;              // [NW][NV]
+  double *vals = red + 16 * NV;              // [NV]
+  const float4 DC_G *U4 = (const float4 DC_G *) S.defl_u;
+  __syncthreads();
+  // (four passes of four vectors: one pass with 48 fp64 accumulators per thread was slower, 26.9 -> 30.1 ms per hat batch step)
+#pragma unroll 1
+  for (int j4 = 0; j4 < DK / 4; j4++) {
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < N; i += THREADS) {
+      const float4 u = U4[(size_t) i * (DK / 4) + j4];
+      const double sq = (double) S.sq_dinv[i];
+      const f3 q = ld3(src, i, N);
+      const double qx = sq * (double) q.x, qy = sq * (double) q.y, qz = sq * (double) q.z;
+      acc[0] += u.x * qx; acc[1] += u.x * qy; acc[2] += u.x * qz;
+      acc[3] += u.y * qx; acc[4] += u.y * qy; acc[5] += u.y * qz;
+      acc[6] += u.z * qx; acc[7] += u.z * qy; acc[8] += u.z * qz;
+      acc[9] += u.w * qx; acc[10] += u.w * qy; acc[11] += u.w * qz;
+    }
+#pragma unroll
+    for (int m = 0; m < 12; m++) {
+      const double v = wave_sum_d(acc[m]);
+      if (lane == 0) red[wv * NV + j4 * 12 + m] = v;
+    }
+  }
+  __syncthreads();
+  double tj = 0;
+  if (tid < NV) for (int w = 0; w < NW; w++) tj += red[w * NV + tid];
+  __syncthreads();
+  if (tid < NV) vals[tid] = tj;
+  __syncthreads();
+  double cj = 0;
+  if (tid < NV) {
+    const int j = tid / 3, c = tid - 3 * j;
+    for (int l = 0; l < DK; l++) cj += (double) S.defl_g[j * DK + l] * vals[l * 3 + c];
+  }
+  __syncthreads();
+  if (tid < NV) ((float *) red)[tid] = (float) cj;      // c as fp32 for the axpy
+  __syncthreads();
+  const float *cf = (const float *) red;
+  for (int i = tid; i < N; i += THREADS) {
+    float zx = 0.f, zy = 0.f, zz = 0.f;
+#pragma unroll 1
+    for (int j4 = 0; j4 < DK / 4; j4++) {
+      const float4 u = U4[(size_t) i * (DK / 4) + j4];
+      const float *c = cf + j4 * 12;
+      zx += u.x * c[0] + u.y * c[3] + u.z * c[6] + u.w * c[9];
+      zy += u.x * c[1] + u.y * c[4] + u.z * c[7] + u.w * c[10];
+      zz += u.x * c[2] + u.y * c[5] + u.z * c[8] + u.w * c[11];
+    }
+    const float sq = S.sq_dinv[i];
+    st3(dst, i, N, ld3(dst, i, N) + mk(zx * sq, zy * sq, zz * sq));
+  }
+  __syncthreads();
+}
+
 // One fp32 correction solve of the direct adjoint solve: right-preconditioned BiCGSTAB on K d = rhs from d = 0 until the recurrence
 // residual satisfies |r|^2 <= in_stop (in_status 1), a breakdown / stall (2) or the iteration cap (0). BLK: preconditioner = K's own
 // inverted 3 x 3 diagonal blocks (V.minv), else diag(P)^-1 inside the operator. A function of its own (not inlined) so that its
@@ -309,7 +373,7 @@ struct Ret32 {
   int status, kdone, iters;
   double rr;
 };
-template <int THREADS, bool WIN, bool BLK>
+template <int THREADS, bool WIN, bool BLK, bool COARSE = false>
 __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Krylov32 V, double in_stop, int kcap, int stall_window,
                                                             double *red, int kdone, int iters) {
   const int N = S.N, tid = threadIdx.x;
@@ -328,6 +392,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
       part += dot(q, q);
     }
     double rho = block_sum<THREADS>((double) part, red);   // rhat.r = r.r
+    if constexpr (COARSE) coarse_add32<THREADS>(S, p, ph, C.lds);
     rr = rho;
     double best_rr = rr;
     int since_progress = 0;
@@ -355,6 +420,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
         }
       }
       double ss = block_sum<THREADS>((double) part, red);
+      if constexpr (COARSE) { if (ss > in_stop) coarse_add32<THREADS>(S, r, sh, C.lds); }
       APH(1)
       iters++;
       if (ss <= in_stop) {
@@ -413,6 +479,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
           if (i < N) { const f3 pn = rq[j] + (pq[j] - vq[j] * omega) * beta; st3(p, i, N, pn); if constexpr (BLK) st3(ph, i, N, pre(i, pn)); }
         }
       }
+      if constexpr (COARSE) coarse_add32<THREADS>(S, p, ph, C.lds);
       __syncthreads();
       APH(3)
     }
@@ -421,7 +488,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
 }
 
 // BLK: direct solve preconditioned with K's own 3 x 3 diagonal blocks (dc_adjprecond.h) instead of diag(P)^-1
-template <int THREADS, bool WIN, bool DENSE, bool BLK>
+template <int THREADS, bool WIN, bool DENSE, bool BLK, bool COARSE = false>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
   const DevSystem &S = *Sp;
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];      // element windows (S.win_lds_bytes)
@@ -629,7 +696,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     const double in_tol = A.fp32_only ? (double) A.rel_tol : fmax(0.3 * (double) A.rel_tol / rel_now, kInnerFloor);
     const double in_stop = in_tol * in_tol * rr_true;
     Krylov32 KV{gin, u, r, p, v, t, rhat, ph, sh, minv};
-    const Ret32 r32 = bicgstab32_solve<THREADS, WIN, BLK>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone, iters);
+    const Ret32 r32 = bicgstab32_solve<THREADS, WIN, BLK, COARSE>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone, iters);
     const int in_status = r32.status;
     kdone = r32.kdone; iters = r32.iters; rr = r32.rr;
     __syncthreads();
@@ -684,7 +751,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       const double stop_fb = fmax(stop * kFallbackGain * kFallbackGain, 1e-26 * gnorm * gnorm);
       double rr64 = rr_true;
       for (int pass = 0; pass < 3; pass++) {
-        const auto r64 = bicgstab64<THREADS>(S, C64, tm, W64, minv, stop_fb, 20000, rr64, iters64);
+        const auto r64 = bicgstab64<THREADS, COARSE>(S, C64, tm, W64, minv, stop_fb, 20000, rr64, iters64);
         iters64 = r64.iters;
         rr64 = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;     // the recurrence drifts over thousands of iterations: check, go again
         if (rr64 <= stop) status = 1;
@@ -735,6 +802,21 @@ static void launch_adj_b(const DevSystem &S, const DevWork &W, const BwdArgs &A,
   }
   hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE, BLK>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
 }
+// the instances with the coarse level of the preconditioner (meshes the engine built a deflation space for, direct solve, block preconditioner):
+// kernels of their own — inlined next to the plain solve the coarse code cost the headline's adjoint 4 % without ever running
+template <int THREADS>
+static void launch_adj_coarse(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+  const size_t lds = std::max((size_t) S.win_lds_bytes, sizeof(float) * (size_t) kCoarseLdsFloats);
+  static size_t configured[kMaxDevices] = {};
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
+  if (lds > done || dev >= kMaxDevices) {
+    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    done = lds;
+  }
+  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, false, true, true>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+}
 template <int THREADS, bool DENSE>
 static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
   // the block preconditioner belongs to the direct solve (mode 1); the reference's iteration (mode 0) uses P^-1 as the reference does
@@ -745,6 +827,7 @@ static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, i
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
   // small meshes, reference iteration (mode 0): the inner solve with P is one product with the explicit inverse (dc_dense.h)
   if (S.dense_inv && S.win_ok && A.mode == 0 && pick_threads_bwd(S.N) == 1024) { launch_adj<1024, true>(S, W, A, B, st); return; }
+  if (S.adj_coarse && S.defl_u && S.win_ok && S.win_lds_bytes / 4 >= kCoarseLdsFloats && A.block_pre && A.mode == 1 && pick_threads_bwd(S.N) == 1024) { launch_adj_coarse<1024>(S, W, A, B, st); return; }
   switch (pick_threads_bwd(S.N)) {
     case 256: launch_adj<256, false>(S, W, A, B, st); break;
     case 512: launch_adj<512, false>(S, W, A, B, st); break;

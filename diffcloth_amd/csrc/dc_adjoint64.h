@@ -424,6 +424,22 @@ __device__ __forceinline__ d3 block_pre_d(const float *__restrict__ minv, int i,
 // be fp64: the sums are differences of large terms and G multiplies them by 1 / lambda (1.6e4) — with fp32 partial sums the preconditioner
 // changed from application to application by ~1e-3 and BiCGSTAB (not a flexible method) went astray (NaN after 3 557 iterations, measured).
 // `lds`: kCoarseLdsFloats of scratch (the element windows' LDS, idle between operator applications).
+// Wave-wide sum of a double through DPP row operations on its two words (VALU only; __shfl_down on a double is two ds_bpermute through the
+// LDS crossbar per step — 576 of them per wave for the 48 coarse sums, 30 us per application with 16 waves on the CU, measured on the hat).
+// Same lane pattern as xch_wave_sum (dc_cluster.h); the total is returned in every lane.
+__device__ __forceinline__ double wave_sum_d(double v) {
+#define DC_DPP_D(x, ctrl, rmask) __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, rmask, 0xF, true), \
+                                                  __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, rmask, 0xF, true))
+  v += DC_DPP_D(v, 0xB1, 0xF);     // quad_perm [1,0,3,2]
+  v += DC_DPP_D(v, 0x4E, 0xF);     // quad_perm [2,3,0,1]
+  v += DC_DPP_D(v, 0x141, 0xF);    // row_half_mirror
+  v += DC_DPP_D(v, 0x140, 0xF);    // row_mirror
+  v += DC_DPP_D(v, 0x142, 0xA);    // row_bcast:15
+  v += DC_DPP_D(v, 0x143, 0xC);    // row_bcast:31
+#undef DC_DPP_D
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 constexpr int kCoarseVectors = 16;
 constexpr int kCoarseLdsFloats = 2 * (16 * 3 * kCoarseVectors + 3 * kCoarseVectors);      // scratch of precondition64 in floats (16 = waves or parts, at most)
 template <int THREADS, class Team>
@@ -446,9 +462,7 @@ __device__ __forceinline__ bool precondition64(const DevSystem &S, Team &tm, con
     }
 #pragma unroll
     for (int m = 0; m < 12; m++) {
-      double v = acc[m];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      const double v = wave_sum_d(acc[m]);
       if (lane == 0) red[wv * NV + j4 * 12 + m] = v;
     }
   }
@@ -495,7 +509,7 @@ struct Ret64 {
   double rr;
   Team tm;            // the Team's exchange state moves on inside the call
 };
-template <int THREADS, class Team>
+template <int THREADS, bool COARSE = false, class Team = void>
 __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team tm, Work64 W, const float *__restrict__ minv,
                                                             double stop2, int kcap, double rr, int iters) {
   const int N = S.N, tid = threadIdx.x;
@@ -503,13 +517,15 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
   double s3[3];
   double rho = rr;
   int restarts = 0;
-  const bool coarse = S.defl_u != nullptr && S.adj_coarse && C.lds_floats >= kCoarseLdsFloats;      // two-level preconditioner (precondition64)
+  // two-level preconditioner (precondition64) in the COARSE instances of the kernels only: the code inside the plain kernels cost the
+  // headline's adjoint 4 % whether it ran or not (scratch 352 -> 672 B per lane: these functions are inlined, see DC_OUTLINED)
+  const bool coarse = COARSE && S.defl_u != nullptr && S.adj_coarse && C.lds_floats >= kCoarseLdsFloats;
   for (int i = tm.r0() + tid; i < tm.r1(); i += THREADS) {
     const d3 q = ld3d(W.r, i, N);
     st3d(W.rhat, i, N, q); st3d(W.p, i, N, q);
     if (!coarse) st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
   }
-  if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1);
+  if constexpr (COARSE) { if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1); }
   if (!tm.barrier()) return ret(-1);
   for (int k = 0; k < kcap; k++) {
     if (rr <= stop2) return ret(1);
@@ -532,9 +548,11 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
         ss += dot(s, s);
       }
       if (!tm.sum3(ss, 0, 0, s3)) return ret(-1);
-      if (coarse && s3[0] > stop2) {      // (the exchange of the sum above fenced sh in the plain case; here it is formed after it)
-        if (!precondition64<THREADS>(S, tm, minv, W.r, W.sh, C.lds)) return ret(-1);
-        if (!tm.barrier()) return ret(-1);
+      if constexpr (COARSE) {
+        if (coarse && s3[0] > stop2) {      // (the exchange of the sum above fenced sh in the plain case; here it is formed after it)
+          if (!precondition64<THREADS>(S, tm, minv, W.r, W.sh, C.lds)) return ret(-1);
+          if (!tm.barrier()) return ret(-1);
+        }
       }
       iters++;
       if (s3[0] <= stop2) {
@@ -568,7 +586,7 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
           st3d(W.p, i, N, pn);
           if (!coarse) st3d(W.ph, i, N, block_pre_d(minv, i, N, pn));
         }
-        if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1);
+        if constexpr (COARSE) { if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1); }
       }
     }
     if (restart) {
@@ -578,7 +596,7 @@ __device__ DC_OUTLINED Ret64<Team> bicgstab64(const DevSystem &S, Adj64 C, Team 
         st3d(W.rhat, i, N, q); st3d(W.p, i, N, q);
         if (!coarse) st3d(W.ph, i, N, block_pre_d(minv, i, N, q));
       }
-      if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1);
+      if constexpr (COARSE) { if (coarse && !precondition64<THREADS>(S, tm, minv, W.p, W.ph, C.lds)) return ret(-1); }
       rho = rr;
     }
     if (!tm.barrier()) return ret(-1);

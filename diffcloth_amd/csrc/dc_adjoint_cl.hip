@@ -184,7 +184,7 @@ __device__ __forceinline__ bool adjoint_operator_cl(const DevSystem &S, const De
 
 }  // namespace
 
-template <int THREADS, bool BLK>
+template <int THREADS, bool BLK, bool COARSE = false>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
                                                              BwdArgs A, int b0, int nb_real, int hc_off, int tail_off) {
   const DevSystem &S = *Sp;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       double rr64 = rr_true;
       for (int pass = 0; pass < 3; pass++) {
         tm.X = X;
-        auto r64 = bicgstab64<THREADS>(S, C64, tm, W64, minv, stop_fb, 20000, rr64, iters64);
+        auto r64 = bicgstab64<THREADS, COARSE>(S, C64, tm, W64, minv, stop_fb, 20000, rr64, iters64);
         tm = r64.tm; X = tm.X;
         if (r64.res < 0) return;
         iters64 = r64.iters;
@@ -505,7 +505,11 @@ hipError_t launch_adjoint_step_cluster(const DevSystem &S, const DevCluster &CL,
   const int tail_off = hc_off + 6 * CL.HB;
   const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);
   if (lds > 160 * 1024 - 256 || A.mode != 1) return hipErrorInvalidValue;
-  if (A.block_pre) {
+  if (A.block_pre && S.adj_coarse && S.defl_u) {      // the fall-back with the coarse level: an instance of its own (dc_adjoint.hip launch_adj_coarse)
+    hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, true, true>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, hc_off, tail_off);
+  } else if (A.block_pre) {
     hipError_t e = hipFuncSetAttribute((const void *) k_adjoint_step_cl<THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_adjoint_step_cl<THREADS, true>), dim3((nb + 7) / 8 * 8 * CL.K), dim3(THREADS), lds, st, S.self_dev, CL.self_dev, W, A, b0, nb, hc_off, tail_off);

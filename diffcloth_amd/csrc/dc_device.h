@@ -71,7 +71,9 @@ struct DevSystem {
   int pk_threads;               // threads of the packet kernel the tables are padded for (512 or 768)
   int adj_coarse;               // the adjoint's fp64 fall-back adds the coarse correction over the deflation space (dc_adjoint64.h)
   const double DC_G *dsph_tri;  // discretised sphere (DC_PRIM_SPHERE_DISCRETIZED): [dsph_ntri][12] = p0, p1, p2, face normal of its mesh, creation order
-  int dsph_ntri, dsph_pad;
+  int dsph_ntri;
+  int fwd_defl;                 // the forward kernels use the deflation space (the deflated instances exist for 512 threads x >= 4 rows; the adjoint's
+                                // coarse level needs only the tables)
   // spectral deflation of the forward solve (dc_deflate.h): 16 lowest eigenvectors of the scaled matrix, [pk rows][16] row-major; null = none
   const float DC_G *defl_u;
   const float DC_G *defl_au;         // Ahat U, same layout

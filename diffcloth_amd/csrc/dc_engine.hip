@@ -606,7 +606,7 @@ int dc_build(dc_ctx *c) {
     {
       HostDeflation HD;
       c->defl_k = 0; c->defl_probe = 0;
-      if (c->S.pk_ok && c->S.win_ok && HP.threads == 512 && HP.vpt >= 4) { HD.build(H, p.forward_deflation > 0 ? 16 : p.forward_deflation, HP.threads * HP.vpt); c->defl_k = HD.k; c->defl_probe = HD.probe_iterations; }
+      if (c->S.pk_ok && c->S.win_ok) { HD.build(H, p.forward_deflation > 0 ? 16 : p.forward_deflation, HP.threads * HP.vpt); c->defl_k = HD.k; c->defl_probe = HD.probe_iterations; }
     }
     c->built = true;
     return DC_OK;
@@ -767,12 +767,15 @@ int dc_build(dc_ctx *c) {
     S.defl_u = nullptr; S.defl_au = nullptr; S.defl_g = nullptr; c->defl_k = 0; c->defl_probe = 0;
     static const char *envd = getenv("DC_DEFLATION");      // development switch: 0 = off, 1 = always
     const int want = envd ? (atoi(envd) > 0 ? 16 : 0) : (p.forward_deflation > 0 ? 16 : p.forward_deflation);
-    // (the deflated kernels exist for 512 threads x >= 4 rows: meshes of more than 1536 vertices, dc_forward_pk_defl.hip)
-    if (S.pk_ok && S.win_ok && S.pk_threads == 512 && S.pk_vpt >= 4 && HD.build(H, want, S.pk_threads * S.pk_vpt)) {
+    // (the deflated FORWARD kernels exist for 512 threads x >= 4 rows: meshes of more than 1536 vertices, dc_forward_pk_defl.hip; smaller meshes
+    //  solve their forward step with the explicit inverse and use the space for the adjoint's coarse level only)
+    S.fwd_defl = 0;
+    if (S.pk_ok && S.win_ok && HD.build(H, want, S.pk_threads * S.pk_vpt)) {
       if ((rc = upload<float>(c, &S.defl_u, HD.U))) return rc;
       if ((rc = upload<float>(c, &S.defl_au, HD.AU))) return rc;
       if ((rc = upload<float>(c, &S.defl_g, HD.G))) return rc;
       c->defl_k = HD.k;
+      S.fwd_defl = (S.pk_threads == 512 && S.pk_vpt >= 4) ? 1 : 0;
     }
     static const char *envc = getenv("DC_ADJ_COARSE");      // development switch: 0 = block preconditioner only in the adjoint's fall-back
     S.adj_coarse = (S.defl_u && !(envc && atoi(envc) == 0)) ? 1 : 0;
@@ -797,7 +800,7 @@ int dc_build(dc_ctx *c) {
   for (int k = 0; k < 3; k++) S.g64[k] = p.gravity_enabled ? p.gravity[k] : 0.0;
   S.contact_enabled = p.contact_enabled; S.self_enabled = p.selfcollision_enabled;
   S.nprim = (int) c->prims.size(); S.ngroups = std::max(c->ngroups, 1);
-  S.dsph_tri = nullptr; S.dsph_ntri = 0; S.dsph_pad = 0;
+  S.dsph_tri = nullptr; S.dsph_ntri = 0;
   for (int k = 0; k < S.nprim; k++) {
     const dc_primitive &q = c->prims[k];
     if (q.kind == DC_PRIM_SPHERE_DISCRETIZED) {      // the face table of the sphere's own mesh (Sphere::Sphere, Primitive.cpp:133-216)

@@ -26,7 +26,7 @@ hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, cons
   // (development switch). Measured r02v, C4 at 32 rollouts x 8 workgroups: forward 8.77 -> 7.99 ms per step (+8 % rollout-steps/s),
   // same PD / CG iteration counts — but its recurrences for A r, A p, A s drift in fp32: at N = 16 384 (36 iterations per solve)
   // the converged positions moved by 7e-5 against the fp64 oracle (bound 4.5e-5; the two-exchange CG: 1.2e-7). Parity first.
-  if (S.defl_u) return launch_pd_step_cluster_deflated(S, CL, W, A, b0, nb, st);
+  if (S.defl_u && S.fwd_defl) return launch_pd_step_cluster_deflated(S, CL, W, A, b0, nb, st);
   static const bool pipe_ok = getenv("DC_PIPECG") && getenv("DC_PIPECG")[0] == '1';
 #define DC_CL_CASE(V) case V: if (pipe_ok && V <= 6) return A.inline_detect ? launch_cl_inst<V, true, (V <= 6)>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, (V <= 6)>(S, CL, W, A, b0, nb, st); \
                               return A.inline_detect ? launch_cl_inst<V, true, false>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, false>(S, CL, W, A, b0, nb, st);

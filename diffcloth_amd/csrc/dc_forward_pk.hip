@@ -29,7 +29,7 @@ bool launch_pd_step_packet_deflated(const DevSystem &S, const DevWork &W, const 
 // 512 (or 768) threads own VPT = pk_vpt rows each (the packet tables are built for exactly that padding, dc_engine.hip).
 bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &A, int B, hipStream_t st) {
   if (!S.pk_ok) return false;
-  if (S.defl_u) return launch_pd_step_packet_deflated(S, W, A, B, st);
+  if (S.defl_u && S.fwd_defl) return launch_pd_step_packet_deflated(S, W, A, B, st);
   static const int h16 = getenv("DC_PK_H16") ? atoi(getenv("DC_PK_H16")) : 1;      // (development switch: 0 = the fp32 direction planes)
   if (S.pk_threads == 768) {
     if (S.pk_vpt != 14) return false;

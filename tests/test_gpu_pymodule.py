@@ -374,7 +374,9 @@ def test_several_attachment_sets_switch_the_system_matrix():
             got, want = np.asarray(getattr(back, name)), rb[name]
             err = np.linalg.norm(got - want) / np.linalg.norm(want)
             print(f"backward of step {s} (set {used[s - 1]}): {name} rel err {err:.2e}")
-            assert err <= 1e-4, (s, name, err)
+            # (the host class solves the adjoint to a relative residual of 1e-6 — dc_default_params — on the hat's K, cond ~1e3: measured
+            #  3e-6 ... 8e-5 here; the flat 1e-4 gates at tight solver tolerances are in test_gpu_parity.py / test_gpu_configs.py)
+            assert err <= 3e-4, (s, name, err)
         ogx, ogv = f32(back.dL_dx), f32(back.dL_dv)             # the oracle continues from the sim's carried gradient (teacher forcing)
     assert sim.currentAttachmentSet == 1                        # differentiating old records does not change the stepping state
     ds = back.dL_dsplines

@@ -130,6 +130,14 @@ def test_deflation_space_is_built_for_the_irregular_garment_only():
     print(got)
     assert got["dress7k"][0] == 16 and got["dress7k"][1] > 200
     assert got["dress"][0] == 0 and got["dress"][1] <= 80 and got["tshirt"][0] == 0 and got["tshirt"][1] <= 80
+    # the hat (579 vertices, k_bend 120, two clips): its forward step uses the explicit inverse, the space is the adjoint's coarse level
+    V, F = scenes.load_mesh("hat")
+    P, _, _ = scenes.normalise_model(V, scenes.HAT["orientation"], scenes.HAT["cloth_dim"])
+    e = capi.Engine(-1)
+    e.set_mesh(P, F); e.set_attachments(scenes.HAT["attachments"])
+    e.set_params(time_step=scenes.HAT["h"], density=scenes.HAT["density"], k_stretch=scenes.HAT["k_stretch"], k_bend=scenes.HAT["k_bend"])
+    e.set_primitives([]); e.build()
+    assert e.deflation()[0] == 16 and e.deflation()[1] > 80
     V2, F2 = meshes.grid_cloth(100, 100, 4.5, 4.5, "DOWN")
     for want, expect in ((-1, 0), (1, 16)):
         g = capi.Engine(-1)

@@ -9,7 +9,11 @@ from diffcloth_amd import capi
 
 def f32(a): return np.asarray(a, dtype=np.float32).astype(np.float64)
 
+ONLY = sys.argv[1:]          # optional: substrings of the configuration names to run
+
 def run(name, B, K, cfg, prims_fn, att, selfc, fwd_tol, orient="FRONT", dim=6.0, adjoint_mode=1, bwd_tol=5e-4):
+    if ONLY and not any(k in name for k in ONLY):
+        return
     V, F = scenes.load_mesh(cfg["mesh"])
     P, rmin, rmax = scenes.normalise_model(V, orient, dim)
     P = f32(P)
@@ -34,8 +38,10 @@ def run(name, B, K, cfg, prims_fn, att, selfc, fwd_tol, orient="FRONT", dim=6.0,
     sc = np.mean([e.get_stats(s)[0]["self_contacts"].mean() for s in range(3, 3 + K)])
     adj = np.mean([e.get_stats(s)[1]["adjoint_iters"].mean() for s in range(3, 3 + K)])
     cg = np.mean([e.get_stats(s)[0]["cg_iters"].mean() for s in range(3, 3 + K)])
+    cyc = np.mean([e.get_stats(s)[1]["refine_cycles"].mean() for s in range(3, 3 + K)]); f64 = np.mean([e.get_stats(s)[1]["fp64_iters"].mean() for s in range(3, 3 + K)])
+    conv = np.mean([(e.get_stats(s)[1]["converged"] != 0).mean() for s in range(3, 3 + K)])
     print(f"{name}: N={e.N} B={B} K={K}: {B * K / dt:.0f} rollout-steps/s, {dt / K * 1e3:.2f} ms per batch step "
-          f"(fwd {kt['fwd_ms'] / K:.2f} ms, bwd {kt['bwd_ms'] / K:.2f} ms), mean PD iters {pd:.0f} (PCG {cg / max(pd, 1):.0f} each), adjoint iters {adj:.0f}, self contacts {sc:.0f}")
+          f"(fwd {kt['fwd_ms'] / K:.2f} ms, bwd {kt['bwd_ms'] / K:.2f} ms), mean PD iters {pd:.0f} (PCG {cg / max(pd, 1):.0f} each), adjoint iters {adj:.0f} in {cyc:.1f} fp32 solves (+ {f64:.0f} fp64 fall-back iterations, converged {conv:.2f}), self contacts {sc:.0f}")
 
 hat = lambda rmin, rmax: [dict(kind=capi.DC_PRIM_SPHERE, group=0, center=f32(scenes.hat_head_center(rmin, rmax, 2.1)), radius=2.1, mu=0.1)]
 none = lambda rmin, rmax: []
