@@ -93,11 +93,13 @@ typedef struct dc_params {
   int adjoint_fp32_only;
   int max_self_contacts;            /* capacity of the per-rollout self-contact list of one step; <=0: sized from the mesh,
                                        max(2048, N) pairs (at most 16000); overflow is reported, never silent: dc_step_stats */
-  /* forward solve, spectral deflation for irregular garments (csrc/dc_deflate.h): < 0 (default) = decided in dc_build by a probe solve
-   * (16 eigenvectors of the scaled system matrix when Jacobi-PCG needs more than 80 iterations on a smooth right-hand side: the
-   * reference's 7 742-vertex dress needs 337, the cloth / T-shirt / sock / dress-3634 meshes 15 ... 37 and get none), 0 = never, > 0 = always.
-   * Every solve of the one-workgroup forward kernel then starts with a Galerkin projection onto those vectors (after its recycled first
-   * direction); the stopping rule and what the solve converges to are unchanged.                                                       */
+  /* spectral deflation for ill-conditioned meshes (csrc/dc_deflate.h): < 0 (default) = decided in dc_build by a probe solve (16 eigenvectors of
+   * the scaled system matrix when Jacobi-PCG needs more than 80 iterations on a smooth right-hand side: the reference's 7 742-vertex dress
+   * needs 337, the hat 171; the cloth / T-shirt / sock / dress-3634 meshes 15 ... 39 and get none), 0 = never, > 0 = always.
+   * Forward step (meshes of more than 1536 vertices; smaller ones solve with the explicit inverse): every PCG solve starts with a Galerkin
+   * projection onto those vectors, after its recycled first direction. Adjoint (direct solve with the block preconditioner): the vectors are
+   * the coarse level of the BiCGSTAB preconditioner. Stopping rules and what the solves converge to are unchanged. dc_get_deflation reports
+   * what dc_build decided.                                                                                                            */
   int forward_deflation;
 } dc_params;
 
