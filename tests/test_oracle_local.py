@@ -225,3 +225,52 @@ def test_plane_and_bowl_contact_sets_match_an_independent_restatement(kind):
     assert set(got) == set(want) and 10 < len(want) < len(X)
     for i in want:
         np.testing.assert_allclose(got[i], want[i], atol=1e-12)
+
+
+def test_discretised_sphere_normals_are_face_normals_of_the_sphere_mesh():
+    """Known answers for the oracle's discretized Sphere::isInContact (Primitive.cpp:230-253): vertices resting just above a radius-15
+    sphere get, as contact normal, the normal of the mesh face whose prism holds them — worked out here a third time with numpy from the
+    face table (barycentric weights of Primitive.h:176-190 in [0, 1]; the LAST such face in creation order whose swapped-weight projection is
+    within one radius: that rules the antipodal face out). Piecewise constant: every vertex over one face gets the identical normal, a
+    vertex over the neighbouring face a different one, and none is the radial direction."""
+    import ctypes as C
+    R, res = 15.0, 40
+    c = np.array([-0.5, -16.0, 0.0])
+    V, F = meshes.grid_cloth(9, 9, 3.2, 3.2, "DOWN")
+    X = V.copy()
+    X[:, 0] += c[0] - V[:, 0].mean() + 0.37; X[:, 2] += c[2] - V[:, 2].mean() - 0.21
+    X[:, 1] = c[1] + np.sqrt(R * R - (X[:, 0] - c[0]) ** 2 - (X[:, 2] - c[2]) ** 2) + 0.03
+    o = orc.Oracle(X, F, h=1 / 120, density=0.3, k_stretch=150.0, k_bend=0.05, selfcollision=False, gradient_clipping=False)
+    o.add_discretized_sphere(c, R, 0.2, res)
+    o.build()
+    ref = o.step(X.reshape(-1), np.zeros(X.size))
+    pc = o.prim_contacts(ref["id"])
+    assert len(pc["particle"]) == len(X)                       # every vertex is within 0.1 of the surface
+    L = orc.lib()
+    L.orc_sphere_mesh.restype = C.c_int
+    tab = np.zeros(12 * 2 * res * res)
+    n = L.orc_sphere_mesh(C.c_double(R), C.c_int(res), tab.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(tab.size // 12))
+    tab = tab[:12 * n].reshape(n, 4, 3)
+    p0, p1, p2, fn = tab[:, 0], tab[:, 1], tab[:, 2], tab[:, 3]
+    AB, AC = p1 - p0, p2 - p0
+    nn = np.cross(AB, AC); n2 = (nn * nn).sum(axis=1)
+    want = np.zeros((len(X), 3)); face = -np.ones(len(X), dtype=int)
+    for k, i in enumerate(pc["particle"]):
+        q = X[i] - c                                           # (zero velocity: the three time samples coincide)
+        AP = q - p0
+        alpha = (np.cross(AB, AP) * nn).sum(axis=1) / n2
+        beta = (np.cross(AP, AC) * nn).sum(axis=1) / n2
+        gamma = 1 - alpha - beta
+        inside = (alpha >= 0) & (beta >= 0) & (gamma >= 0) & (gamma <= 1) & (alpha <= 1) & (beta <= 1)
+        proj = alpha[:, None] * p1 + beta[:, None] * p2 + gamma[:, None] * p0
+        ok = inside & (np.linalg.norm(q - proj, axis=1) < R)
+        hits = np.nonzero(ok)[0]
+        assert len(hits) >= 1 and inside.sum() >= 2            # the face below the vertex and (at least) the antipodal one hold it in their prisms
+        face[k] = hits[-1]
+        want[k] = fn[hits[-1]]
+    np.testing.assert_allclose(pc["normal"], want, rtol=0, atol=1e-15)
+    radial = (X[pc["particle"]] - c) / np.linalg.norm(X[pc["particle"]] - c, axis=1)[:, None]
+    assert ((pc["normal"] * radial).sum(axis=1) > 0.99).all() and np.abs(pc["normal"] - radial).max() > 1e-3
+    assert 6 <= len(set(face.tolist())) <= 24                  # a 3.2 x 3.2 sheet on quads of 2.4 x 1.2, two faces each
+    for f in set(face.tolist()):
+        assert np.ptp(pc["normal"][face == f], axis=0).max() == 0.0
