@@ -39,7 +39,8 @@ bool launch_pd_step_packet(const DevSystem &S, const DevWork &W, const FwdArgs &
   }
 #ifdef DC_PK_ONLY20      // development builds: only the 10 000-vertex variant (compile time)
   if (S.pk_vpt != 20) return false;
-  launch_pk<512, 20, 6>(S, W, A, B, st);
+  if (h16 && S.win_ok) launch_pk_h16<512, 20, 12>(S, W, A, B, st);
+  else launch_pk<512, 20, 6>(S, W, A, B, st);
   return true;
 #else
   switch (S.pk_vpt) {

@@ -55,6 +55,14 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   // A.nsteps consecutive time steps of this rollout in one launch (dc_rollout_forward without self-collision): rollouts
   // are independent, so nothing forces them to wait for the slowest one after every step. Step s reads tape slot k + s
   // and writes slot k + s + 1 (slot strides: A.slot_state floats, A.slot_prim ints, A.slot_stats entries).
+  // H16 product: packet-row address and packet count of the wave's k-th chunk, held in lane k for the whole launch (see spmv)
+  unsigned tbl_lo = 0, tbl_hi = 0;
+  int tbl_n = 0;
+  if constexpr (H16) {
+    const int ch = wv + min(lane, VPT - 1) * WAVES;
+    const unsigned long long a = (unsigned long long) (S.pk + S.pk_ptr[ch]);
+    tbl_lo = (unsigned) a; tbl_hi = (unsigned) (a >> 32); tbl_n = S.pk_n[ch];
+  }
   for (int step = 0; step < A.nsteps; step++) {
   if (step > 0) __syncthreads();              // the previous step's state written by the whole workgroup
   const size_t so = (size_t) step * A.slot_state;
@@ -358,12 +366,52 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     PH(1)
     // ap = Ahat * (the vector in lp), part2 += <lp, ap>; rows of a thread tid + k * THREADS
     auto spmv = [&](int wz, float &part2, bool with_pr, float &part3) {
+      if constexpr (H16) {
+        // Row table from the lanes (tbl_*: lane k = the wave's k-th chunk): one v_readlane per value instead of scalar loads of pk_ptr / pk_n
+        // and of the table pointers themselves in every row — each of those was an `s_waitcnt lgkmcnt(0)`, i.e. an exposed scalar-cache
+        // round trip that also drains the LDS gathers in flight (94 scalar loads per product in the round-4 code object). The lane
+        // index carries the opaque zero so that the 3 x VPT values are not hoisted out of the CG loop into SGPRs that do not exist.
+        const int zl = wz - wv;
+        auto row_of = [&](int k) -> const int4 DC_G * {
+          const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) tbl_lo, k + zl), hi = (unsigned) __builtin_amdgcn_readlane((int) tbl_hi, k + zl);
+          return (const int4 DC_G *) (((unsigned long long) hi << 32) | lo) + lane;
+        };
+        int4 nxt[PB];
+        const int4 DC_G *row = row_of(0);
+#pragma unroll
+        for (int j = 0; j < PB; j++) nxt[j] = row[j * 64];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int i = (wz + k * WAVES) * 64 + lane;
+          const int np = __builtin_amdgcn_readlane(tbl_n, k + zl);
+          int4 cur[PB];
+#pragma unroll
+          for (int j = 0; j < PB; j++) cur[j] = nxt[j];
+          const int4 DC_G *row_next = row;
+          if (k + 1 < VPT) {
+            row_next = row_of(k + 1);
+#pragma unroll
+            for (int j = 0; j < PB; j++) nxt[j] = row_next[j * 64];
+          }
+          unsigned rowbase = lh_addr + 8u * (unsigned) (i - 512);
+          asm volatile("" : "+v"(rowbase));      // opaque: one register per row, not (row + delta) * 8 + LDS base per non-zero
+          float ax, ay, az;
+          pk_v2i own;
+          consume_h_row(cur, rowbase, ax, ay, az, own);
+          for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
+#pragma unroll
+            for (int j = 0; j < PB; j++) cur[j] = row[(s0 + j) * 64];
+            consume_h(cur, rowbase, ax, ay, az);
+          }
+          row = row_next;
+          ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
+          dot3_h(ax, ay, az, own, part2);
+          dot3_h(rr[k][0], rr[k][1], rr[k][2], own, part3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       int4 nxt[PB];
       load_batch(nxt, S.pk + S.pk_ptr[wz] + lane, 0);
-#ifdef DC_PK_PF2      // packets of the row after next in flight as well (two rows = 8 KB per wave outstanding)
-      int4 nx2[PB];
-      if (VPT > 1) load_batch(nx2, S.pk + S.pk_ptr[wz + WAVES] + lane, 0);
-#endif
 #pragma unroll
       for (int k = 0; k < VPT; k++) {
         const int chunk = wz + k * WAVES;   // wave-uniform: pk_ptr / pk_n are scalar loads
@@ -373,29 +421,21 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         int4 cur[PB];
 #pragma unroll
         for (int j = 0; j < PB; j++) cur[j] = nxt[j];
-#ifdef DC_PK_PF2
-#pragma unroll
-        for (int j = 0; j < PB; j++) nxt[j] = nx2[j];
-        if (k + 2 < VPT) load_batch(nx2, S.pk + S.pk_ptr[chunk + 2 * WAVES] + lane, 0);
-#else
         if (k + 1 < VPT) load_batch(nxt, S.pk + S.pk_ptr[chunk + WAVES] + lane, 0);
-#endif
-        float2 pxy; float pz;
-        if constexpr (H16) { const h4 q = lh[i]; pxy = make_float2((float) q.x, (float) q.y); pz = (float) q.z; }
-        else { pxy = ((const float2 *) lp)[i]; pz = lp[2 * NP + i]; }
+        const float2 pxy = ((const float2 *) lp)[i];
+        const float pz = lp[2 * NP + i];
         float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
         const int base = i - 512;
-        unsigned rowbase = lh_addr + 8u * (unsigned) base;
-        asm volatile("" : "+v"(rowbase));      // opaque: one register per row, not (row + delta) * 8 + LDS base per non-zero
-        if constexpr (H16) consume_h(cur, rowbase, ax, ay, az); else consume<NP>(cur, lp, base, ax, ay, az);
+        consume<NP>(cur, lp, base, ax, ay, az);
         for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
           load_batch(cur, row, s0);
-          if constexpr (H16) consume_h(cur, rowbase, ax, ay, az); else consume<NP>(cur, lp, base, ax, ay, az);
+          consume<NP>(cur, lp, base, ax, ay, az);
         }
         ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
         part2 += pxy.x * ax + pxy.y * ay + pz * az;
-        if (H16 || with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];      // fp32 planes: seeded pass only (uniform branch)
+        if (with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];      // seeded pass only (uniform branch)
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
     };
     // ---- global step: Jacobi PCG on P dv = rhs as plain CG on the scaled system, resident in LDS + registers ----

@@ -86,12 +86,54 @@ __device__ __forceinline__ void consume_h(const int4 (&e)[PB], unsigned rowbase,
     q[j][1] = *(lds_int2p) (size_t) (rowbase + (d1 << 3));
     q[j][2] = *(lds_int2p) (size_t) (rowbase + (d2 << 3));
   }
+  // Nothing crosses: the compiler's scheduler otherwise interleaves read / wait / product to shorten the live ranges of the gathered
+  // values — two or three reads in flight and an exposed LDS round trip per non-zero on 13 of the 20 rows of the 10 000-vertex kernel
+  // (code object of round 4: `ds_read_b64; s_waitcnt lgkmcnt(0); 3 x v_fma_mix` chains). Behind the fence the waits count down
+  // lgkmcnt(11) ... (0) while the products issue.
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < PB; j++) {
     fma3_h(__int_as_float(e[j].x), q[j][0].x, q[j][0].y, ax, ay, az);
     fma3_h(__int_as_float(e[j].y), q[j][1].x, q[j][1].y, ax, ay, az);
     fma3_h(__int_as_float(e[j].z), q[j][2].x, q[j][2].y, ax, ay, az);
   }
+}
+// First batch of a row: the row's OWN direction entry (the unit diagonal's operand, LDS address rowbase + 8 * 512) is read in the same
+// group as the 12 gathers and enters the sums last, as one more v_fma_mix with coefficient 1 — read on its own ahead of the gathers
+// (to initialise the sums) it cost an exposed LDS round trip per row before the first gather was even issued. `own` returns its bits for
+// the dot products; they are made to depend on the finished sums so that their conversions are scheduled behind the products.
+__device__ __forceinline__ void consume_h_row(const int4 (&e)[PB], unsigned rowbase, float &ax, float &ay, float &az, pk_v2i &own) {
+  pk_v2i q[PB][3];
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    const unsigned w = (unsigned) e[j].w;
+    unsigned d0, d1, d2;
+    asm("v_bfe_u32 %0, %1, 0, 10" : "=v"(d0) : "v"(w));
+    asm("v_bfe_u32 %0, %1, 10, 10" : "=v"(d1) : "v"(w));
+    asm("v_bfe_u32 %0, %1, 20, 10" : "=v"(d2) : "v"(w));
+    q[j][0] = *(lds_int2p) (size_t) (rowbase + (d0 << 3));
+    q[j][1] = *(lds_int2p) (size_t) (rowbase + (d1 << 3));
+    q[j][2] = *(lds_int2p) (size_t) (rowbase + (d2 << 3));
+  }
+  pk_v2i o = *(lds_int2p) (size_t) (rowbase + 4096u);
+  __builtin_amdgcn_sched_barrier(0);
+  ax = 0.f; ay = 0.f; az = 0.f;
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    fma3_h(__int_as_float(e[j].x), q[j][0].x, q[j][0].y, ax, ay, az);
+    fma3_h(__int_as_float(e[j].y), q[j][1].x, q[j][1].y, ax, ay, az);
+    fma3_h(__int_as_float(e[j].z), q[j][2].x, q[j][2].y, ax, ay, az);
+  }
+  asm("v_fma_mix_f32 %0, 1.0, %1, %0 op_sel_hi:[0,1,0]" : "+v"(ax) : "v"(o.x));
+  asm("v_fma_mix_f32 %0, 1.0, %1, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(ay) : "v"(o.x));
+  asm("v_fma_mix_f32 %0, 1.0, %1, %0 op_sel_hi:[0,1,0]" : "+v"(az) : "v"(o.y));
+  own = o;
+}
+// acc += <(x, y, z), the three halves of q>: the dot products of the product loop take the direction's halves as they are, behind the sums
+__device__ __forceinline__ void dot3_h(float x, float y, float z, pk_v2i q, float &acc) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(x), "v"(q.x));
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(y), "v"(q.x));
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(acc) : "v"(z), "v"(q.y));
 }
 __device__ __forceinline__ unsigned lds_byte_address(const void *p) {
   return (unsigned) (size_t) (const __attribute__((address_space(3))) char *) p;
