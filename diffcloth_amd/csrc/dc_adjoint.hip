@@ -825,6 +825,9 @@ static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, i
 }
 
 void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
+#ifdef DC_ADJ_ONLY_BENCH      // development builds: only the instances of the 10 000-vertex headline (compile time)
+  launch_adj_b<1024, false, false>(S, W, A, B, st);
+#else
   // small meshes, reference iteration (mode 0): the inner solve with P is one product with the explicit inverse (dc_dense.h)
   if (S.dense_inv && S.win_ok && A.mode == 0 && pick_threads_bwd(S.N) == 1024) { launch_adj<1024, true>(S, W, A, B, st); return; }
   if (S.adj_coarse && S.defl_u && S.win_ok && S.win_lds_bytes / 4 >= kCoarseLdsFloats && A.block_pre && A.mode == 1 && pick_threads_bwd(S.N) == 1024) { launch_adj_coarse<1024>(S, W, A, B, st); return; }
@@ -833,6 +836,7 @@ void launch_adjoint_step(const DevSystem &S, const DevWork &W, const BwdArgs &A,
     case 512: launch_adj<512, false>(S, W, A, B, st); break;
     default: launch_adj<1024, false>(S, W, A, B, st); break;
   }
+#endif
 }
 
 }  // namespace dc

@@ -145,13 +145,35 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     if (S.win_ok) {
       // ---- local step + vertex pass, window by window inside LDS (dc_winlib.h) ----
       float *scr = W.cg_r + off;
-      // (issuing the vertex's global reads ahead of the gather — dc_winlib.h, vert_with_pre — costs this kernel 176 B more scratch per
-      // lane and 3 ms per batch step: its registers are the PCG's)
+#ifndef DC_FWD_NO_VPRE
+      // the vertex's unconditional global reads, issued by the per-vertex phase ahead of the gather (dc_winlib.h, vert_with_pre)
+      struct VIn { f3 g, v; int a; float m; int prim; float sq; };
+      auto vert = vert_with_pre([&](int i) {
+        VIn q;
+        q.g = ld3(g, i, N); q.v = ld3(vnow, i, N); q.a = S.att_of_vertex[i]; q.m = S.mass[i]; q.prim = rec_prim[i]; q.sq = S.sq_dinv[i];
+        return q;
+      }, [&](int i, f3 fint, f3, const VIn &q) {
+        f3 f = q.g + fint;
+        if (q.a >= 0) f = f + ((ld3(xfix, q.a, S.Af) - ld3(xn, i, N)) - q.v * h) * (h * S.k_att);   // AttachmentSpring.cpp:25-29
+        f3 r = mk(0, 0, 0);
+        if (q.prim >= 0) {  // calculateDryFrictionVector, primitive part (Simulation.cpp:640-652)
+          f3 n = ld3(rec_n, i, N);
+          f3 d = f - prim_vout(S.prims[q.prim], n) * q.m;
+          r = dry_friction(n, d, mu[S.prims[q.prim].group]);
+        }
+        st3(rec_f, i, N, f);
+        st3(rec_r, i, N, r);
+        f3 rhs = (f + r - q.v * q.m) * q.sq;       // scaled residual D^-1/2 rhs
+        st3(scr, i, N, rhs);
+        part += dot(rhs, rhs);
+      });
+#else
       auto vert = [&](int i, f3 sum, f3) {
         f3 rhs = vertex_body(i, sum);
         st3(scr, i, N, rhs);
         part += dot(rhs, rhs);
       };
+#endif
       element_windows<THREADS, kFwdOpsPrecise>(S, lp, StagePlanar{xn, N}, vnow, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
       __syncthreads();
       PH(0)

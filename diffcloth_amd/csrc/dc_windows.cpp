@@ -92,7 +92,9 @@ Plan plan_for(const HostSystem &H, int own, const std::vector<int> &emin, const 
       if (in(q[0]) || in(q[1]) || in(q[2]) || in(q[3])) { nb++; lo = std::min(lo, emin[id]); hi = std::max(hi, emax[id] + 1); }
     }
     p.vcap = std::max(p.vcap, hi - lo);
-    p.nrcap = std::max(p.nrcap, 2 * nt + nb + 1);      // + the zero vector the padding entries of the incidence rows point at
+    // + the zero vector the padding entries of the incidence rows point at + one dump slot per lane for the masked elements of the
+    // last round (dc_winlib.h: their stores are redirected, not skipped)
+    p.nrcap = std::max(p.nrcap, 2 * nt + nb + 1 + kWinDumpSlots);
   }
   return p;
 }

@@ -20,12 +20,14 @@
 
 namespace dc {
 
+constexpr int kWinDumpSlots = 64;   // result slots behind a window's zero vector, one per lane: where masked elements store (dc_winlib.h)
+
 struct HostWindows {
   bool ok = false;
   int own = 0;                    // owned vertices per window (multiple of 64)
   int nwin = 0;
   int vcap = 0;                   // max vertex span of a window
-  int nrcap = 0;                  // max result vectors of a window (2 * triangles + flaps + 1 zero vector)
+  int nrcap = 0;                  // max result vectors of a window (2 * triangles + flaps + 1 zero vector + kWinDumpSlots)
   size_t lds_bytes = 0;           // 4 * (6 * vcap + 3 * nrcap)
   std::vector<int> win;           // 8 ints per window: v0, v1, lo, vs, tri_off, ntri, bend_off, nbend
   std::vector<int> tri_rec;       // 4 ints per window-triangle: j0 | j1 << 16, j2, bits(area * k_stretch), global triangle id

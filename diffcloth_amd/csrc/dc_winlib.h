@@ -38,18 +38,38 @@ struct In2Plain {
   __device__ __forceinline__ f3 operator()(int i) const { return mk(v[i], v[N + i], v[2 * N + i]); }
 };
 // Elements a thread keeps in flight in the per-element phase: the largest batch (-DDC_WIN_EB, A/B builds) and the dispatch of a batch
-// size to its unrolled variant: `left` rounds remain, the batch takes min(left, MAXB) of them, at least 2 (one masked).
+// size to its unrolled variant.
 #ifndef DC_WIN_EB
 #define DC_WIN_EB 4
 #endif
 constexpr int kWinMaxBatch = DC_WIN_EB;
+#ifndef DC_WIN_SUB1024
+#define DC_WIN_SUB1024 1
+#endif
+constexpr int kWinSubBatch1024 = DC_WIN_SUB1024;
+// scheduling fence behind the gather pass of several elements (all their LDS reads issued before the arithmetic starts); -DDC_WIN_NOFENCE: A/B
+// builds. Not with one element at a time — the 1024-thread kernels: there the fence (like any batch of more than one element) sent the
+// register allocation of the 128-register kernels from 133 to 4 500 spilled registers (measured on the code objects, round 5).
+#ifdef DC_WIN_NOFENCE
+#define DC_WIN_GATHER_FENCE
+#else
+#define DC_WIN_GATHER_FENCE if constexpr (SUB > 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+template <int B, class F>
+__device__ __forceinline__ void batch_exact(int take, F f) {
+  if constexpr (B <= 1) f(std::integral_constant<int, 1>());
+  else {
+    if (take >= B) f(std::integral_constant<int, B>());
+    else batch_exact<B - 1>(take, f);
+  }
+}
+// `left` rounds remain for this WAVE: the batch takes all of them when they fit, half of them (rounded up) when two batches do — 5 rounds run
+// as 3 + 2, not 4 + 1, so that no batch is left without a partner element to overlap with — else MAXB
 template <int MAXB, class F>
 __device__ __forceinline__ int batch_dispatch(int left, F f) {
-  if constexpr (MAXB <= 2) { f(std::integral_constant<int, 2>()); return 2; }
-  else {
-    if (left >= MAXB) { f(std::integral_constant<int, MAXB>()); return MAXB; }
-    return batch_dispatch<MAXB - 1>(left, f);
-  }
+  const int take = left >= 2 * MAXB ? MAXB : (left > MAXB ? (left + 1) / 2 : left);
+  batch_exact<MAXB>(take, f);
+  return take;
 }
 
 // Sub-phase timing of the window passes (-DDC_PROFILE_PHASES): thread 0 of workgroup 0 accumulates shader-clock totals of the
@@ -115,6 +135,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     };
     WinTriRecs<MB, PRECISE> tcur;
     WinBendRecs<MB, PRECISE> bcur;
+    const int dump = 2 * nt + nb + 1 + lane;      // kWinDumpSlots result slots behind the zero vector (dc_windows.cpp: nrcap)
     __syncthreads();
     // two span vertices per thread and round (clamped index, no divergence): their global loads overlap
     for (int j0 = tid; j0 < vs; j0 += 2 * THREADS) {
@@ -135,47 +156,96 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     // The batch size follows the number of rounds left (4, 3 or 2 elements per thread: three unrolled variants) so that
     // e.g. 2250 triangles on 1024 threads cost 3 rounds, not 4. (Exactly ceil(n / THREADS) rounds behind wave-uniform
     // branches inside ONE batch was 2x slower: the branches end the overlap.)
+    // A batch runs in three passes over its elements — gather the vertices from LDS and form the edge vectors (every operator works
+    // on differences to the element's first vertex), compute, store the results — so that the batch is ONE basic block whose LDS reads
+    // all precede its LDS writes: written element by element (read, compute, write, next element) the compiler has to keep element
+    // j + 1's reads behind element j's writes (it cannot prove the planes disjoint), and the elements of a batch ran strictly one
+    // after the other, each with its LDS round trips and its dependent chain of ~60 fp64-rate operations exposed at 2 waves per SIMD.
+    // Elements past the end of the last round (clamped duplicates) store into the lane's dump slot behind the zero vector: a guarded
+    // store would make each element an exec-masked block of its own again.
+    // (SUB elements at a time: the whole batch where the registers allow it — the 512-thread kernels, 256 registers per lane — and
+    // kWinSubBatch1024 = 1 in the 1024-thread kernels, whose 128 registers do not hold the edge vectors of several elements: their four
+    // waves per SIMD hide what a wave's own elements cannot)
+    constexpr int SUBMAX = THREADS >= 1024 ? kWinSubBatch1024 : MB;
     auto tri_compute = [&](auto ebc, const WinTriRecs<MB, PRECISE> &R, int t0) {
       constexpr int EB = decltype(ebc)::value;
+      constexpr int SUB = EB < SUBMAX ? EB : SUBMAX;
 #pragma unroll
-      for (int j = 0; j < EB; j++) {
-        const int t = t0 + j * THREADS;
-        const int j0 = R.r[j].x & 0xffff, j1 = (int) ((unsigned) R.r[j].x >> 16), j2 = R.r[j].y;
-        f3 r0, r1;
-        if constexpr (PRECISE)
-          tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
-                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), R.D[j], R.Dl[j], __int_as_float(R.r[j].z), r0, r1);
-        else
-          tri_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a2xy, L.a2z, j0),
-                 ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), R.D[j], __int_as_float(R.r[j].z), r0, r1);
-        // the triangle's contributions to its corners 1 and 2 (Triangle.cpp: A^T applied to the residual columns; corner 0 = -(c1 + c2))
-        if (t < nt) { stw(L.erxy, L.erz, t, r0 * R.D[j].x + r1 * R.D[j].y); stw(L.erxy, L.erz, nt + t, r0 * R.D[j].z + r1 * R.D[j].w); }
+      for (int s0 = 0; s0 < EB; s0 += SUB) {
+        f3 ea0[SUB], ea1[SUB], eb0[SUB], eb1[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+          const int j = min(s0 + u, EB - 1);
+          const int j0 = R.r[j].x & 0xffff, j1 = (int) ((unsigned) R.r[j].x >> 16), j2 = R.r[j].y;
+          const f3 p0 = ldw(L.a1xy, L.a1z, j0), p1 = ldw(L.a1xy, L.a1z, j1), p2 = ldw(L.a1xy, L.a1z, j2);
+          const f3 q0 = ldw(L.a2xy, L.a2z, j0), q1 = ldw(L.a2xy, L.a2z, j1), q2 = ldw(L.a2xy, L.a2z, j2);
+          ea0[u] = p1 - p0; ea1[u] = p2 - p0; eb0[u] = q1 - q0; eb1[u] = q2 - q0;
+        }
+        DC_WIN_GATHER_FENCE
+        f3 c1[SUB], c2[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+          const int j = min(s0 + u, EB - 1);
+          f3 r0, r1;
+          if constexpr (PRECISE) tri_op.edges(ea0[u], ea1[u], eb0[u], eb1[u], R.D[j], R.Dl[j], __int_as_float(R.r[j].z), r0, r1);
+          else tri_op.edges(ea0[u], ea1[u], eb0[u], eb1[u], R.D[j], __int_as_float(R.r[j].z), r0, r1);
+          // the triangle's contributions to its corners 1 and 2 (Triangle.cpp: A^T applied to the residual columns; corner 0 = -(c1 + c2))
+          c1[u] = r0 * R.D[j].x + r1 * R.D[j].y; c2[u] = r0 * R.D[j].z + r1 * R.D[j].w;
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+          if (s0 + u < EB) {
+            const int t = t0 + (s0 + u) * THREADS;
+            const bool live = t < nt;
+            stw(L.erxy, L.erz, live ? t : dump, c1[u]);
+            stw(L.erxy, L.erz, live ? nt + t : dump, c2[u]);
+          }
+        }
       }
     };
     auto bend_compute = [&](auto ebc, const WinBendRecs<MB, PRECISE> &R, int e0) {
       constexpr int EB = decltype(ebc)::value;
+      constexpr int SUB = EB < SUBMAX ? EB : SUBMAX;
 #pragma unroll
-      for (int j = 0; j < EB; j++) {
-        const int e = e0 + j * THREADS;
-        const int j0 = R.r[j].x & 0xffff, j1 = (int) ((unsigned) R.r[j].x >> 16), j2 = R.r[j].y & 0xffff, j3 = (int) ((unsigned) R.r[j].y >> 16);
-        f3 res;
-        if constexpr (PRECISE)
-          bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
-                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), R.w[j], R.wl[j],
-                  __int_as_float(R.r[j].z), __int_as_float(R.r[j].w), res);
-        else
-          bend_op(ldw(L.a1xy, L.a1z, j0), ldw(L.a1xy, L.a1z, j1), ldw(L.a1xy, L.a1z, j2), ldw(L.a1xy, L.a1z, j3),
-                  ldw(L.a2xy, L.a2z, j0), ldw(L.a2xy, L.a2z, j1), ldw(L.a2xy, L.a2z, j2), ldw(L.a2xy, L.a2z, j3), R.w[j],
-                  __int_as_float(R.r[j].z), __int_as_float(R.r[j].w), res);
-        if (e < nb) stw(L.erxy, L.erz, 2 * nt + e, res);
+      for (int s0 = 0; s0 < EB; s0 += SUB) {
+        f3 ea1[SUB], ea2[SUB], ea3[SUB], eb1[SUB], eb2[SUB], eb3[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+          const int j = min(s0 + u, EB - 1);
+          const int j0 = R.r[j].x & 0xffff, j1 = (int) ((unsigned) R.r[j].x >> 16), j2 = R.r[j].y & 0xffff, j3 = (int) ((unsigned) R.r[j].y >> 16);
+          const f3 p0 = ldw(L.a1xy, L.a1z, j0), q0 = ldw(L.a2xy, L.a2z, j0);
+          ea1[u] = ldw(L.a1xy, L.a1z, j1) - p0; ea2[u] = ldw(L.a1xy, L.a1z, j2) - p0; ea3[u] = ldw(L.a1xy, L.a1z, j3) - p0;
+          eb1[u] = ldw(L.a2xy, L.a2z, j1) - q0; eb2[u] = ldw(L.a2xy, L.a2z, j2) - q0; eb3[u] = ldw(L.a2xy, L.a2z, j3) - q0;
+        }
+        DC_WIN_GATHER_FENCE
+        f3 res[SUB];
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+          const int j = min(s0 + u, EB - 1);
+          if constexpr (PRECISE)
+            bend_op.edges(ea1[u], ea2[u], ea3[u], eb1[u], eb2[u], eb3[u], R.w[j], R.wl[j], __int_as_float(R.r[j].z), __int_as_float(R.r[j].w), res[u]);
+          else
+            bend_op.edges(ea1[u], ea2[u], ea3[u], eb1[u], eb2[u], eb3[u], R.w[j], __int_as_float(R.r[j].z), __int_as_float(R.r[j].w), res[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+          if (s0 + u < EB) {
+            const int e = e0 + (s0 + u) * THREADS;
+            stw(L.erxy, L.erz, e < nb ? 2 * nt + e : dump, res[u]);
+          }
+        }
       }
     };
-    for (int q = 0, rounds = (nt + THREADS - 1) / THREADS; q < rounds;) {      // wave-uniform control flow
+    // Rounds per WAVE (wave-uniform control flow, no barrier inside): a wave whose lanes are all past the end of the list in the last
+    // round skips it — the redirected stores above would otherwise make every wave compute a full round of duplicates there (2 100
+    // triangles on 1024 threads: a third round for the sake of 52 lanes of wave 0)
+    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+    for (int q = 0, rounds = max(nt - wbase + THREADS - 1, 0) / THREADS; q < rounds;) {
       const int left = rounds - q, t0 = q * THREADS + tid;
       q += batch_dispatch<MB>(left, [&](auto ebc) { tri_load(ebc, tcur, t0); tri_compute(ebc, tcur, t0); });
     }
     WPH(1)
-    for (int q = 0, rounds = (nb + THREADS - 1) / THREADS; q < rounds;) {
+    for (int q = 0, rounds = max(nb - wbase + THREADS - 1, 0) / THREADS; q < rounds;) {
       const int left = rounds - q, e0 = q * THREADS + tid;
       q += batch_dispatch<MB>(left, [&](auto ebc) { bend_load(ebc, bcur, e0); bend_compute(ebc, bcur, e0); });
     }
@@ -302,7 +372,11 @@ struct StagePlanar {
 struct FwdTriOp {   // Triangle::project (Triangle.cpp:310-351): columns of h w^2 (T - F)
   float h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float w2, f3 &r0, f3 &r1) const {
-    f3 e0 = (x1 - x0) + (v1 - v0) * h, e1 = (x2 - x0) + (v2 - v0) * h;
+    edges(x1 - x0, x2 - x0, v1 - v0, v2 - v0, D, w2, r0, r1);
+  }
+  // (a0, a1) = edges of x_n from the first vertex, (b0, b1) = the same of v
+  __device__ __forceinline__ void edges(f3 a0, f3 a1, f3 b0, f3 b1, float4 D, float w2, f3 &r0, f3 &r1) const {
+    f3 e0 = a0 + b0 * h, e1 = a1 + b1 * h;
     f3 f0 = e0 * D.x + e1 * D.z, f1 = e0 * D.y + e1 * D.w;
     Polar P = polar3x2(f0, f1);
     const float s = h * w2;
@@ -312,9 +386,12 @@ struct FwdTriOp {   // Triangle::project (Triangle.cpp:310-351): columns of h w^
 struct FwdBendOp {  // TriangleBending::project (TriangleBending.cpp:138-151)
   float h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 x3, f3 v0, f3 v1, f3 v2, f3 v3, float4 w, float n, float w2, f3 &res) const {
-    f3 ev = ((x1 - x0) + (v1 - v0) * h) * w.y;
-    ev = ev + ((x2 - x0) + (v2 - v0) * h) * w.z;
-    ev = ev + ((x3 - x0) + (v3 - v0) * h) * w.w;
+    edges(x1 - x0, x2 - x0, x3 - x0, v1 - v0, v2 - v0, v3 - v0, w, n, w2, res);
+  }
+  __device__ __forceinline__ void edges(f3 a1, f3 a2, f3 a3, f3 b1, f3 b2, f3 b3, float4 w, float n, float w2, f3 &res) const {
+    f3 ev = (a1 + b1 * h) * w.y;
+    ev = ev + (a2 + b2 * h) * w.z;
+    ev = ev + (a3 + b3 * h) * w.w;
     f3 p = mk(0, 0, 0);
     if (n > 1e-6f) p = normalized_fast(ev) * n;
     res = (p - ev) * (h * w2);
@@ -329,7 +406,9 @@ struct FwdBendOp {  // TriangleBending::project (TriangleBending.cpp:138-151)
 struct PreciseTriOp {
   double h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float4 Dl, float w2, f3 &r0, f3 &r1) const {
-    const f3 a0 = x1 - x0, a1 = x2 - x0, b0 = v1 - v0, b1 = v2 - v0;
+    edges(x1 - x0, x2 - x0, v1 - v0, v2 - v0, D, Dl, w2, r0, r1);
+  }
+  __device__ __forceinline__ void edges(f3 a0, f3 a1, f3 b0, f3 b1, float4 D, float4 Dl, float w2, f3 &r0, f3 &r1) const {
     const double e0x = (double) a0.x + h * (double) b0.x, e0y = (double) a0.y + h * (double) b0.y, e0z = (double) a0.z + h * (double) b0.z;
     const double e1x = (double) a1.x + h * (double) b1.x, e1y = (double) a1.y + h * (double) b1.y, e1z = (double) a1.z + h * (double) b1.z;
     const double Dx = (double) D.x + (double) Dl.x, Dy = (double) D.y + (double) Dl.y, Dz = (double) D.z + (double) Dl.z, Dw = (double) D.w + (double) Dl.w;
@@ -347,8 +426,10 @@ struct PreciseTriOp {
 struct PreciseBendOp {   // wl = low-order parts of the cotan weights 1..3 and (.w) of the rest norm
   double h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 x3, f3 v0, f3 v1, f3 v2, f3 v3, float4 w, float4 wl, float n, float w2, f3 &res) const {
+    edges(x1 - x0, x2 - x0, x3 - x0, v1 - v0, v2 - v0, v3 - v0, w, wl, n, w2, res);
+  }
+  __device__ __forceinline__ void edges(f3 a1, f3 a2, f3 a3, f3 b1, f3 b2, f3 b3, float4 w, float4 wl, float n, float w2, f3 &res) const {
     const double w1 = (double) w.y + (double) wl.x, w2d = (double) w.z + (double) wl.y, w3 = (double) w.w + (double) wl.z;
-    const f3 a1 = x1 - x0, a2 = x2 - x0, a3 = x3 - x0, b1 = v1 - v0, b2 = v2 - v0, b3 = v3 - v0;
     const double ex = ((double) a1.x + h * (double) b1.x) * w1 + ((double) a2.x + h * (double) b2.x) * w2d + ((double) a3.x + h * (double) b3.x) * w3;
     const double ey = ((double) a1.y + h * (double) b1.y) * w1 + ((double) a2.y + h * (double) b2.y) * w2d + ((double) a3.y + h * (double) b3.y) * w3;
     const double ez = ((double) a1.z + h * (double) b1.z) * w1 + ((double) a2.z + h * (double) b2.z) * w2d + ((double) a3.z + h * (double) b3.z) * w3;
@@ -371,7 +452,9 @@ struct PreciseBendOp {   // wl = low-order parts of the cotan weights 1..3 and (
 struct HybridTriOp {
   double h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 v0, f3 v1, f3 v2, float4 D, float4 Dl, float w2, f3 &r0, f3 &r1) const {
-    const f3 a0 = x1 - x0, a1 = x2 - x0, b0 = v1 - v0, b1 = v2 - v0;
+    edges(x1 - x0, x2 - x0, v1 - v0, v2 - v0, D, Dl, w2, r0, r1);
+  }
+  __device__ __forceinline__ void edges(f3 a0, f3 a1, f3 b0, f3 b1, float4 D, float4 Dl, float w2, f3 &r0, f3 &r1) const {
     const double e0x = (double) a0.x + h * (double) b0.x, e0y = (double) a0.y + h * (double) b0.y, e0z = (double) a0.z + h * (double) b0.z;
     const double e1x = (double) a1.x + h * (double) b1.x, e1y = (double) a1.y + h * (double) b1.y, e1z = (double) a1.z + h * (double) b1.z;
     const double Dx = (double) D.x + (double) Dl.x, Dy = (double) D.y + (double) Dl.y, Dz = (double) D.z + (double) Dl.z, Dw = (double) D.w + (double) Dl.w;
@@ -395,8 +478,10 @@ struct HybridTriOp {
 struct HybridBendOp {
   double h;
   __device__ __forceinline__ void operator()(f3 x0, f3 x1, f3 x2, f3 x3, f3 v0, f3 v1, f3 v2, f3 v3, float4 w, float4 wl, float n, float w2, f3 &res) const {
+    edges(x1 - x0, x2 - x0, x3 - x0, v1 - v0, v2 - v0, v3 - v0, w, wl, n, w2, res);
+  }
+  __device__ __forceinline__ void edges(f3 a1, f3 a2, f3 a3, f3 b1, f3 b2, f3 b3, float4 w, float4 wl, float n, float w2, f3 &res) const {
     const double w1 = (double) w.y + (double) wl.x, w2d = (double) w.z + (double) wl.y, w3 = (double) w.w + (double) wl.z;
-    const f3 a1 = x1 - x0, a2 = x2 - x0, a3 = x3 - x0, b1 = v1 - v0, b2 = v2 - v0, b3 = v3 - v0;
     const double ex = ((double) a1.x + h * (double) b1.x) * w1 + ((double) a2.x + h * (double) b2.x) * w2d + ((double) a3.x + h * (double) b3.x) * w3;
     const double ey = ((double) a1.y + h * (double) b1.y) * w1 + ((double) a2.y + h * (double) b2.y) * w2d + ((double) a3.y + h * (double) b3.y) * w3;
     const double ez = ((double) a1.z + h * (double) b1.z) * w1 + ((double) a2.z + h * (double) b2.z) * w2d + ((double) a3.z + h * (double) b3.z) * w3;
@@ -435,9 +520,11 @@ __device__ __forceinline__ HybridBendOp fwd_bend_op(float, double h) { return Hy
 struct AdjTriOp {   // Triangle::projectToManifoldBackward (Triangle.cpp:354-451) in closed form
   float h2;
   __device__ __forceinline__ void operator()(f3 q0, f3 q1, f3 q2, f3 x0, f3 x1, f3 x2, float4 D, float w2, f3 &r0, f3 &r1) const {
-    f3 e0 = x1 - x0, e1 = x2 - x0;
+    edges(q1 - q0, q2 - q0, x1 - x0, x2 - x0, D, w2, r0, r1);
+  }
+  // (d0, d1) = edges of y from the first vertex, (e0, e1) = the same of x_new
+  __device__ __forceinline__ void edges(f3 d0, f3 d1, f3 e0, f3 e1, float4 D, float w2, f3 &r0, f3 &r1) const {
     Polar P = polar3x2(e0 * D.x + e1 * D.z, e0 * D.y + e1 * D.w);
-    f3 d0 = q1 - q0, d1 = q2 - q0;
     f3 y0 = d0 * D.x + d1 * D.z, y1 = d0 * D.y + d1 * D.w;
     const float c = (dot(P.t1, y0) - dot(P.t0, y1)) * fast_rcp(P.trS);
     f3 z0 = y0 * P.i00 + y1 * P.i01, z1 = y0 * P.i01 + y1 * P.i11;
@@ -450,10 +537,13 @@ struct AdjTriOp {   // Triangle::projectToManifoldBackward (Triangle.cpp:354-451
 struct AdjBendOp {  // TriangleBending::backwardGradient (TriangleBending.cpp:154-172)
   float h2;
   __device__ __forceinline__ void operator()(f3 q0, f3 q1, f3 q2, f3 q3, f3 x0, f3 x1, f3 x2, f3 x3, float4 w, float n, float w2, f3 &res) const {
-    f3 ey = (q1 - q0) * w.y + (q2 - q0) * w.z + (q3 - q0) * w.w;
+    edges(q1 - q0, q2 - q0, q3 - q0, x1 - x0, x2 - x0, x3 - x0, w, n, w2, res);
+  }
+  __device__ __forceinline__ void edges(f3 d1, f3 d2, f3 d3, f3 e1, f3 e2, f3 e3, float4 w, float n, float w2, f3 &res) const {
+    f3 ey = d1 * w.y + d2 * w.z + d3 * w.w;
     res = ey;
     if (n > 1e-6f) {
-      f3 ev = (x1 - x0) * w.y + (x2 - x0) * w.z + (x3 - x0) * w.w;
+      f3 ev = e1 * w.y + e2 * w.z + e3 * w.w;
       const float ien = fast_rsqrt(dot(ev, ev));
       f3 eh = ev * ien;
       res = ey - (ey - eh * dot(eh, ey)) * (n * ien);
