@@ -20,6 +20,18 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y,
 __device__ __forceinline__ f3 fma3(f3 a, float s, f3 acc) { return {fmaf(a.x, s, acc.x), fmaf(a.y, s, acc.y), fmaf(a.z, s, acc.z)}; }
 __device__ __forceinline__ f3 ld3(const float *p, int i, int n) { return {p[i], p[n + i], p[2 * n + i]}; }
 __device__ __forceinline__ void st3(float *p, int i, int n, f3 v) { p[i] = v.x; p[n + i] = v.y; p[2 * n + i] = v.z; }
+// One plane of a planar vector as a buffer resource of `count` floats: a store (load) at an index >= count is dropped (returns 0) by the
+// hardware's range check — rows past the end of a vector cost no branch, and count = 0 switches a whole stream of stores off.
+struct PlaneBuf {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ void st(int i, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs, i * 4, 0, 0); }
+  __device__ __forceinline__ float ld(int i) const { return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, i * 4, 0, 0)); }
+};
+__device__ __forceinline__ PlaneBuf plane_buf(const float *p, int count) {
+  PlaneBuf b;
+  b.rs = __builtin_amdgcn_make_buffer_rsrc((void *) p, 0, count * 4, 0x00020000);
+  return b;
+}
 __device__ __forceinline__ f3 normalized(f3 a) {
   float n2 = dot(a, a);
   return n2 > 0.f ? a * (1.0f / sqrtf(n2)) : a;    // Eigen::normalized(): unchanged when the norm is 0

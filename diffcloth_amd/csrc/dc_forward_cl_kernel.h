@@ -236,10 +236,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         const float pz = vz[li];
         float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
         const int base = li - 512;
-        consume_p(cur, vxy, vz, base, ax, ay, az);
+        consume_pf(cur, vxy, vz, base, ax, ay, az);      // all gathers of the batch in flight before the first product (dc_pklib.h)
         for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
           load_batch(cur, row, s0);
-          consume_p(cur, vxy, vz, base, ax, ay, az);
+          consume_pf(cur, vxy, vz, base, ax, ay, az);
         }
         ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
         part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;

@@ -194,13 +194,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         }
       }
       if constexpr (!H16) {
-      for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread (clamped index), then the LDS stores
+      const PlaneBuf tb0 = plane_buf(scr, N), tb1 = plane_buf(scr + N, N), tb2 = plane_buf(scr + 2 * N, N);      // (rows past N read 0)
+      for (int k0 = 0; k0 < VPT; k0 += 4) {     // 4 rows = 12 loads in flight per thread, then the LDS stores
         float t[4][3];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int i = tq + min(k0 + j, VPT - 1) * THREADS, ic = min(i, N - 1);
-          const float ok = (i < N) ? 1.f : 0.f;
-          t[j][0] = scr[ic] * ok; t[j][1] = scr[N + ic] * ok; t[j][2] = scr[2 * N + ic] * ok;
+          const int i = tq + min(k0 + j, VPT - 1) * THREADS;
+          t[j][0] = tb0.ld(i); t[j][1] = tb1.ld(i); t[j][2] = tb2.ld(i);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -264,20 +264,19 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     // residual, A p and (most of) the iterate of the scaled CG live in registers from here to the update
     float rr[VPT][3], ap[VPT][3], xx[XR > 0 ? XR : 1][3];
     if constexpr (H16) {      // the right-hand side goes from the work array straight into the residual registers
+      // (range-checked buffer loads: rows past N read 0, a row costs one shift for its three addresses — as plain loads the clamped
+      // 64-bit indices of the 20 rows were common subexpressions of every row loop of the PD iteration, lived across the CG loop in
+      // scratch, and each reload was an `s_waitcnt vmcnt(0)` in the middle of the loads it fed)
       const float *scr = W.cg_r + off;
+      const PlaneBuf sb0 = plane_buf(scr, N), sb1 = plane_buf(scr + N, N), sb2 = plane_buf(scr + 2 * N, N);
       part = 0.f;
 #pragma unroll
-      for (int k0 = 0; k0 < VPT; k0 += 4) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (k0 + j < VPT) {
-            const int k = k0 + j, i = tq + k * THREADS, ic = min(i, N - 1);
-            const float ok = (i < N) ? 1.f : 0.f;
-            rr[k][0] = scr[ic] * ok; rr[k][1] = scr[N + ic] * ok; rr[k][2] = scr[2 * N + ic] * ok;
-            part = fmaf(rr[k][0], rr[k][0], fmaf(rr[k][1], rr[k][1], fmaf(rr[k][2], rr[k][2], part)));
-          }
-        }
+      for (int k = 0; k < VPT; k++) {
+        const int i = tq + k * THREADS;
+        rr[k][0] = sb0.ld(i); rr[k][1] = sb1.ld(i); rr[k][2] = sb2.ld(i);
       }
+#pragma unroll
+      for (int k = 0; k < VPT; k++) part = fmaf(rr[k][0], rr[k][0], fmaf(rr[k][1], rr[k][1], fmaf(rr[k][2], rr[k][2], part)));
     }
     double rz = block_sum<THREADS>((double) part, red);
     float hs = 1.f, pn = 0.f;               // H16: scale of the direction in LDS (a power of two) and the bound on its entries it comes from
@@ -509,12 +508,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
       bool seed = A.cg_seed && iter > 0;
       if (seed) {
         if constexpr (H16) hs = half_scale(dnorm);      // |d_prev|_2 from the update loop of the previous PD iteration
+        const PlaneBuf pb0 = plane_buf(dprev, N), pb1 = plane_buf(dprev + N, N), pb2 = plane_buf(dprev + 2 * N, N);
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
-          const int i = tq + k * THREADS, ic = min(i, N - 1);
-          const float okf = i < N ? 1.f : 0.f;
-          if constexpr (H16) lh[i] = pack_h4(dprev[ic] * (okf * hs), dprev[N + ic] * (okf * hs), dprev[2 * N + ic] * (okf * hs));
-          else { ((float2 *) lp)[i] = make_float2(dprev[ic] * okf, dprev[N + ic] * okf); lp[2 * NP + i] = dprev[2 * N + ic] * okf; }
+          const int i = tq + k * THREADS;
+          const float d0 = pb0.ld(i), d1 = pb1.ld(i), d2 = pb2.ld(i);      // (0 past N)
+          if constexpr (H16) lh[i] = pack_h4(d0 * hs, d1 * hs, d2 * hs);
+          else { ((float2 *) lp)[i] = make_float2(d0, d1); lp[2 * NP + i] = d2; }
         }
       }
       for (int it = 0; it < A.cg_max;) {
@@ -586,16 +586,22 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     // registers and stays there for the best-iterate bookkeeping below
     part = 0.f;
     float partd = 0.f;
+    // (stores through range-checked buffer resources: the rows past N of the last chunks are dropped by the hardware, and the recycled
+    // direction's array has no records at all when the seed is off — guarded with `if (i < N)` every one of the 3 x VPT stores was an
+    // exec-masked block of its own with its address arithmetic inside, 46 ... 60 k cycles per PD iteration)
+    const PlaneBuf vb0 = plane_buf(vnow, N), vb1 = plane_buf(vnow + N, N), vb2 = plane_buf(vnow + 2 * N, N);
+    const PlaneBuf qb = plane_buf((const float *) S.sq_dinv, N);
+    const int nd = A.cg_seed ? N : 0;
+    const PlaneBuf db0 = plane_buf(dprev, nd), db1 = plane_buf(dprev + N, nd), db2 = plane_buf(dprev + 2 * N, nd);
 #pragma unroll
     for (int k0 = 0; k0 < VPT; k0 += 4) {
       float vq[4][3], sq[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (k0 + j < VPT) {
-          const int i = min(tq + (k0 + j) * THREADS, N - 1);
-          sq[j] = S.sq_dinv[i];
-#pragma unroll
-          for (int c = 0; c < 3; c++) vq[j][c] = vnow[c * N + i];
+          const int i = tq + (k0 + j) * THREADS;
+          sq[j] = qb.ld(i);
+          vq[j][0] = vb0.ld(i); vq[j][1] = vb1.ld(i); vq[j][2] = vb2.ld(i);
         }
       }
 #pragma unroll
@@ -607,7 +613,9 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           for (int c = 0; c < 3; c++) {
             const float xs = (k < XR) ? xx[k < XR ? k : 0][c] : lx[((k - XR) * 3 + c) * THREADS + tq];
             ap[k][c] = xs * sq[j];             // delta v (A p is dead here)
-            if (i < N) { vnow[c * N + i] = vq[j][c] + ap[k][c]; part = fmaf(ap[k][c], ap[k][c], part); if (A.cg_seed) dprev[c * N + i] = xs; if constexpr (H16) partd = fmaf(xs, xs, partd); }
+            (c == 0 ? vb0 : (c == 1 ? vb1 : vb2)).st(i, vq[j][c] + ap[k][c]);
+            (c == 0 ? db0 : (c == 1 ? db1 : db2)).st(i, xs);
+            if (i < N) { part = fmaf(ap[k][c], ap[k][c], part); if constexpr (H16) partd = fmaf(xs, xs, partd); }
           }
         }
       }

@@ -57,6 +57,25 @@ __device__ __forceinline__ void consume_p(const int4 (&e)[PB], const float2 *lxy
     ax = fmaf(a2, q2.x, ax); ay = fmaf(a2, q2.y, ay); az = fmaf(a2, z2, az);
   }
 }
+// the same with all 24 gathers of the batch issued before the first product (see consume_h): the kernels that have the registers for it
+__device__ __forceinline__ void consume_pf(const int4 (&e)[PB], const float2 *lxy, const float *lz, int base, float &ax, float &ay, float &az) {
+  float2 q[PB][3];
+  float z[PB][3];
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    const int c0 = base + (e[j].w & 1023), c1 = base + ((e[j].w >> 10) & 1023), c2 = base + ((e[j].w >> 20) & 1023);
+    q[j][0] = lxy[c0]; q[j][1] = lxy[c1]; q[j][2] = lxy[c2];
+    z[j][0] = lz[c0]; z[j][1] = lz[c1]; z[j][2] = lz[c2];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < PB; j++) {
+    const float a0 = __int_as_float(e[j].x), a1 = __int_as_float(e[j].y), a2 = __int_as_float(e[j].z);
+    ax = fmaf(a0, q[j][0].x, ax); ay = fmaf(a0, q[j][0].y, ay); az = fmaf(a0, z[j][0], az);
+    ax = fmaf(a1, q[j][1].x, ax); ay = fmaf(a1, q[j][1].y, ay); az = fmaf(a1, z[j][1], az);
+    ax = fmaf(a2, q[j][2].x, ax); ay = fmaf(a2, q[j][2].y, ay); az = fmaf(a2, z[j][2], az);
+  }
+}
 // The same with the search direction held as four halves per row (x, y, z, unused: 8 bytes, ONE ds_read_b64 per non-zero instead of a
 // b64 + a b32, and a third less LDS): the products are v_fma_mix_f32 (half operand converted inside the FMA).
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));

@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT)
 from diffcloth_amd import build as B
 
 name, extra, files = sys.argv[1], sys.argv[2].split(), sys.argv[3:]
-B.build_engine()
+if not os.environ.get('DC_SKIP_BASE'):      # DC_SKIP_BASE=1: link against the objects as they are (only the listed sources are recompiled)
+    B.build_engine()
 objdir = os.path.join(B.LIBDIR, "obj_" + name)
 os.makedirs(objdir, exist_ok=True)
 flags = [f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-function", "-I", os.path.join(ROOT, "include")] + extra
