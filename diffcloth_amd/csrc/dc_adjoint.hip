@@ -674,8 +674,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     };
     if constexpr (BLK) build_blocks();
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
-    // (meshes the engine found ill-conditioned, S.adj_coarse: the fp64 fall-back has the coarse level the fp32 solve lacks — hand over after 400)
-    const int kcap = std::min(A.it_cap > 0 ? 4 * A.it_cap : 1600, S.adj_coarse ? 400 : 1 << 30);
+    // (meshes the engine found ill-conditioned: where the fp64 fall-back of THIS instance has the coarse level — the condition of
+    // bicgstab64, dc_adjoint64.h — the fp32 solve hands over after 400 iterations; everywhere else it keeps its budget, the fall-back
+    // there is block-Jacobi only and much slower per digit: ADVICE r04)
+    const bool fb_coarse = COARSE && S.defl_u != nullptr && S.adj_coarse && C.lds_floats >= kCoarseLdsFloats;
+    const int kcap = std::min(A.it_cap > 0 ? 4 * A.it_cap : 1600, fb_coarse ? 400 : 1 << 30);
     // true residual of the start: g itself for u = 0 (mode 1), g - K u after the reference iteration hit its cap (mode 0);
     // `gin` holds the right-hand side of the next fp32 solve: g, later the fp64 residual rounded to fp32
     double rr_true = warm ? rr_warm : gnorm * gnorm;

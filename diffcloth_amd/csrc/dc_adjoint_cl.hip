@@ -276,8 +276,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   if (gnorm > 0) {
     // ---- direct solve of K u = g in mixed precision (see dc_adjoint.hip): fp32 BiCGSTAB for corrections of the fp64 residual ----
     const double stop = (double) A.rel_tol * (double) A.rel_tol * gnorm * gnorm;
-    // (meshes the engine found ill-conditioned, S.adj_coarse: the fp64 fall-back has the coarse level the fp32 solve lacks — hand over after 400)
-    const int kcap = std::min(A.it_cap > 0 ? 4 * A.it_cap : 1600, S.adj_coarse ? 400 : 1 << 30);
+    // (meshes the engine found ill-conditioned: where the fp64 fall-back of THIS instance has the coarse level — the condition of
+    // bicgstab64, dc_adjoint64.h — the fp32 solve hands over after 400 iterations; everywhere else it keeps its budget, the fall-back
+    // there is block-Jacobi only and much slower per digit: ADVICE r04)
+    const bool fb_coarse = COARSE && S.defl_u != nullptr && S.adj_coarse && hc_off >= kCoarseLdsFloats;
+    const int kcap = std::min(A.it_cap > 0 ? 4 * A.it_cap : 1600, fb_coarse ? 400 : 1 << 30);
     constexpr int VB = 4;
     bool fallback = false;
     double rr = rr_true;

@@ -108,6 +108,11 @@ struct dc_ctx {
   int cus = 0;                      // compute units of the device
   int bandwidth = 0;                // of the scalar system matrix in device numbering
   int defl_k = 0, defl_probe = 0;   // deflation space of the forward solve (dc_deflate.h)
+  // the last deflation build of this context and what it was built from: a rebuild that leaves P unchanged (another tolerance, contact flags,
+  // primitives ...) skips the probe solve and the eigen-solve (0.9 s on the 7 742-vertex dress)
+  HostDeflation defl_cache;
+  uint64_t defl_key = 0;
+  bool defl_cache_valid = false, defl_cache_built = false;
 };
 
 namespace {
@@ -376,6 +381,28 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   return DC_OK;
 }
 
+// Which deflation space the forward solve wants (dc_params::forward_deflation: -1 decide by the probe solve, 0 never, > 0 always; the
+// development switch DC_DEFLATION overrides it: 0 = off, 1 = always) — one rule for device and host-only contexts, read at every build.
+static int deflation_want(const dc_params &p) {
+  const char *envd = getenv("DC_DEFLATION");
+  if (envd) return atoi(envd) > 0 ? 16 : 0;
+  return p.forward_deflation > 0 ? 16 : p.forward_deflation;
+}
+// HostDeflation::build through the context's cache (key: the scalar system matrix, the request, the padded row count)
+static bool build_deflation_cached(dc_ctx *c, const HostSystem &H, int want, int rows_padded, HostDeflation **out) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void *q, size_t n) { const unsigned char *b = (const unsigned char *) q; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+  mix(&H.N, sizeof(int)); mix(&want, sizeof(int)); mix(&rows_padded, sizeof(int));
+  mix(H.P_ptr.data(), H.P_ptr.size() * sizeof(H.P_ptr[0])); mix(H.P_col.data(), H.P_col.size() * sizeof(H.P_col[0]));
+  mix(H.P_val.data(), H.P_val.size() * sizeof(H.P_val[0])); mix(H.mass.data(), H.mass.size() * sizeof(H.mass[0]));
+  if (!c->defl_cache_valid || c->defl_key != h) {
+    c->defl_cache_built = c->defl_cache.build(H, want, rows_padded);
+    c->defl_key = h; c->defl_cache_valid = true;
+  }
+  *out = &c->defl_cache;
+  return c->defl_cache_built;
+}
+
 // K for this batch: enough parts to give every CU a workgroup (B rollouts x K <= CUs, K <= 8), at least as many as a mesh too
 // large for the one-workgroup kernel needs; DC_CLUSTER=k forces k (development switch; 0 / 1 = off).
 int choose_cluster(dc_ctx *c) {
@@ -587,6 +614,7 @@ int dc_set_primitives(dc_ctx *c, int count, const dc_primitive *prims) {
 int dc_build(dc_ctx *c) {
   if (!c) return DC_ERR_INVALID;
   if (!c->mesh_set) return fail(c, DC_ERR_STATE, "dc_build: dc_set_mesh has not been called");
+  c->inj_slot = -1;      // a rebuilt system no longer matches a record handed in before (dc_set_record)
   const dc_params &p = c->params;
   HostSystem &H = c->host;
   H.att_vertex = c->att_user;
@@ -604,9 +632,9 @@ int dc_build(dc_ctx *c) {
     c->S.pk_ok = HP.build(H) ? 1 : 0;
     c->S.nwin = HW.nwin; c->S.pk_vpt = HP.vpt; c->S.pk_threads = HP.threads;
     {
-      HostDeflation HD;
+      HostDeflation *HD = nullptr;
       c->defl_k = 0; c->defl_probe = 0;
-      if (c->S.pk_ok && c->S.win_ok) { HD.build(H, p.forward_deflation > 0 ? 16 : p.forward_deflation, HP.threads * HP.vpt); c->defl_k = HD.k; c->defl_probe = HD.probe_iterations; }
+      if (c->S.pk_ok && c->S.win_ok) { build_deflation_cached(c, H, deflation_want(p), HP.threads * HP.vpt, &HD); c->defl_k = HD->k; c->defl_probe = HD->probe_iterations; }
     }
     c->built = true;
     return DC_OK;
@@ -763,14 +791,14 @@ int dc_build(dc_ctx *c) {
     }
   }
   {  // irregular garments: the 16 lowest eigenvectors of the scaled matrix as a deflation space of the forward solve (dc_deflate.h)
-    HostDeflation HD;
+    HostDeflation *HDp = nullptr;
     S.defl_u = nullptr; S.defl_au = nullptr; S.defl_g = nullptr; c->defl_k = 0; c->defl_probe = 0;
-    static const char *envd = getenv("DC_DEFLATION");      // development switch: 0 = off, 1 = always
-    const int want = envd ? (atoi(envd) > 0 ? 16 : 0) : (p.forward_deflation > 0 ? 16 : p.forward_deflation);
+    const int want = deflation_want(p);
     // (the deflated FORWARD kernels exist for 512 threads x >= 4 rows: meshes of more than 1536 vertices, dc_forward_pk_defl.hip; smaller meshes
     //  solve their forward step with the explicit inverse and use the space for the adjoint's coarse level only)
     S.fwd_defl = 0;
-    if (S.pk_ok && S.win_ok && HD.build(H, want, S.pk_threads * S.pk_vpt)) {
+    if (S.pk_ok && S.win_ok && build_deflation_cached(c, H, want, S.pk_threads * S.pk_vpt, &HDp)) {
+      const HostDeflation &HD = *HDp;
       if ((rc = upload<float>(c, &S.defl_u, HD.U))) return rc;
       if ((rc = upload<float>(c, &S.defl_au, HD.AU))) return rc;
       if ((rc = upload<float>(c, &S.defl_g, HD.G))) return rc;
@@ -779,7 +807,7 @@ int dc_build(dc_ctx *c) {
     }
     static const char *envc = getenv("DC_ADJ_COARSE");      // development switch: 0 = block preconditioner only in the adjoint's fall-back
     S.adj_coarse = (S.defl_u && !(envc && atoi(envc) == 0)) ? 1 : 0;
-    c->defl_probe = HD.probe_iterations;
+    c->defl_probe = HDp ? HDp->probe_iterations : 0;
   }
   {  // small meshes: explicit inverse of the scaled matrix (dc_dense.h) for the forward global step
     HostDense HD;
@@ -1065,6 +1093,7 @@ int dc_set_state(dc_ctx *c, int slot, const double *x, const double *v) {
   if (rc) return rc;
   if (!x || !v) return fail(c, DC_ERR_INVALID, "dc_set_state: null state");
   HIPCHK(c, hipSetDevice(c->device));
+  if (slot == c->inj_slot || slot + 1 == c->inj_slot) c->inj_slot = -1;      // a record handed in with dc_set_record described the state overwritten here
   const size_t se = slot_elems(c);
   if ((rc = h2d_planar(c, x, c->X + se * slot, c->host.N, 0, true))) return rc;
   if ((rc = h2d_planar(c, v, c->V + se * slot, c->host.N, 1, true))) return rc;
@@ -1315,6 +1344,7 @@ int dc_set_state_dev(dc_ctx *c, int slot, const void *d_x, const void *d_v, int 
   if (rc) return rc;
   if (!d_x || !d_v) return fail(c, DC_ERR_INVALID, "dc_set_state_dev: null state");
   HIPCHK(c, hipSetDevice(c->device));
+  if (slot == c->inj_slot || slot + 1 == c->inj_slot) c->inj_slot = -1;      // (see dc_set_state)
   const size_t se = slot_elems(c);
   launch_dev_to_planar(d_x, is_f32, c->X + se * slot, c->B, c->host.N, c->d_user_of, c->stream);
   launch_dev_to_planar(d_v, is_f32, c->V + se * slot, c->B, c->host.N, c->d_user_of, c->stream);

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
         spmv(wz, part2, seed, part3);
         PH(2)
         double pAp, pr = rz;
-        if constexpr (H16) block_sum2_f<THREADS>(part2, part3, red2, pAp, pr);      // exact line search along the rounded direction
+        if constexpr (H16) block_sum2_f_nb<THREADS>(part2, part3, red2, pAp, pr);      // exact line search along the rounded direction
         else {
           pAp = block_sum_f<THREADS>(part2, red);
           if (seed) pr = block_sum_f<THREADS>(part3, red);
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
             part2 = fmaf(rr[k][c], rr[k][c], part2);
           }
         }
-        double rz_new = block_sum_f<THREADS>(part2, red);
+        double rz_new = H16 ? block_sum_f_nb<THREADS>(part2, red) : block_sum_f<THREADS>(part2, red);
         it++; cg_total++;
         if (!(rz_new > stop)) break;
         if (defl && seed) {                 // after the recycled direction: project the residual, then plain CG from it (beta = 0)
@@ -563,10 +563,20 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           pn = sqrtf((float) rz_new) + beta * pn;
           const float hs_new = half_scale(pn), c2 = beta * hs_new / hs;
           hs = hs_new;
+          // DEFL: deflate() has used the first rows of the direction's LDS as float scratch; after it beta = 0 and the old direction
+          // must not be READ as halves at all (a float's bits can be an Inf / NaN half, and 0 * Inf is NaN): its bits are masked off
+          // (tests/test_gpu_configs.py::test_forced_deflation_on_the_bench_cloth)
+          [[maybe_unused]] const int keep = (beta != 0.f) ? -1 : 0;
 #pragma unroll
           for (int k = 0; k < VPT; k++) {
             const int i = tz + k * THREADS;
-            const h4 q = lh[i];
+            h4 q = lh[i];
+            if constexpr (DEFL) {
+              int2 b;
+              __builtin_memcpy(&b, &q, 8);
+              b.x &= keep; b.y &= keep;
+              __builtin_memcpy(&q, &b, 8);
+            }
             lh[i] = pack_h4(fmaf(c2, (float) q.x, rr[k][0] * hs), fmaf(c2, (float) q.y, rr[k][1] * hs), fmaf(c2, (float) q.z, rr[k][2] * hs));
           }
         } else {

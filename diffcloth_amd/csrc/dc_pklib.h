@@ -187,6 +187,32 @@ __device__ __forceinline__ void block_sum2_f(float &a, float &b, double *red, do
   for (int k = 0; k < NW; k++) { sa += red[k]; sb += red[NW + k]; }
 }
 
+// The two reductions of a CG iteration without their leading barrier: each has a buffer of its own (`red2`: p.Ap and p.r, `red`: r.r),
+// written once per iteration, and between a buffer's read and its next write lie at least two barriers of the loop (the other reduction's
+// and the one that ends the direction update) — 3 instead of 5 barriers per iteration.
+template <int THREADS>
+__device__ __forceinline__ double block_sum_f_nb(float v, double *red) {
+  v = wave_sum_f(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) red[w] = (double) v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; k++) s += red[k];
+  return s;
+}
+template <int THREADS>
+__device__ __forceinline__ void block_sum2_f_nb(float &a, float &b, double *red, double &sa, double &sb) {
+  a = wave_sum_f(a); b = wave_sum_f(b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  constexpr int NW = THREADS / 64;
+  if (l == 0) { red[w] = (double) a; red[NW + w] = (double) b; }
+  __syncthreads();
+  sa = 0; sb = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { sa += red[k]; sb += red[NW + k]; }
+}
+
 template <int NP>
 __device__ __forceinline__ void consume(const int4 (&e)[PB], const float *lp, int base, float &ax, float &ay, float &az) {
   consume_p(e, (const float2 *) lp, lp + 2 * NP, base, ax, ay, az);

@@ -137,16 +137,22 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     WinBendRecs<MB, PRECISE> bcur;
     const int dump = 2 * nt + nb + 1 + lane;      // kWinDumpSlots result slots behind the zero vector (dc_windows.cpp: nrcap)
     __syncthreads();
-    // two span vertices per thread and round (clamped index, no divergence): their global loads overlap
-    for (int j0 = tid; j0 < vs; j0 += 2 * THREADS) {
-      const int jb = j0 + THREADS;
-      const bool vb = jb < vs;
-      const int ia = lo + j0, ib = lo + (vb ? jb : j0);
-      const f3 ua = in2(ia), ub = in2(ib);
-      const f3 sa = stage1(ia), sb = stage1(ib);
-      stw(L.a2xy, L.a2z, j0, ua);
-      stw(L.a1xy, L.a1z, j0, sa);
-      if (vb) { stw(L.a2xy, L.a2z, jb, ub); stw(L.a1xy, L.a1z, jb, sb); }
+    // SVR span vertices per thread and round (clamped index, no divergence): their global loads overlap. A span is ~1.3 windows wide:
+    // three vertices per thread stage it in ONE round of the 512-thread kernels (two rounds = two exposed memory round trips per window
+    // before: 5.2 k of a window's 29 k cycles in the forward step), two in one round of the 1024-thread kernels.
+    constexpr int SVR = THREADS < 1024 ? 3 : 2;
+    for (int j0 = tid; j0 < vs; j0 += SVR * THREADS) {
+      f3 u[SVR], sv[SVR];
+#pragma unroll
+      for (int q = 0; q < SVR; q++) {
+        const int j = j0 + q * THREADS, i = lo + (j < vs ? j : j0);
+        u[q] = in2(i); sv[q] = stage1(i);
+      }
+#pragma unroll
+      for (int q = 0; q < SVR; q++) {
+        const int j = j0 + q * THREADS;
+        if (q == 0 || j < vs) { stw(L.a2xy, L.a2z, j, u[q]); stw(L.a1xy, L.a1z, j, sv[q]); }
+      }
     }
     if (tid == 0) stw(L.erxy, L.erz, 2 * nt + nb, mk(0, 0, 0));      // the zero vector the padding entries of the per-vertex rows point at
     __syncthreads();

@@ -455,3 +455,44 @@ def test_dress_7742_forward_solve_with_spectral_deflation(monkeypatch, split):
     print(f"[dress 7742, deflated forward solve, {8 if split else 1} workgroup(s)] PCG iterations per PD iteration {per_pd[0]:.0f} with the 16-vector deflation space, {per_pd[1]:.0f} without; "
           f"step time for {B} rollouts {a['ms']:.0f} ms / {b['ms']:.0f} ms")
     assert per_pd[0] <= 0.45 * per_pd[1]
+
+
+def test_forced_deflation_on_the_bench_cloth(monkeypatch):
+    """the 10 000-vertex instance of the deflated forward kernel keeps its search direction as halves in LDS (H16) and
+    its projection uses the first rows of that LDS as float scratch; after a projection behind the recycled direction (beta = 0) the
+    direction update must not READ those rows as halves (a float's bits can be an Inf / NaN half, and 0 * Inf is NaN). No shipped mesh
+    reaches that instance (the 7 742-vertex dress runs 16 rows per thread with fp32 planes), so the space is forced onto the bench cloth
+    (forward_deflation = 1): states finite and the undeflated run's within the fp32 floor, same PD iteration counts, fewer PCG iterations."""
+    monkeypatch.setenv("DC_CLUSTER", "1")
+    import meshes
+    V, F = meshes.grid_cloth(100, 100, 4.5, 4.5, "DOWN")
+    V = f32(V)
+    c = f32(meshes.sphere_scene_center(V, 2.0))
+    B, S = 4, 3
+    X0 = np.stack([f32((V + np.array([0.05 * b, -0.05, 0.03 * b])).reshape(-1)) for b in range(B)])
+    out = {}
+    for want in (1, 0):
+        e = capi.Engine(0)
+        e.set_mesh(V, F)
+        e.set_params(time_step=1.0 / 180, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_tol=1e-8, backward_tol=5e-4, cg_rel_tol=1e-4,
+                     cg_max_iter=500, gradient_clipping=1, selfcollision_enabled=0, adjoint_mode=1, adjoint_rel_tol=1e-6, forward_deflation=want)
+        e.set_primitives([dict(kind=capi.DC_PRIM_SPHERE, group=0, center=c, radius=2.0, mu=0.5)])
+        e.build()
+        k, _ = e.deflation()
+        assert k == (16 if want else 0)
+        assert e.layout()["packet_kernel"] and e.layout()["element_windows"]      # (10 000 vertices: 20 rows per thread, the H16 instance)
+        e.alloc_batch(B, S)
+        assert e.cluster() == 1
+        e.set_state(0, X0, np.zeros_like(X0))
+        sts = [e.step_forward(s) for s in range(S)]
+        x, v = e.get_state(S)
+        out[want] = dict(x=x, v=v, pd=np.array([st["pd_iters"] for st in sts]), cg=np.array([st["cg_iters"] for st in sts]),
+                         conv=np.array([st["converged"] for st in sts]))
+    a, b = out[1], out[0]
+    assert np.isfinite(a["x"]).all() and np.isfinite(a["v"]).all()
+    dx = np.abs(a["x"] - b["x"]).max()
+    print(f"\n[bench cloth, forced 16-vector deflation, H16 direction] max|dx| vs the plain kernel {dx:.2e}; PD iterations {a['pd'].sum()} / {b['pd'].sum()}, "
+          f"PCG iterations {a['cg'].sum()} / {b['cg'].sum()}")
+    assert (a["conv"] == 1).all() and (b["conv"] == 1).all()
+    assert dx <= 2e-5 and np.abs(a["pd"] - b["pd"]).max() <= 1
+    assert a["cg"].sum() < b["cg"].sum()
