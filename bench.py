@@ -366,8 +366,17 @@ def main():
         ent["bound"] = max(cand, key=cand.get)
         ent["bound_frac"] = cand[ent["bound"]]
         return ent
+    # The roof the resident forward design is actually up against: instruction issue. Floor of the PCG products alone — 6 instructions per
+    # non-zero (bit-field extract, address add, ds_read_b64, three v_fma_mix_f32), each a wave-instruction of 4 cycles on its SIMD
+    # (VERDICT r04's accounting; MI355X_MICROARCH.md quotes 2 cycles for a plain v_fma_f32, which halves the figure) — per CU:
+    #   cycles = products of the CU's rollouts x 6 x nnz x (1 / 64 lanes) x (1 / 4 SIMDs) x 4
+    nnz_p = float(getattr(e, "nnz", 12.8 * N))
+    issue_floor_cycles = (cg_f / max(B * cl, 1)) * 6.0 * nnz_p / 64.0 / 4.0 * 4.0
     k_fwd = kernel_entry("k_pd_step_cl" if cl > 1 else "k_pd_step_pk", bytes_fwd, lds_cycles_fwd, kt["fwd_ms"], kt["fwd_launches"],
-                         {"streaming_model_bytes": bytes_fwd_stream, "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
+                         {"issue_floor_cycles_per_cu": issue_floor_cycles,
+                          "issue_frac": issue_floor_cycles / max(kt["fwd_ms"] * 1e-3 * clock_hz, 1e-30),
+                          "issue_model": "VALU / LDS issue floor of the PCG products alone: 6 instructions per non-zero x 4 cycles per wave-instruction and SIMD, over the launch time",
+                          "streaming_model_bytes": bytes_fwd_stream, "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
                           "model": "compulsory HBM bytes of the resident design: (108 I_pd + 64 per step) N; CG vectors never leave the CU"})
     k_bwd = kernel_entry("k_adjoint_step_cl" if cl > 1 else "k_adjoint_step", bytes_bwd, lds_cycles_bwd, kt["bwd_ms"], kt["bwd_launches"],
                          {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + 48.0 * cyc + 60.0 * B * K) * N,
@@ -398,7 +407,13 @@ def main():
                        "fp64_fallback_iters": it64, "adjoint_precision": "mixed: fp32 BiCGSTAB corrections of the fp64 residual",
                        "converged_fraction": conv / (B * K),
                        "slowest_rollout_over_mean": {"forward_pcg_iterations": float(cg_per_rollout.max() / max(cg_per_rollout.mean(), 1e-30)),
-                                                     "adjoint_iterations": float(adj_per_rollout.max() / max(adj_per_rollout.mean(), 1e-30))},
+                                                     "adjoint_iterations": float(adj_per_rollout.max() / max(adj_per_rollout.mean(), 1e-30)),
+                                                     # what starting a rollout's backward sweep as soon as ITS forward sweep ends could save: per-rollout
+                                                     # sweep times modelled as the launch times scaled by the rollout's share of the iterations
+                                                     "two_launches_over_per_rollout_handover": float(
+                                                         (kt["fwd_ms"] + kt["bwd_ms"]) / max((kt["fwd_ms"] * cg_per_rollout / max(cg_per_rollout.max(), 1e-30)
+                                                                                             + kt["bwd_ms"] * adj_per_rollout / max(adj_per_rollout.max(), 1e-30)).max(), 1e-30)),
+                                                     "correlation_forward_backward_work": float(np.corrcoef(cg_per_rollout, adj_per_rollout)[0, 1]) if B > 1 else 0.0},
                        "batch_steps_per_s": K / dt, "gradients_finite": finite,
                        "dL_dmu_sum_over_job": float(np.asarray(dmu_total).sum()),
                        "per_rank_sweep_ms": rank_ms, "allreduce_ms": t_reduce * 1e3,

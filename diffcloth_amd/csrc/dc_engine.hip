@@ -634,7 +634,7 @@ int dc_build(dc_ctx *c) {
     {
       HostDeflation *HD = nullptr;
       c->defl_k = 0; c->defl_probe = 0;
-      if (c->S.pk_ok && c->S.win_ok) { build_deflation_cached(c, H, deflation_want(p), HP.threads * HP.vpt, &HD); c->defl_k = HD->k; c->defl_probe = HD->probe_iterations; }
+      if (c->S.win_ok) { build_deflation_cached(c, H, deflation_want(p), c->S.pk_ok ? HP.threads * HP.vpt : round64(H.N), &HD); c->defl_k = HD->k; c->defl_probe = HD->probe_iterations; }
     }
     c->built = true;
     return DC_OK;
@@ -788,6 +788,14 @@ int dc_build(dc_ctx *c) {
       if ((rc = upload<int>(c, &S.pk_n, HP.pk_n))) return rc;
       if ((rc = upload<float>(c, &S.sq_dinv, HP.sq_dinv))) return rc;
       S.pk_vpt = HP.vpt; S.pk_threads = HP.threads; S.pk_ok = 1;
+    } else {
+      // no packet tables (matrix bandwidth beyond the +-511 of their column deltas: the reference's 17 562-vertex dress, 647 after
+      // renumbering): the scaling D^-1/2 alone, for the coarse level of the ADJOINT's preconditioner (dc_adjoint64.h), which such a mesh needs
+      std::vector<float> sq((size_t) round64(N), 0.f);
+      for (int r = 0; r < N; r++)
+        for (int k = H.P_ptr[r]; k < H.P_ptr[r + 1]; k++)
+          if (H.P_col[k] == r) sq[r] = (float) (1.0 / std::sqrt(H.P_val[k]));
+      if ((rc = upload<float>(c, &S.sq_dinv, sq))) return rc;
     }
   }
   {  // irregular garments: the 16 lowest eigenvectors of the scaled matrix as a deflation space of the forward solve (dc_deflate.h)
@@ -797,13 +805,13 @@ int dc_build(dc_ctx *c) {
     // (the deflated FORWARD kernels exist for 512 threads x >= 4 rows: meshes of more than 1536 vertices, dc_forward_pk_defl.hip; smaller meshes
     //  solve their forward step with the explicit inverse and use the space for the adjoint's coarse level only)
     S.fwd_defl = 0;
-    if (S.pk_ok && S.win_ok && build_deflation_cached(c, H, want, S.pk_threads * S.pk_vpt, &HDp)) {
+    if (S.win_ok && build_deflation_cached(c, H, want, S.pk_ok ? S.pk_threads * S.pk_vpt : round64(N), &HDp)) {
       const HostDeflation &HD = *HDp;
       if ((rc = upload<float>(c, &S.defl_u, HD.U))) return rc;
       if ((rc = upload<float>(c, &S.defl_au, HD.AU))) return rc;
       if ((rc = upload<float>(c, &S.defl_g, HD.G))) return rc;
       c->defl_k = HD.k;
-      S.fwd_defl = (S.pk_threads == 512 && S.pk_vpt >= 4) ? 1 : 0;
+      S.fwd_defl = (S.pk_ok && S.pk_threads == 512 && S.pk_vpt >= 4) ? 1 : 0;
     }
     static const char *envc = getenv("DC_ADJ_COARSE");      // development switch: 0 = block preconditioner only in the adjoint's fall-back
     S.adj_coarse = (S.defl_u && !(envc && atoi(envc) == 0)) ? 1 : 0;

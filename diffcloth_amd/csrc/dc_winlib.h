@@ -47,6 +47,10 @@ constexpr int kWinMaxBatch = DC_WIN_EB;
 #define DC_WIN_SUB1024 1
 #endif
 constexpr int kWinSubBatch1024 = DC_WIN_SUB1024;
+#ifndef DC_WIN_LEGACY1024
+#define DC_WIN_LEGACY1024 1
+#endif
+constexpr bool kWinLegacy1024 = DC_WIN_LEGACY1024 != 0;
 // scheduling fence behind the gather pass of several elements (all their LDS reads issued before the arithmetic starts); -DDC_WIN_NOFENCE: A/B
 // builds. Not with one element at a time — the 1024-thread kernels: there the fence (like any batch of more than one element) sent the
 // register allocation of the 128-register kernels from 133 to 4 500 spilled registers (measured on the code objects, round 5).
@@ -176,7 +180,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     auto tri_compute = [&](auto ebc, const WinTriRecs<MB, PRECISE> &R, int t0) {
       constexpr int EB = decltype(ebc)::value;
       constexpr int SUB = EB < SUBMAX ? EB : SUBMAX;
-      if constexpr (SUBMAX == 1) {      // one element at a time, its store guarded (the 1024-thread kernels: measured 6 % faster there than the passes below)
+      if constexpr (SUBMAX == 1 && kWinLegacy1024) {      // one element at a time, its store guarded (the 1024-thread kernels: measured 6 % faster there than the passes below)
 #pragma unroll
         for (int j = 0; j < EB; j++) {
           const int t = t0 + j * THREADS;
@@ -227,7 +231,7 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     auto bend_compute = [&](auto ebc, const WinBendRecs<MB, PRECISE> &R, int e0) {
       constexpr int EB = decltype(ebc)::value;
       constexpr int SUB = EB < SUBMAX ? EB : SUBMAX;
-      if constexpr (SUBMAX == 1) {
+      if constexpr (SUBMAX == 1 && kWinLegacy1024) {
 #pragma unroll
         for (int j = 0; j < EB; j++) {
           const int e = e0 + j * THREADS;
@@ -277,11 +281,10 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     // Rounds per WAVE (wave-uniform control flow, no barrier inside): a wave whose lanes are all past the end of the list in the last
     // round skips it — the redirected stores above would otherwise make every wave compute a full round of duplicates there (2 100
     // triangles on 1024 threads: a third round for the sake of 52 lanes of wave 0)
-#ifdef DC_WIN_WG_ROUNDS
-    const int wbase = 0;
-#else
-    const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-#endif
+    // (the 1024-thread kernels keep the rounds of the workgroup and their guarded stores: a masked element is an exec-masked block a wave
+    // without live lanes branches over. Measured round 5, rounds per wave there: one-workgroup adjoint 11.90 -> 11.79 ms, split adjoint
+    // 3.60 -> 4.08 ms per batch step)
+    const int wbase = (SUBMAX == 1 && kWinLegacy1024) ? 0 : __builtin_amdgcn_readfirstlane(tid & ~63);
     for (int q = 0, rounds = max(nt - wbase + THREADS - 1, 0) / THREADS; q < rounds;) {
       const int left = rounds - q, t0 = q * THREADS + tid;
       q += batch_dispatch<MB>(left, [&](auto ebc) { tri_load(ebc, tcur, t0); tri_compute(ebc, tcur, t0); });

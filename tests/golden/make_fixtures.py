@@ -60,6 +60,10 @@ def main():
         "sock": "src/assets/meshes/remeshed/sock1055-2081.obj",
         "dress": "src/assets/meshes/remeshed/dress-handsup-drape.obj",
         "dress7k": "src/assets/meshes/remeshed/dress-v7k-f14k.obj",      # 7 742 vertices: the garment-sized self-contact workload of tools/bench_dress7k.py
+        # the reference's own 10k-class meshes: the 17 562-vertex dress (needs >= 3 workgroups per rollout) and the
+        # 96 x 96 performance fabric lying on the slope plane (9 216 vertices: the one-workgroup kernels at 18 rows per thread)
+        "dress17k": "src/assets/meshes/remeshed/dress-v17k-f34k.obj",
+        "perf96": "src/assets/meshes/remeshed/Slope/perfFabric4-96x96-onPlane.obj",
     }
     out = {}
     for name, rel in meshes.items():

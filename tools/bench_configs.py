@@ -15,7 +15,10 @@ def run(name, B, K, cfg, prims_fn, att, selfc, fwd_tol, orient="FRONT", dim=6.0,
     if ONLY and not any(k in name for k in ONLY):
         return
     V, F = scenes.load_mesh(cfg["mesh"])
-    P, rmin, rmax = scenes.normalise_model(V, orient, dim)
+    if cfg.get("raw"):      # the mesh file's own coordinates (the slope fabric lies on its plane as shipped)
+        P, rmin, rmax = V, V.min(axis=0), V.max(axis=0)
+    else:
+        P, rmin, rmax = scenes.normalise_model(V, orient, dim)
     P = f32(P)
     e = capi.Engine(0)
     e.set_mesh(P, F); e.set_attachments(att)
@@ -58,5 +61,15 @@ run("C3 hat", 64, 10, scenes.HAT, hat, scenes.HAT["attachments"], False, 1e-8)
 run("C3 hat, reference adjoint iteration, tol 5e-4", 64, 10, scenes.HAT, hat, scenes.HAT["attachments"], False, 1e-8, adjoint_mode=0)
 run("C3 hat, reference adjoint iteration, tol 1e-9", 64, 10, scenes.HAT, hat, scenes.HAT["attachments"], False, 1e-8, adjoint_mode=0, bwd_tol=1e-9)
 run("C5 sock", 512, 10, scenes.SOCK, leg, scenes.SOCK["attachments"], False, 1e-9, "CUSTOM", 5.0)
+# the reference's own 10k-class meshes (tests/test_gpu_garments10k.py holds their parity tests)
+def slope(rmin, rmax):
+    V, _ = scenes.load_mesh("perf96")
+    P = f32(V); c0 = P.mean(axis=0)
+    n = np.linalg.svd(P - c0)[2][2]; n = -n if n[1] < 0 else n
+    ex = np.array([1.0, 0.0, 0.0]); ex = ex - n * (ex @ n); ex /= np.linalg.norm(ex); es = np.cross(n, ex)
+    return [dict(kind=capi.DC_PRIM_PLANE, group=0, center=f32(c0 - 0.02 * n), top_offset=f32(-3.6 * ex + 3.6 * es), corner2=f32(3.6 * ex + 3.6 * es), radius=0.0, mu=0.2)]
+run("perfFabric 96x96 sliding on the slope plane (9216 vertices, all in contact)", 256, 10, dict(mesh="perf96", raw=True, h=1.0 / 100, density=0.2, k_stretch=50.0, k_bend=1e-5), slope, [], False, 1e-8)
+# (the 17 562-vertex dress has no throughput line: bandwidth 647 after renumbering puts it on the general global-memory kernels — 355 PCG iterations
+#  per PD iteration, seconds per step; tests/test_gpu_garments10k.py holds its parity test)
 D = dict(mesh="dress", h=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
 run("dress (3634 vertices, self-collision on)", 256, 5, D, none, [0, 1, 2, 3, 4, 5], True, 1e-8, "FRONT", 8.0)
