@@ -278,13 +278,36 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
     }
     __syncthreads();
     APH(0)
-    element_windows<THREADS>(S, C.lds, [&](int i) {      // (both candidates loaded, then selected: one memory round trip, not two —
-      const int m = mark[i];                              //  loading y only behind the mark: 12.7 -> 13.2 ms per batch step)
+    auto stage_y = [&](int i) {      // (both candidates loaded, then selected: one memory round trip, not two —
+      const int m = mark[i];         //  loading y only behind the mark: 12.7 -> 13.2 ms per batch step)
       const f3 yi = ld3(C.y, i, N);
       f3 z = ld3(zin, i, N);
       if (precond) z = z * S.dinv[i];
       return mk(m ? yi.x : z.x, m ? yi.y : z.y, m ? yi.z : z.z);
-    }, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
+    };
+    if constexpr (PRE) {
+      // the per-vertex operator takes y_i (attachment vertices only) from its own reads instead of the window's input plane: the per-vertex phase
+      // then reads the result planes only and the next window stages without a barrier in between (dc_winlib.h, NOA)
+      struct VertInY { f3 z, d, y; float m; int a; };
+      auto vert_sp = vert_with_pre_noa([&](int i) {
+        VertInY q;
+        q.z = ld3(zin, i, N);
+        if (precond) q.z = q.z * S.dinv[i];
+        q.d = d1 ? ld3(d1, i, N) : mk(0, 0, 0);
+        q.m = S.mass[i]; q.a = S.att_of_vertex[i];
+        q.y = mk(0, 0, 0);
+        if (q.a >= 0) q.y = mark[i] ? ld3(C.y, i, N) : q.z;
+        return q;
+      }, [&](int i, f3 sum, f3, const VertInY &q) {
+        f3 o = q.z * q.m + sum;
+        if (q.a >= 0) o = o + q.y * (h2 * S.k_att);   // attachment: dp/dx = 0 (AttachmentSpring.cpp:35-37)
+        st3(out, i, N, o);
+        if (d1) a1 += dot(o, q.d);
+        a2 += dot(o, o);
+      });
+      element_windows<THREADS>(S, C.lds, stage_y, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert_sp);
+    } else
+    element_windows<THREADS>(S, C.lds, stage_y, C.xnew, AdjTriOp{h2}, AdjBendOp{h2}, vert);
   } else {
     // (self-contact working set beyond the LDS: y = (I + dr_df)^T z is formed in global memory first)
     contact_transpose<THREADS>(S, C, zin, precond, C.y);     // ends with a barrier

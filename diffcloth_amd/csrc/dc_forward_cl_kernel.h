@@ -146,11 +146,11 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     };
     // ---- local step + vertex pass through this part's element windows ----
     float psum = 0.f;
-    auto vert = [&](int i, f3 sum, f3) {
+    auto vert = vert_noa([&](int i, f3 sum, f3) {      // (does not use input 1 at the vertex: dc_winlib.h, NOA)
       f3 rhs = vertex_body(i, sum);
       st3(scr, i, N, rhs);
       psum += dot(rhs, rhs);
-    };
+    });
     element_windows_t<THREADS, kFwdOpsPrecise>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
     __syncthreads();
     CPH(0)

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
 #ifndef DC_FWD_NO_VPRE
       // the vertex's unconditional global reads, issued by the per-vertex phase ahead of the gather (dc_winlib.h, vert_with_pre)
       struct VIn { f3 g, v; int a; float m; int prim; float sq; };
-      auto vert = vert_with_pre([&](int i) {
+      auto vert = vert_with_pre_noa([&](int i) {
         VIn q;
         q.g = ld3(g, i, N); q.v = ld3(vnow, i, N); q.a = S.att_of_vertex[i]; q.m = S.mass[i]; q.prim = rec_prim[i]; q.sq = S.sq_dinv[i];
         return q;

@@ -95,13 +95,27 @@ static __device__ long long g_win_ph[4];
 // vertex's stores, which the compiler may not move them across (one exposed L2 round trip per vertex and window otherwise).
 template <class V, class = void> struct vert_has_pre : std::false_type {};
 template <class V> struct vert_has_pre<V, std::void_t<decltype(std::declval<V &>().pre(0))>> : std::true_type {};
-template <class P, class O>
+// NOA ("no a"): the operator does not use input 1 at the vertex (its third argument). The per-vertex phase of a window then reads the result
+// planes only, and the NEXT window may stage its span — which overwrites the input planes — without a barrier in between: a window costs two barriers
+// instead of three, and the waves that finish their vertices first have their staging loads in flight while the others finish.
+template <class P, class O, bool NOA = false>
 struct VertWithPre {
+  static constexpr bool kIgnoresInput1 = NOA;
   P p; O o;
   __device__ __forceinline__ auto pre(int i) { return p(i); }
   template <class Q> __device__ __forceinline__ void operator()(int i, f3 sum, f3 a, const Q &q) { o(i, sum, a, q); }
 };
 template <class P, class O> __device__ __forceinline__ VertWithPre<P, O> vert_with_pre(P p, O o) { return VertWithPre<P, O>{p, o}; }
+template <class P, class O> __device__ __forceinline__ VertWithPre<P, O, true> vert_with_pre_noa(P p, O o) { return VertWithPre<P, O, true>{p, o}; }
+template <class O>
+struct VertNoA {
+  static constexpr bool kIgnoresInput1 = true;
+  O o;
+  __device__ __forceinline__ void operator()(int i, f3 sum, f3 a) { o(i, sum, a); }
+};
+template <class O> __device__ __forceinline__ VertNoA<O> vert_noa(O o) { return VertNoA<O>{o}; }
+template <class V, class = void> struct vert_ignores_a : std::false_type {};
+template <class V> struct vert_ignores_a<V, std::enable_if_t<V::kIgnoresInput1>> : std::true_type {};
 
 template <int EB, bool PRECISE>
 struct WinTriRecs { int4 r[EB]; float4 D[EB]; float4 Dl[PRECISE ? EB : 1]; };
@@ -140,7 +154,8 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
     WinTriRecs<MB, PRECISE> tcur;
     WinBendRecs<MB, PRECISE> bcur;
     const int dump = 2 * nt + nb + 1 + lane;      // kWinDumpSlots result slots behind the zero vector (dc_windows.cpp: nrcap)
-    __syncthreads();
+    constexpr bool NOA = vert_ignores_a<VertOp>::value;
+    if (!NOA || w == w0) __syncthreads();      // (NOA: the previous window's per-vertex phase reads the result planes only; the staging below writes the input planes)
     // SVR span vertices per thread and round (clamped index, no divergence): their global loads overlap. A span is ~1.3 windows wide:
     // three vertices per thread stage it in ONE round of the 512-thread kernels (two rounds = two exposed memory round trips per window
     // before: 5.2 k of a window's 29 k cycles in the forward step), two in one round of the 1024-thread kernels.
@@ -158,8 +173,9 @@ __device__ __forceinline__ void element_windows_t(const TB &S, int w0, int w1, f
         if (q == 0 || j < vs) { stw(L.a2xy, L.a2z, j, u[q]); stw(L.a1xy, L.a1z, j, sv[q]); }
       }
     }
-    if (tid == 0) stw(L.erxy, L.erz, 2 * nt + nb, mk(0, 0, 0));      // the zero vector the padding entries of the per-vertex rows point at
     __syncthreads();
+    if (tid == 0) stw(L.erxy, L.erz, 2 * nt + nb, mk(0, 0, 0));      // the zero vector the padding entries of the per-vertex rows point at (read behind the next barrier;
+                                                                     // written behind this one: the result planes may be in use by the previous window until here)
     WPH(0)
     // per-element phase: up to 4 elements of a thread at a time, their records loaded up front (clamped index, no
     // divergence) so that the L2 round trips and the gather -> math chains of a batch overlap instead of queueing up.
