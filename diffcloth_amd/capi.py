@@ -55,7 +55,7 @@ class dc_record(C.Structure):
 EXPORTED_SYMBOLS = [
     "dc_create", "dc_destroy", "dc_last_error", "dc_version", "dc_set_mesh", "dc_set_attachments", "dc_set_params",
     "dc_set_primitives", "dc_build", "dc_default_params", "dc_set_solver", "dc_set_flags", "dc_get_counts", "dc_get_system_matrix",
-    "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force", "dc_set_vertex_forces", "dc_get_force_gradient",
+    "dc_get_vertex_data", "dc_alloc_batch", "dc_set_state", "dc_get_state", "dc_set_mu", "dc_set_uniform_force", "dc_set_vertex_forces", "dc_set_vertex_force_field", "dc_get_force_gradient",
     "dc_step_forward", "dc_get_record", "dc_get_contacts", "dc_get_self_contacts", "dc_step_backward", "dc_rollout_forward",
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
@@ -236,6 +236,11 @@ class Engine:
     def set_vertex_forces(self, f):
         a = None if f is None else self._vec(f, 3 * self.N)
         self._chk(self.lib.dc_set_vertex_forces(self.h, _d(a)))
+
+    def set_vertex_force_field(self, f):
+        """second per-vertex force term with factor 1 (the constant force field next to a scheduled wind with fall-off)"""
+        a = None if f is None else self._vec(f, 3 * self.N)
+        self._chk(self.lib.dc_set_vertex_force_field(self.h, _d(a)))
 
     def get_force_gradient(self):
         """h^2 (I + dr_df)^T u* per vertex of the last backward step (dL_dfext_vec of the reference)."""

@@ -169,6 +169,8 @@ struct FwdArgs {
   const float *fu;              // [B][3] uniform extra force or nullptr
   const float *fv;              // [B][3][N] per-vertex extra force (wind with fall-off, constant force field) or nullptr
   const float *fv_scale;        // [B] factor on fv for this step (per-step wind factor of a force schedule) or nullptr = 1
+  const float *fv2;             // [B][3][N] second per-vertex term with factor 1 (the constant force field next to a wind with fall-off and its own
+                                // time factor, Simulation.cpp:91-93 + :99-106) or nullptr
   dc_step_stats *stats;         // [B]
   SelfRec self;                 // record k+1 (filled by k_self_detect before the step kernel runs)
   float fwd_tol, cg_tol;

@@ -81,6 +81,8 @@ struct dc_ctx {
   bool fu_set = false;
   float *fv = nullptr;              // [B][3][N] per-vertex extra force
   bool fv_set = false;
+  float *fv2 = nullptr;             // [B][3][N] second per-vertex force term, factor 1 (dc_set_vertex_force_field)
+  bool fv2_set = false;
   float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DMU = nullptr, *target = nullptr;
   float *DXF = nullptr;             // [(tape+1)][B][3][Af] dL_dxfixed of the step that produced the slot
   // device-resident schedules of the fused rollouts (dc_set_*_schedule); flags per tape slot
@@ -199,6 +201,7 @@ FwdArgs fwd_args(dc_ctx *c, int slot) {
   A.rec_f = c->F + se * (slot + 1); A.rec_r = c->R + se * (slot + 1); A.rec_n = c->NRM + se * (slot + 1);
   A.rec_prim = c->PRIM + sp * (slot + 1);
   A.x_fixed = c->xf_cur; A.mu = c->mu; A.fu = c->fu_set ? c->fu : nullptr; A.fv = c->fv_set ? c->fv : nullptr;
+  A.fv2 = c->fv2_set ? c->fv2 : nullptr;
   A.fv_scale = nullptr; A.slot_xfix = 0; A.slot_fu = 0; A.slot_fvs = 0;
   // scheduled values of this step (dc_set_*_schedule) take precedence over the current ones
   if (c->S.Af > 0 && c->sched_xf[slot + 1]) A.x_fixed = c->XF + (size_t) c->B * 3 * c->S.Af * (slot + 1);
@@ -989,6 +992,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->mu, (size_t) B * G))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fu, (size_t) B * 3))) return rc;
   if ((rc = dev_alloc(c, pool, &c->fv, (size_t) B * 3 * N))) return rc;
+  if ((rc = dev_alloc(c, pool, &c->fv2, (size_t) B * 3 * N))) return rc;
   if ((rc = dev_alloc(c, pool, &c->GX, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->GV, se))) return rc;
   if ((rc = dev_alloc(c, pool, &c->IX, se))) return rc;
@@ -1006,7 +1010,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   if ((rc = dev_alloc(c, pool, &c->bstats, (size_t) B * slots))) return rc;
   c->stage_elems = se;
   for (int k = 0; k < 4; k++) if ((rc = dev_alloc(c, pool, &c->stage[k], se))) return rc;
-  c->fu_set = false; c->fv_set = false;
+  c->fu_set = false; c->fv_set = false; c->fv2_set = false;
   // default fixed-point targets = rest positions of the attached vertices (FixedPoint::pos = pos_rest)
   if (Af > 0) {
     std::vector<float> xf((size_t) B * 3 * Af);
@@ -1043,6 +1047,17 @@ int dc_set_uniform_force(dc_ctx *c, const double *f) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->fu, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
   c->fu_set = true;
+  return DC_OK;
+}
+
+int dc_set_vertex_force_field(dc_ctx *c, const double *f) {
+  if (!c || c->B <= 0) return fail(c, DC_ERR_STATE, "dc_set_vertex_force_field: no batch");
+  if (!f) { c->fv2_set = false; return DC_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = h2d_planar(c, f, c->fv2, c->host.N, 0, true);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->fv2_set = true;
   return DC_OK;
 }
 

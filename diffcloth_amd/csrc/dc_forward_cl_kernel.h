@@ -75,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // detection + layering of this step: part 0, then the lists change hands
     X.site = 2;
-    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lds); __syncthreads(); }
+    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lds, A.fv2); __syncthreads(); }
   }
   // number of self contacts of this step: part 0 knows it (its own detection, or the stand-alone detection kernel's record) and
   // hands it to the others inside an exchange, so that no part ever has to read it from memory another part wrote
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     f3 v = ld3c(vinb, i);
     f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
     if (A.fv) fext = fext + ld3(A.fv + off, i, N) * fvs;
+    if (A.fv2) fext = fext + ld3(A.fv2 + off, i, N);
     f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
     st3c(vnb, i, v0);
     st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h

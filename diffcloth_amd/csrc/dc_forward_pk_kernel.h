@@ -77,7 +77,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   srec.pair += (size_t) step * A.slot_self; srec.nrm += (size_t) step * A.slot_self; srec.dvec += (size_t) step * A.slot_self;
   srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // fused sweeps: detection + layering of this step run here (dc_selflib.h)
-    self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lp);
+    self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lp, A.fv2);
     __syncthreads();
   }
   const float *mu = A.mu + (size_t) b * S.ngroups;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
     f3 v = ld3(vn, i, N);
     f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
     if (A.fv) fext = fext + ld3(A.fv + off, i, N) * fvs;
+    if (A.fv2) fext = fext + ld3(A.fv2 + off, i, N);
     f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
     st3(vnow, i, N, v0);
     st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h

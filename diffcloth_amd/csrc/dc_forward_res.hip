@@ -57,6 +57,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_res(const DevSystem *__rest
     f3 v = ld3(vn, i, N);
     f3 fext = grav * m + fu;                      // fillForces (Simulation.cpp:55-116)
     if (A.fv) fext = fext + ld3(A.fv + off, i, N) * (A.fv_scale ? A.fv_scale[b] : 1.f);
+    if (A.fv2) fext = fext + ld3(A.fv2 + off, i, N);
     f3 v0 = v + fext * (h / m);                   // (s_n - x_n) / h
     st3(vnow, i, N, v0);
     st3(g, i, N, v0 * m);                         // M (s_n - x_n) / h

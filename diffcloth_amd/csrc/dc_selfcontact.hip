@@ -20,7 +20,7 @@ namespace dc {
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_self_detect(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
   __shared__ int lds[kSelfDetectLdsInts];
-  self_detect_rollout<THREADS>(*Sp, W, blockIdx.x, A.x_in, A.v_in, A.rec_prim, A.self, A.fu, A.fv, A.fv_scale, lds);
+  self_detect_rollout<THREADS>(*Sp, W, blockIdx.x, A.x_in, A.v_in, A.rec_prim, A.self, A.fu, A.fv, A.fv_scale, lds, A.fv2);
 }
 
 static int pick_threads_sd(int N) { return N <= 1536 ? 256 : (N <= 6144 ? 512 : 1024); }

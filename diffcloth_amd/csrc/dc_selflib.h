@@ -133,7 +133,7 @@ __device__ int contact_layering_rest(const SelfTmp &t, int nact, int remaining) 
 // rec_prim / self / fu are the step's record pointers of the whole batch (indexed by b inside). Call with all threads.
 template <int THREADS>
 __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const DevWork &W, int b, const float *x_in, const float *v_in,
-                                                    int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, const float *fv_all, const float *fvs_all, int *lds) {
+                                                    int *rec_prim_all, const SelfRec &selfrec, const float *fu_all, const float *fv_all, const float *fvs_all, int *lds, const float *fv2_all = nullptr) {
   float *redf = (float *) lds;              // [16]
   int *hist = lds + 16;                     // [kSelfCells + 1]
   int *cursor = hist + kSelfCells + 1;      // [kSelfCells]
@@ -160,6 +160,7 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
     const float m = S.mass[i];
     f3 fext = grav * m + fu;
     if (fv) fext = fext + ld3(fv, i, N) * fvs;
+    if (fv2_all) fext = fext + ld3(fv2_all + (size_t) b * 3 * N, i, N);
     return ld3(vn, i, N) + fext * (h / m);
   };
 

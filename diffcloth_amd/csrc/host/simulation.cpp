@@ -624,8 +624,8 @@ void Simulation::step() {
   rec.deviceSlot = prev.deviceSlot + 1;
   rec.x_prev = prev.x; rec.v_prev = prev.v;
   rec.windFactor = windFactorAt(rec.t, rec.stepIdx);       // (the reference indexes perstepWindFactor by forwardRecords.size())
-  // fillForces (Simulation.cpp:55-116): uniform wind through dc_set_uniform_force; wind with per-vertex fall-off and the
-  // constant force field through dc_set_vertex_forces
+  // fillForces (Simulation.cpp:55-116): uniform wind through dc_set_uniform_force; wind with per-vertex fall-off through
+  // dc_set_vertex_forces, the constant force field through dc_set_vertex_force_field (the same two terms a fused rollout uses)
   const bool fallOff = windEnabled && windHasFallOff() && windFallOff.size() == 3 * (size_t) N;
   const bool field = enableConstantForcefield && external_force_field.size() == 3 * (size_t) N;
   if (windEnabled && !fallOff) {
@@ -633,14 +633,12 @@ void Simulation::step() {
     for (int d = 0; d < 3; d++) f[d] = wind[d] * windNorm * rec.windFactor;
     check(ctx, dc_set_uniform_force(ctx, f), "dc_set_uniform_force");
   } else check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
-  if (fallOff || field) {
+  if (fallOff) {
     VecXd fv(3 * (size_t) N, 0.0);
-    for (size_t k = 0; k < fv.size(); k++) {
-      if (fallOff) fv[k] += wind[k % 3] * windNorm * rec.windFactor * windFallOff[k];
-      if (field) fv[k] += external_force_field[k];
-    }
+    for (size_t k = 0; k < fv.size(); k++) fv[k] = wind[k % 3] * windNorm * rec.windFactor * windFallOff[k];
     check(ctx, dc_set_vertex_forces(ctx, fv.data()), "dc_set_vertex_forces");
   } else check(ctx, dc_set_vertex_forces(ctx, nullptr), "dc_set_vertex_forces");
+  check(ctx, dc_set_vertex_force_field(ctx, field ? external_force_field.data() : nullptr), "dc_set_vertex_force_field");
   rec.x_fixedpoints = fixedPointTargets(rec.t);
   rec.simDurartionFraction = rec.t / (sceneConfig.timeStep * sceneConfig.stepNum);
   rec.splines = controlPointSplines;
@@ -834,7 +832,6 @@ bool Simulation::rolloutOnDevice(int nsteps) {
   const size_t n3 = 3 * (size_t) N, Af = attachmentVertices.size();
   const bool fallOff = windEnabled && windHasFallOff() && windFallOff.size() == n3;
   const bool field = enableConstantForcefield && external_force_field.size() == n3;
-  if (fallOff && field) return false;                                        // two per-vertex terms with different time factors
   const auto tStart = std::chrono::steady_clock::now();
   pushParams();
   const int slot0 = forwardRecords.back().deviceSlot;
@@ -859,11 +856,14 @@ bool Simulation::rolloutOnDevice(int nsteps) {
   // from here on a failing device call (capacity overflow, exchange time-out ...) must not leave half-made records behind
   try {
   check(ctx, dc_clear_schedules(ctx), "dc_clear_schedules");
-  if (fallOff || field) {
+  // the two per-vertex terms of fillForces (Simulation.cpp:91-106): the wind with fall-off, whose factor changes from step to step (the
+  // schedule's fv_scale), and the constant force field, factor 1 in every step (dc_set_vertex_force_field)
+  if (fallOff) {
     VecXd fv(n3, 0.0);
-    for (size_t k = 0; k < n3; k++) fv[k] = fallOff ? wind[k % 3] * windNorm * windFallOff[k] : external_force_field[k];
+    for (size_t k = 0; k < n3; k++) fv[k] = wind[k % 3] * windNorm * windFallOff[k];
     check(ctx, dc_set_vertex_forces(ctx, fv.data()), "dc_set_vertex_forces");
   } else check(ctx, dc_set_vertex_forces(ctx, nullptr), "dc_set_vertex_forces");
+  check(ctx, dc_set_vertex_force_field(ctx, field ? external_force_field.data() : nullptr), "dc_set_vertex_force_field");
   check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
   check(ctx, dc_set_force_schedule(ctx, slot0, nsteps, (windEnabled && !fallOff) ? fu.data() : nullptr, fallOff ? fvs.data() : nullptr), "dc_set_force_schedule");
   if (Af > 0) check(ctx, dc_set_fixed_point_schedule(ctx, slot0, nsteps, xf.data()), "dc_set_fixed_point_schedule");

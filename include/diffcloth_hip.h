@@ -181,6 +181,11 @@ int dc_set_uniform_force(dc_ctx *ctx, const double *f);
  * what fillForces adds per vertex beyond gravity and the uniform wind: wind * windNorm * windFactor (.) windFallOff for
  * WIND_SIN_AND_FALLOFF / WIND_FACTOR_PER_STEP and the constant force field (Simulation.cpp:87-105); NULL = none       */
 int dc_set_vertex_forces(dc_ctx *ctx, const double *f /*B*3N or NULL*/);
+/* a SECOND per-vertex external force, added with factor 1 in every step: the constant force field of fillForces
+ * (`if (enableConstantForcefield) f_ext += external_force_field`, Simulation.cpp:91-93) next to a wind with fall-off whose per-step
+ * factor travels with dc_set_vertex_forces + dc_set_force_schedule (fv_scale) — the two per-vertex terms of a step have different
+ * time factors, and a fused rollout needs both on the device. Same layout as dc_set_vertex_forces; NULL = none                    */
+int dc_set_vertex_force_field(dc_ctx *ctx, const double *f /*B*3N or NULL*/);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* Simulation::step()/stepNN() (Simulation.cpp:1020-1428): advance slot -> slot+1 for all rollouts.

@@ -62,6 +62,10 @@ def test_scheduled_rollout_equals_per_step_calls(nx, cluster, monkeypatch):
     X0 = np.stack([f32(V.reshape(-1)), f32(V.reshape(-1) + np.tile([0.05, 0.0, 0.02], N))])
     V0 = np.zeros_like(X0)
 
+    # a constant per-vertex force field next to the scaled per-vertex term: the SECOND per-vertex term of fillForces (Simulation.cpp:91-93),
+    # factor 1 in every step, per step and inside the fused rollout (dc_set_vertex_force_field)
+    FF = f32(0.0005 * rng.standard_normal((B, 3 * N)))
+    e.set_vertex_force_field(FF)
     # ---- (a) per-step calls: every value handed over as an argument of its step
     e.set_state(0, X0, V0)
     for s in range(S):
@@ -113,6 +117,11 @@ def test_scheduled_rollout_equals_per_step_calls(nx, cluster, monkeypatch):
     e.rollout_forward(0, S)                                             # and without schedules the current values apply again
     xc, _ = e.get_states(S, 1)
     assert np.abs(xc[0] - xa[S]).max() > 1e-6
+    e.set_vertex_force_field(None)                                      # ... and the field is a term of its own: without it the rollout differs
+    e.set_state(0, X0, V0)
+    e.rollout_forward(0, S)
+    xd, _ = e.get_states(S, 1)
+    assert np.abs(xd[0] - xc[0]).max() > 1e-7
 
 
 def test_schedules_with_self_collision_and_explicit_fixed_points_override():
