@@ -62,6 +62,43 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *red) {
   a = sa; b = sb;
 }
 
+// The four reductions of a BiCGSTAB iteration: fp64 as before, but inside a wave through DPP row operations (wave_sum_d, dc_adjoint64.h; a
+// wave sum of doubles through __shfl_down is twelve ds_bpermute round trips through the LDS crossbar) and with ONE barrier each — every
+// reduction of the iteration has a slot of its own in `red4` ([4][2][waves]), and between a slot's read and its next write lies the rest of
+// the iteration with all the barriers of two operator applications. On a one-window mesh (hat, sock, T-shirt) an iteration is ~20
+// barrier-separated phases of a microsecond: four reductions of two barriers and twelve crossbar trips each were a sixth of it.
+// NOT fp32 inside the wave (measured, tools/r05_ab/r05_run21.sh): <rhat, r> cancels, and with wave sums rounded to fp32 one T-shirt rollout
+// of 256 needed 214 instead of 78 iterations per step — the launch waits for the slowest rollout (5.5 -> 9.2 ms per batch step).
+template <int THREADS>
+__device__ __forceinline__ double krylov_sum(float v, double *slot) {
+#ifdef DC_ADJ_OLDSUM
+  return block_sum<THREADS>((double) v, slot);
+#endif
+  const double vs = wave_sum_d((double) v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) slot[w] = vs;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < THREADS / 64; k++) s += slot[k];
+  return s;
+}
+template <int THREADS>
+__device__ __forceinline__ void krylov_sum2(float a, float b, double *slot, double &sa, double &sb) {
+#ifdef DC_ADJ_OLDSUM
+  sa = (double) a; sb = (double) b; block_sum2<THREADS>(sa, sb, slot); return;
+#endif
+  const double as = wave_sum_d((double) a), bs = wave_sum_d((double) b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  constexpr int NW = THREADS / 64;
+  if (l == 0) { slot[w] = as; slot[NW + w] = bs; }
+  __syncthreads();
+  sa = 0; sb = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) { sa += slot[k]; sb += slot[NW + k]; }
+}
+
+
 struct AdjCtx {
   const float *xnew, *rec_f, *rec_n, *mu;
   const int *rec_prim;
@@ -401,6 +438,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
                                                             double *red, int kdone, int iters) {
   const int N = S.N, tid = threadIdx.x;
   constexpr int VB = 4;
+  __shared__ double red4[8 * (THREADS / 64)];      // (krylov_sum: a slot per reduction of the iteration)
   float *gin = V.rhs, *u = V.d, *r = V.r, *p = V.p, *v = V.v, *t = V.t, *rhat = V.rhat, *ph = V.ph, *sh = V.sh;
   const float *minv = V.minv;
   auto pre = [&](int i, f3 z) { return block_pre(minv, i, N, z); };
@@ -424,7 +462,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
       // v = K M^-1 p ;  alpha = rho / (rhat . v)
       if constexpr (BLK) adjoint_operator<THREADS, WIN, false>(S, C, ph, false, v, rhat, d1, d2);
       else adjoint_operator<THREADS, WIN, true>(S, C, p, true, v, rhat, d1, d2);
-      double rv = block_sum<THREADS>((double) d1, red);
+      double rv = krylov_sum<THREADS>(d1, red4);
       if (!(fabs(rv) > 1e-300)) { in_status = 2; break; }
       const float alpha = (float) (rho / rv);
       APH_DECL
@@ -442,7 +480,7 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
           if (i < N) { st3(r, i, N, s); if constexpr (BLK) st3(sh, i, N, pre(i, s)); part += dot(s, s); }
         }
       }
-      double ss = block_sum<THREADS>((double) part, red);
+      double ss = krylov_sum<THREADS>(part, red4 + 2 * (THREADS / 64));
       if constexpr (COARSE) { if (ss > in_stop) coarse_add32<THREADS>(S, r, sh, C.lds); }
       APH(1)
       iters++;
@@ -453,8 +491,8 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
       // t = K M^-1 s ;  omega = (t . s) / (t . t)
       if constexpr (BLK) adjoint_operator<THREADS, WIN, false>(S, C, sh, false, t, r, d1, d2);
       else adjoint_operator<THREADS, WIN, true>(S, C, r, true, t, r, d1, d2);
-      double ts = (double) d1, tt = (double) d2;
-      block_sum2<THREADS>(ts, tt, red);
+      double ts, tt;
+      krylov_sum2<THREADS>(d1, d2, red4 + 4 * (THREADS / 64), ts, tt);
       if (!(tt > 1e-300)) { in_status = 2; break; }
       const float omega = (float) (ts / tt);
       APH_SKIP
@@ -481,9 +519,8 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
           }
         }
       }
-      double rho_new = (double) pa;
-      rr = (double) pb;
-      block_sum2<THREADS>(rho_new, rr, red);
+      double rho_new;
+      krylov_sum2<THREADS>(pa, pb, red4 + 6 * (THREADS / 64), rho_new, rr);
       APH(2)
       if (rr <= in_stop) { in_status = 1; break; }
       if (rr < best_rr) { best_rr = rr; since_progress = 0; }

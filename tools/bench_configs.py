@@ -43,8 +43,9 @@ def run(name, B, K, cfg, prims_fn, att, selfc, fwd_tol, orient="FRONT", dim=6.0,
     cg = np.mean([e.get_stats(s)[0]["cg_iters"].mean() for s in range(3, 3 + K)])
     cyc = np.mean([e.get_stats(s)[1]["refine_cycles"].mean() for s in range(3, 3 + K)]); f64 = np.mean([e.get_stats(s)[1]["fp64_iters"].mean() for s in range(3, 3 + K)])
     conv = np.mean([(e.get_stats(s)[1]["converged"] != 0).mean() for s in range(3, 3 + K)])
+    per_rollout = np.sum([e.get_stats(s)[1]["adjoint_iters"] for s in range(3, 3 + K)], axis=0) / K      # (the launch waits for the slowest rollout)
     print(f"{name}: N={e.N} B={B} K={K}: {B * K / dt:.0f} rollout-steps/s, {dt / K * 1e3:.2f} ms per batch step "
-          f"(fwd {kt['fwd_ms'] / K:.2f} ms, bwd {kt['bwd_ms'] / K:.2f} ms), mean PD iters {pd:.0f} (PCG {cg / max(pd, 1):.0f} each), adjoint iters {adj:.0f} in {cyc:.1f} fp32 solves (+ {f64:.0f} fp64 fall-back iterations, converged {conv:.2f}), self contacts {sc:.0f}")
+          f"(fwd {kt['fwd_ms'] / K:.2f} ms, bwd {kt['bwd_ms'] / K:.2f} ms), mean PD iters {pd:.0f} (PCG {cg / max(pd, 1):.0f} each), adjoint iters {adj:.0f} (slowest rollout {per_rollout.max():.0f}) in {cyc:.1f} fp32 solves (+ {f64:.0f} fp64 fall-back iterations, converged {conv:.2f}), self contacts {sc:.0f}")
 
 hat = lambda rmin, rmax: [dict(kind=capi.DC_PRIM_SPHERE, group=0, center=f32(scenes.hat_head_center(rmin, rmax, 2.1)), radius=2.1, mu=0.1)]
 none = lambda rmin, rmax: []
