@@ -1271,12 +1271,15 @@ int dc_set_record(dc_ctx *c, int slot, const dc_record *rec) {
       const int C = rec->self_count[b];
       if (C < 0 || C > cap) return fail(c, DC_ERR_CAPACITY, "dc_set_record: more self contacts than max_self_contacts = " + std::to_string(cap));
       int *m = meta.data() + (size_t) b * kMetaStride;
-      std::vector<int> ids;
+      std::vector<int> ids, in_layer((size_t) N, -1);      // (in_layer: the last layer a vertex appeared in)
       int nl = 0;
       for (int k = 0; k < C; k++) {
         const int p1 = rec->self_pairs[2 * (at + k)], p2 = rec->self_pairs[2 * (at + k) + 1], l = rec->self_layer[at + k];
         if (p1 < 0 || p2 >= N || p1 >= p2) return fail(c, DC_ERR_INVALID, "dc_set_record: self contact pair must satisfy 0 <= id1 < id2 < N");
         if (l < 0 || l >= kMaxLayers || (k > 0 && l < rec->self_layer[at + k - 1])) return fail(c, DC_ERR_INVALID, "dc_set_record: self contacts must come in layer order");
+        // the contacts of a layer are applied in parallel (Simulation::contactSorting, Simulation.cpp:422-624, builds them vertex-disjoint)
+        if (in_layer[p1] == l || in_layer[p2] == l) return fail(c, DC_ERR_INVALID, "dc_set_record: rollout " + std::to_string(b) + ": a vertex appears twice in self-contact layer " + std::to_string(l));
+        in_layer[p1] = in_layer[p2] = l;
         nl = std::max(nl, l + 1);
         ids.push_back(p1); ids.push_back(p2);
       }

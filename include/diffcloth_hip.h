@@ -209,7 +209,9 @@ int dc_get_self_contacts(dc_ctx *ctx, int slot, int rollout, int cap, int *count
  * as passed (fp64) for the adjoint's fp64 operator, so that dc_step_backward(slot) solves the adjoint system of exactly this record
  * (teacher-forced parity tests upload the fp64 oracle's record; the forward kernels are not involved). The state the step started from
  * (x_prev, v_prev) is slot - 1 (dc_set_state). The fp64 copy belongs to this one slot and is dropped when a forward step overwrites the
- * slot, when another record is set, or by dc_alloc_batch; a fused backward sweep over an injected slot runs step by step.             */
+ * slot, when the slot's state or the system is rewritten (dc_set_state*, dc_build), when another record is set, or by dc_alloc_batch; a
+ * fused backward sweep over an injected slot runs step by step. Self contacts come in layer order and the contacts of one layer must be
+ * vertex-disjoint (they are applied in parallel, as contactSorting builds them: Simulation.cpp:422-624) — DC_ERR_INVALID otherwise.       */
 typedef struct dc_record {
   const double *x, *v;          /* B*3N  ForwardInformation::x, ::v — the state after the step                                       */
   const double *f;              /* B*3N  ForwardInformation::f (b~ - C v of the last PD iteration: the contact vectors d derive from it) */

@@ -136,6 +136,23 @@ def test_self_contact_list_overflow_fails_loudly():
     assert np.isfinite(x1).all()
 
 
+def test_injected_record_with_a_vertex_twice_in_a_layer_is_refused():
+    """dc_set_record applies the contacts of a layer in parallel: a record whose layer holds a vertex twice is not one contactSorting
+    (Simulation.cpp:422-624) can produce — DC_ERR_INVALID; the same two contacts in successive layers are accepted."""
+    V, F = meshes.grid_cloth(6, 6)
+    V = f32(V)
+    e = engine(V, F, selfcollision_enabled=1)
+    e.alloc_batch(1, 1)
+    x = V.reshape(-1)[None]
+    e.set_state(0, x, np.zeros_like(x))
+    n = np.tile([0.0, 1.0, 0.0], (2, 1))
+    rec = dict(x=x, v=np.zeros_like(x), f=np.zeros_like(x), prim=-np.ones((1, e.N), dtype=np.int32), normal=np.zeros_like(x))
+    bad = dict(pairs=[[3, 20], [3, 27]], layer=[0, 0], normal=n, d=np.zeros((2, 3)))
+    with pytest.raises(capi.DcError, match="twice in self-contact layer 0"):
+        e.set_record(1, self_contacts=[bad], **rec)
+    e.set_record(1, self_contacts=[dict(bad, layer=[0, 1])], **rec)
+
+
 @pytest.mark.parametrize("adjoint_mode", [1, 0])
 def test_two_contexts_agree_bit_for_bit(adjoint_mode):
     """(This test found a missing barrier after the windowed adjoint operator: a fused multi-step sweep read a few entries
