@@ -107,9 +107,14 @@ struct AdjCtx {
   SelfRec self;
   int nself, b;
   // contact vertices of this step (k_adjoint_step builds them once per step): y differs from z only there
-  int *mark;                    // [N] bit 0 = in the working set of the self contacts, bit 1 = in contact with a primitive
+  int *mark;                    // [N] bit 0 = in the working set of the self contacts, bit 1 = in contact with a primitive, bits 2.. = slot in `ylist`
   const int *plist;             // [nplist] the vertices in contact with a primitive
   int nplist;
+  // y at the contact vertices, in LDS behind the element windows' region (slot = position in plist, or nplist + position in the self contacts'
+  // working set): the windows' staging takes y from here instead of loading the y plane for EVERY span vertex next to z (12 of 44 bytes
+  // per span vertex and application; ~1 600 of 10 000 vertices of the bench cloth are in contact). Null when the list does not fit.
+  float *ylist;
+  int nself_verts;
 };
 
 // w = dr_df^T z for the (block-diagonal) primitive contacts: Simulation::calculatedr_df (Simulation.cpp:700-711)
@@ -303,24 +308,42 @@ __device__ __forceinline__ void adjoint_operator(const DevSystem &S, const AdjCt
     return;
   }
   bool sparse = C.mark != nullptr;
+  // the 1024-thread kernels (always alone on their CU: the LDS behind the windows is theirs) take y of the contact vertices from the LDS list
+  // and have no other sparse form: a step whose contact vertices do not fit the list (a sheet lying on a plane) forms y over all vertices below
+  constexpr bool YL = THREADS == 1024;
+  if constexpr (YL) sparse = sparse && C.ylist != nullptr;
   if (sparse && C.nself > 0) sparse = self_JT_layers_lds_v<THREADS>(S, C.self, C.b, SelfInOut{zin, precond ? S.dinv : nullptr, C.y, N}, C.lds, C.lds_floats);   // ends with a barrier
   if (sparse) {
     const int *mark = C.mark;
+    float *ylist = YL ? C.ylist : nullptr;
+    if (YL && C.nself > 0) {      // the self pass's working set is still in the windows' LDS ([3][M] planar at its start): its slots follow the primitives'
+      const int M = C.nself_verts;
+      float *yl = ylist + 3 * C.nplist;
+      for (int s = threadIdx.x; s < M; s += THREADS) { yl[3 * s] = C.lds[s]; yl[3 * s + 1] = C.lds[M + s]; yl[3 * s + 2] = C.lds[2 * M + s]; }
+    }                                // (a vertex with both kinds of contact: the primitive's slot is the one its mark names, written below)
     for (int q = threadIdx.x; q < C.nplist; q += THREADS) {
       const int i = C.plist[q];
       f3 z;
       if (mark[i] & 1) z = ld3(C.y, i, N);
       else { z = ld3(zin, i, N); if (precond) z = z * S.dinv[i]; }
-      st3(C.y, i, N, z + contact_JT(S, C, i, z));
+      const f3 yv = z + contact_JT(S, C, i, z);
+      st3(C.y, i, N, yv);
+      if constexpr (YL) { ylist[3 * q] = yv.x; ylist[3 * q + 1] = yv.y; ylist[3 * q + 2] = yv.z; }
     }
     __syncthreads();
     APH(0)
-    auto stage_y = [&](int i) {      // (both candidates loaded, then selected: one memory round trip, not two —
-      const int m = mark[i];         //  loading y only behind the mark: 12.7 -> 13.2 ms per batch step)
-      const f3 yi = ld3(C.y, i, N);
+    auto stage_y = [&](int i) {
+      const int m = mark[i];
       f3 z = ld3(zin, i, N);
       if (precond) z = z * S.dinv[i];
+      if constexpr (YL) {            // y of a contact vertex from the LDS list: no load of the y plane at all
+        if (m) { const float *yl = ylist + 3 * (m >> 2); z = mk(yl[0], yl[1], yl[2]); }
+        return z;
+      } else {
+      // (both candidates loaded, then selected: one memory round trip, not two — loading y only behind the mark: 12.7 -> 13.2 ms per batch step)
+      const f3 yi = ld3(C.y, i, N);
       return mk(m ? yi.x : z.x, m ? yi.y : z.y, m ? yi.z : z.z);
+      }
     };
     if constexpr (PRE) {
       // the per-vertex operator takes y_i (attachment vertices only) from its own reads instead of the window's input plane: the per-vertex phase
@@ -547,6 +570,18 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
   return Ret32{in_status, kdone, iters, rr};
 }
 
+// The contact vertices' y list (AdjCtx::ylist) in what the windows leave of the CU's LDS — for the 1024-thread kernels, which have their CU to
+// themselves at 128 registers per lane whatever their LDS (4 waves per SIMD): the larger request costs no mesh a second workgroup per CU.
+// Returns the bytes to add to the launch's dynamic LDS and sets A.ycap.
+template <int THREADS>
+static size_t ylist_room(const DevSystem &S, size_t lds, BwdArgs &A) {
+  A.ycap = 0; A.ybase = (int) (lds / 4);
+  if (THREADS != 1024 || lds + 256 + 4096 + 12 > (size_t) 160 * 1024) return 0;      // (4096: static LDS of the instances, rounded up)
+  const size_t room = (size_t) 160 * 1024 - 256 - 4096 - lds;
+  A.ycap = (int) std::min(room / 12, (size_t) S.N + 2 * (size_t) S.self_cap);
+  return (size_t) A.ycap * 12;
+}
+
 // BLK: direct solve preconditioned with K's own 3 x 3 diagonal blocks (dc_adjprecond.h) instead of diag(P)^-1
 template <int THREADS, bool WIN, bool DENSE, bool BLK, bool COARSE = false>
 __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__restrict__ Sp, DevWork W, BwdArgs A) {
@@ -584,7 +619,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
   C.nself = (S.contact_enabled && S.self_enabled) ? A.self.meta[(size_t) b * kMetaStride] : 0;
   // the contact vertices of this step (the detection's cell / order arrays are free during the backward sweep)
   C.mark = A.dense_y ? nullptr : W.sd_cell + (size_t) b * N;
-  C.plist = nullptr; C.nplist = 0;
+  C.plist = nullptr; C.nplist = 0; C.ylist = nullptr; C.nself_verts = 0;
   if (C.mark) {
     int *plist = W.sd_order + (size_t) b * N;
     __shared__ int nplist;
@@ -592,16 +627,19 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     __syncthreads();
     for (int i = tid; i < N; i += THREADS) {
       const bool pc = C.rec_prim[i] >= 0;
-      C.mark[i] = pc ? 2 : 0;
-      if (pc) plist[atomicAdd(&nplist, 1)] = i;        // (order free: the vertices are independent)
+      int m = 0;
+      if (pc) { const int q = atomicAdd(&nplist, 1); plist[q] = i; m = 2 | (q << 2); }        // (order free: the vertices are independent)
+      C.mark[i] = m;
     }
     __syncthreads();
+    int M = 0;
     if (C.nself > 0) {
-      const int M = A.self.meta[(size_t) b * kMetaStride + kMetaStride - 1];
+      M = A.self.meta[(size_t) b * kMetaStride + kMetaStride - 1];
       const int *verts = A.self.verts + (size_t) b * 2 * S.self_cap;
-      for (int q = tid; q < M; q += THREADS) C.mark[verts[q]] |= 1;
+      for (int q = tid; q < M; q += THREADS) { const int v = verts[q], m = C.mark[v]; C.mark[v] = (m & 2) ? (m | 1) : (1 | ((nplist + q) << 2)); }
     }
-    C.plist = plist; C.nplist = nplist;
+    C.plist = plist; C.nplist = nplist; C.nself_verts = M;
+    C.ylist = (WIN && nplist + M <= A.ycap) ? dyn_lds + A.ybase : nullptr;
     __syncthreads();
   }
   float *gx = A.gx + off;
@@ -855,6 +893,8 @@ static void launch_adj_b(const DevSystem &S, const DevWork &W, const BwdArgs &A,
   if (!S.win_ok) { hipLaunchKernelGGL((k_adjoint_step<THREADS, false, false, false>), dim3(B), dim3(THREADS), 0, st, S.self_dev, W, A); return; }
   size_t lds = (size_t) S.win_lds_bytes;
   if (DENSE) lds = std::max(lds, sizeof(float) * (size_t) (3 * S.dense_ld + dense_lds_floats(S.dense_ld, THREADS / 64)));
+  BwdArgs Ay = A;
+  lds += ylist_room<THREADS>(S, lds, Ay);
   static size_t configured[kMaxDevices] = {};        // the attribute is per device: one entry per device this process has used
   int dev = 0;
   (void) hipGetDevice(&dev);
@@ -863,13 +903,15 @@ static void launch_adj_b(const DevSystem &S, const DevWork &W, const BwdArgs &A,
     (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, DENSE, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     done = lds;
   }
-  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE, BLK>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE, BLK>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, Ay);
 }
 // the instances with the coarse level of the preconditioner (meshes the engine built a deflation space for, direct solve, block preconditioner):
 // kernels of their own — inlined next to the plain solve the coarse code cost the headline's adjoint 4 % without ever running
 template <int THREADS>
 static void launch_adj_coarse(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
-  const size_t lds = std::max((size_t) S.win_lds_bytes, sizeof(float) * (size_t) kCoarseLdsFloats);
+  size_t lds = std::max((size_t) S.win_lds_bytes, sizeof(float) * (size_t) kCoarseLdsFloats);
+  BwdArgs Ay = A;
+  lds += ylist_room<THREADS>(S, lds, Ay);
   static size_t configured[kMaxDevices] = {};
   int dev = 0;
   (void) hipGetDevice(&dev);
@@ -878,7 +920,7 @@ static void launch_adj_coarse(const DevSystem &S, const DevWork &W, const BwdArg
     (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     done = lds;
   }
-  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, false, true, true>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, A);
+  hipLaunchKernelGGL((k_adjoint_step<THREADS, true, false, true, true>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, Ay);
 }
 template <int THREADS, bool DENSE>
 static void launch_adj(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {

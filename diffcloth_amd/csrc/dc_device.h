@@ -208,6 +208,7 @@ struct BwdArgs {
   int dense_y;                  // 1 = form y = (I + dr_df)^T z over all vertices in every operator application (development switch DC_ADJ_DENSEY)
   int verify_all;               // direct solve: 1 = evaluate the fp64 residual after EVERY correction solve (development switch DC_ADJ_VERIFY)
   int warm;                     // direct solve inside a fused sweep: start step s > 0 from gamma u*(step s - 1) (DC_ADJ_WARM, dc_adjoint.hip)
+  int ycap, ybase;              // entries of the contact vertices' y list in the dynamic LDS and its start in floats (set by the launch: dc_adjoint.hip, AdjCtx::ylist)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;
   size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements); d_xfixed steps by slot_xf too

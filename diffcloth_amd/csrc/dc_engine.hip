@@ -258,6 +258,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   { const char *envp = getenv("DC_ADJ_DENSEY"); A.dense_y = envp ? (envp[0] == '1') : 0; }
   { const char *envp = getenv("DC_ADJ_VERIFY"); A.verify_all = envp ? (envp[0] == '1') : 0; }     // (development switch)
   { const char *envp = getenv("DC_ADJ_WARM"); A.warm = envp ? (envp[0] == '1') : 0; }            // (development switch)
+  A.ycap = 0; A.ybase = 0;                                                                                    // (set by the launch, dc_adjoint.hip)
   A.nsteps = 1; A.slot = slot;
   const bool inj = c->inj_slot == slot && c->INJ_X;
   A.inj_x = inj ? c->INJ_X : nullptr; A.inj_f = inj ? c->INJ_F : nullptr; A.inj_n = inj ? c->INJ_N : nullptr;
