@@ -132,3 +132,42 @@ for tol in (1e-3, 1e-6):
     op, y, info = scipy_method(spla.tfqmr, tol, maxiter=20000); report("TFQMR", op, y, f"[info {info}]")
     op, y, info = scipy_method(spla.cgs, tol, maxiter=20000); report("CGS", op, y, f"[info {info}]")
     op, y = cg_plain(tol); report("CG on the symmetrically scaled K (not a valid method for this K: what its non-symmetry does to it)", op, y)
+
+# ---- bench scene only: does CG keep working as the contact set evolves? Ten more steps of the rollout, the two-solve refinement of the engine
+# (each correction solve reduces its right-hand side by 1e-3, the residual in between is the true one) with CG against BiCGSTAB
+if SCENE == "bench":
+    print("--- steps 7 .. 16 of the rollout: applications of two correction solves to 1e-3 each (CG | BiCGSTAB), smallest p.Kp / (|p||Kp|) seen by CG ---", flush=True)
+    sq = np.sqrt(Ji)
+    def cg_solve(K, b, tol):
+        z = np.zeros(n3); r = sq * b; p = r.copy(); rz = r @ r; n = 0; bn = np.linalg.norm(b); worst = 1.0
+        while n < 500:
+            Ap = sq * (K @ (sq * p)); n += 1
+            worst = min(worst, (p @ Ap) / (np.linalg.norm(p) * np.linalg.norm(Ap)))
+            al = rz / (p @ Ap); z += al * p; r -= al * Ap
+            if np.linalg.norm(r / sq) <= tol * bn: break
+            rn = r @ r; p = r + (rn / rz) * p; rz = rn
+        return sq * z, n, worst
+    def bi_solve(K, b, tol):
+        y = np.zeros(n3); r = b.copy(); rh = r.copy(); p = r.copy(); rho = rh @ r; n = 0; bn = np.linalg.norm(b)
+        while n < 1000:
+            vv = K @ (Ji * p); n += 1; alpha = rho / (rh @ vv); s_ = r - alpha * vv
+            if np.linalg.norm(s_) <= tol * bn: y += alpha * p; break
+            t = K @ (Ji * s_); n += 1; omega = (t @ s_) / (t @ t); y += alpha * p + omega * s_; r = s_ - omega * t
+            if np.linalg.norm(r) <= tol * bn: break
+            rho_n = rh @ r; beta = (rho_n / rho) * (alpha / omega); rho = rho_n; p = r + beta * (p - omega * vv)
+        return Ji * y, n
+    for s in range(7, 17):
+        ref = o.step(x, v); x, v = f32(ref["x"]), f32(ref["v"])
+        Ks = o.adjoint_matrix(ref["id"]).tocsr()
+        gs = f32(x * (2.0 / (4 * N)))
+        out = []
+        for name in ("cg", "bi"):
+            u = np.zeros(n3); total = 0; worst = 1.0
+            for cyc in range(2):
+                rres = gs - Ks @ u
+                if name == "cg": du, n, w = cg_solve(Ks, rres, 1e-3); worst = min(worst, w)
+                else: du, n = bi_solve(Ks, rres, 1e-3)
+                u += du; total += n
+            out.append((total, np.linalg.norm(gs - Ks @ u) / np.linalg.norm(gs), worst))
+        print(f"step {s}: PD {ref['iters']}, prim {ref['nprim']}, self {ref['nself']}: CG {out[0][0]} applications (residual {out[0][1]:.1e}, min cos {out[0][2]:.2f}) | "
+              f"BiCGSTAB {out[1][0]} (residual {out[1][1]:.1e})", flush=True)
