@@ -171,3 +171,35 @@ if SCENE == "bench":
             out.append((total, np.linalg.norm(gs - Ks @ u) / np.linalg.norm(gs), worst))
         print(f"step {s}: PD {ref['iters']}, prim {ref['nprim']}, self {ref['nself']}: CG {out[0][0]} applications (residual {out[0][1]:.1e}, min cos {out[0][2]:.2f}) | "
               f"BiCGSTAB {out[1][0]} (residual {out[1][1]:.1e})", flush=True)
+
+# ---- the same two-solve scheme with the correction solves in float32 (vectors and operator in fp32, scalars accumulated in fp64 as the kernels
+# do), the residual between them in fp64: does CG on this K survive single precision?
+if SCENE == "bench":
+    print("--- last step above, correction solves in float32 ---", flush=True)
+    K32 = Ks.astype(np.float32); J32 = Ji.astype(np.float32); sq32 = np.sqrt(Ji).astype(np.float32)
+    dot = lambda a, b: float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+    def cg32(b, tol):
+        z = np.zeros(n3, np.float32); r = sq32 * b.astype(np.float32); p = r.copy(); rz = dot(r, r); n = 0; bn = np.linalg.norm(b)
+        while n < 500:
+            Ap = sq32 * (K32 @ (sq32 * p)); n += 1
+            al = np.float32(rz / dot(p, Ap)); z += al * p; r -= al * Ap
+            if np.sqrt(dot(r / sq32, r / sq32)) <= tol * bn: break
+            rn = dot(r, r); p = r + np.float32(rn / rz) * p; rz = rn
+        return (sq32 * z).astype(np.float64), n
+    def bi32(b, tol):
+        y = np.zeros(n3, np.float32); r = b.astype(np.float32); rh = r.copy(); p = r.copy(); rho = dot(rh, r); n = 0; bn = np.linalg.norm(b)
+        while n < 1000:
+            vv = K32 @ (J32 * p); n += 1; alpha = np.float32(rho / dot(rh, vv)); s_ = r - alpha * vv
+            if np.sqrt(dot(s_, s_)) <= tol * bn: y += alpha * p; break
+            t = K32 @ (J32 * s_); n += 1; omega = np.float32(dot(t, s_) / dot(t, t)); y += alpha * p + omega * s_; r = s_ - omega * t
+            if np.sqrt(dot(r, r)) <= tol * bn: break
+            rho_n = dot(rh, r); beta = np.float32((rho_n / rho) * (float(alpha) / float(omega))); rho = rho_n; p = r + beta * (p - omega * vv)
+        return (J32 * y).astype(np.float64), n
+    for name, solve in (("CG", cg32), ("BiCGSTAB", bi32)):
+        u = np.zeros(n3); total = 0; hist = []
+        for cyc in range(3):
+            rres = gs - Ks @ u
+            hist.append(np.linalg.norm(rres) / np.linalg.norm(gs))
+            if hist[-1] <= 1e-6: break
+            du, n = solve(rres, 1e-3); u += du; total += n
+        print(f"{name} in float32: {total} applications, fp64 residual after each solve {['%.1e' % h for h in hist[1:]] + ['%.1e' % (np.linalg.norm(gs - Ks @ u) / np.linalg.norm(gs))]}", flush=True)
