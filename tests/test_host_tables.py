@@ -144,3 +144,39 @@ def test_deflation_space_is_built_for_the_irregular_garment_only():
         g.set_mesh(V2, F2); g.set_attachments([]); g.set_params(time_step=1.0 / 180, density=0.3, k_stretch=150.0, k_bend=1e-5, forward_deflation=want)
         g.set_primitives([]); g.build()
         assert g.deflation()[0] == expect and g.deflation()[1] <= 40
+
+
+def test_deflation_switch_is_read_at_every_build_and_the_space_is_cached(monkeypatch):
+    """One rule for device and host-only contexts (csrc/dc_engine.hip: deflation_want): DC_DEFLATION is read at EVERY dc_build, so a test can
+    toggle it between builds of one context; and a rebuild that leaves the system matrix P unchanged (same mesh, clips, stiffnesses, time step)
+    takes the eigenvectors from the context's cache instead of repeating the probe solve and the Chebyshev subspace iteration — a
+    rebuildSystem per optimisation iterate of the reference's loops (Simulation.cpp:1820-1860) costs what the tables cost."""
+    import time
+    import scenes
+    V, F = scenes.load_mesh("dress7k")
+    P, _, _ = scenes.normalise_model(V, "FRONT", 8.0)
+    top = np.argsort(-P[:, 1])[:6].tolist()
+    par = dict(time_step=1.0 / 120, density=0.2, k_stretch=800.0, k_bend=0.05)
+    e = capi.Engine(-1)
+    e.set_mesh(P, F); e.set_attachments(top); e.set_params(**par); e.set_primitives([])
+    monkeypatch.setenv("DC_DEFLATION", "0")
+    e.build()
+    assert e.deflation() == (0, 0)
+    monkeypatch.delenv("DC_DEFLATION")
+
+    def timed_build():
+        t = time.perf_counter(); e.build()
+        return time.perf_counter() - t
+    t_first = timed_build()
+    first = e.deflation()
+    assert first[0] == 16 and first[1] > 200
+    t_again = timed_build()
+    assert e.deflation() == first
+    e.set_params(forward_tol=1e-6, **par)                  # a parameter that does not enter P
+    t_same_p = timed_build()
+    assert e.deflation() == first
+    e.set_params(**dict(par, k_stretch=900.0))             # P changes: the space is rebuilt
+    t_new_p = timed_build()
+    assert e.deflation()[0] == 16 and e.deflation() != first
+    print(f"\nbuild with the eigen-solve {t_first:.2f} s / {t_new_p:.2f} s, from the cache {t_again:.2f} s / {t_same_p:.2f} s")
+    assert max(t_again, t_same_p) < 0.5 * min(t_first, t_new_p)
