@@ -30,24 +30,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from diffcloth_amd import workloads  # noqa: E402  (the workload definitions live in the package; tests/ is only imported by cpu_baseline)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-GRAVITY = 9.8
 
 
 def scene(args):
     """Rest mesh, folded start shape, flap mask, sphere centre (fp32-representable, as the device sees them)."""
-    import meshes
-    V, F = meshes.grid_cloth(args.grid, args.grid, 4.5, 4.5, "DOWN")       # reference grid builder, Simulation.cpp:2611-2757
-    V = V.astype(np.float32).astype(np.float64)
-    center = meshes.sphere_scene_center(V, 2.0).astype(np.float32).astype(np.float64)
-    if args.fold_rows > 0:
-        V0, flap = meshes.fold_flap(V, args.grid, args.grid, args.fold_rows, args.fold_gap)
-        V0 = V0.astype(np.float32).astype(np.float64)
-    else:
-        V0, flap = V.copy(), np.zeros(V.shape[0], dtype=bool)
-    return V, F, V0, flap, center
+    return workloads.c4_scene(args.grid, args.fold_rows, args.fold_gap)      # reference grid builder, Simulation.cpp:2611-2757
 
 
 def make_engine(device, args, V, F, center):
@@ -65,25 +56,16 @@ def make_engine(device, args, V, F, center):
 
 def flap_force(args, mass, flap):
     """Constant per-vertex force (3N): the flap pressed onto the cloth with `flap_force` times its own weight."""
-    f = np.zeros((mass.size, 3))
-    f[flap, 1] = -args.flap_force * GRAVITY * mass[flap]
-    return f.astype(np.float32).astype(np.float64).reshape(-1)
+    return workloads.c4_flap_force(mass, flap, args.flap_force)
 
 
-def rollout_inputs(V0, ids):
-    """Per-rollout start state and friction coefficient, seeded by the global rollout id."""
-    X = np.empty((len(ids), V0.size)); MU = np.empty((len(ids), 1))
-    for k, gid in enumerate(ids):
-        rng = np.random.default_rng(1000 + int(gid))
-        shift = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.09, -0.02), rng.uniform(-0.5, 0.5)])
-        X[k] = (V0 + shift).astype(np.float32).reshape(-1)
-        MU[k, 0] = rng.uniform(0.1, 0.9)
-    return X, MU
+rollout_inputs = workloads.c4_rollout_inputs      # per-rollout start state and friction coefficient, seeded by the global rollout id
 
 
 def cpu_baseline(args, V, F, center, field, x0, v0, mu, steps, gscale):
     """Reference algorithm (fp64 oracle port, OpenMP at the reference's sites) on the host cores: the SAME window of steps of
     rollout 0 as the GPU timed, forward and backward, direct adjoint solve (solveDirect semantics) like adjoint_mode 1."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))      # the oracle's ctypes wrapper (test infrastructure) — the checker, timed here as the CPU baseline
     import orc
     threads = args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 32)
     o = orc.Oracle(V, F, h=args.h, density=0.3, k_stretch=150.0, k_bend=1e-5, fwd_tol=args.fwd_tol,
@@ -119,9 +101,8 @@ def tshirt_evaluation0():
     sys.path.insert(0, os.path.join(ROOT, "diffcloth_amd", "lib"))
     try:
         import diffcloth_py as d
-        import scenes
-        g = np.load(os.path.join(scenes.GOLDEN, "tshirt_golden.npz"))
-        V, F = scenes.load_mesh("tshirt")
+        g = np.load(os.path.join(workloads.GOLDEN, "tshirt_golden.npz"))
+        V, F = workloads.load_mesh("tshirt")
         sim = d.makeSimFromMesh("wind_tshirt", V.reshape(-1), F.reshape(-1).tolist())
         h = d.makeOptimizeHelperWithSim("wind_tshirt", sim)
         x = np.array([*g["log_wind"][0], g["log_k"][0]])
@@ -137,6 +118,54 @@ def tshirt_evaluation0():
                                   "source": "/root/reference/output/tshirt-exampleopt/forwardLog.txt:3-5, backwardLog.txt:3-9 (authors' machine)"}}
     except Exception as ex:      # secondary information must never take the headline down
         return {"error": f"{type(ex).__name__}: {ex}"}
+
+
+def secondary_config(device, key, K=10):
+    """One of BASELINE.json's other configurations in a LOADED contact state (diffcloth_amd/workloads.py: hat pressed onto the head, sock
+    pulled along the foot, squashed dress with its sheets in self contact, slope fabric sliding on its plane): lead-in steps run by the
+    engine itself, then K timed fwd+bwd steps as two fused launches — contact counts and per-kernel times of the timed steps."""
+    from diffcloth_amd import capi
+    try:
+        w = workloads.SECONDARY_WORKLOADS[key]()
+        e = capi.Engine(device)
+        e.set_mesh(w["P"], w["F"]); e.set_attachments(w["att"])
+        e.set_params(forward_tol=w["fwd_tol"], backward_tol=5e-4, cg_rel_tol=1e-4, cg_max_iter=2000, gradient_clipping=1, adjoint_mode=1,
+                     adjoint_rel_tol=1e-6, **w["params"])
+        e.set_primitives(w["prims"]); e.build()
+        B = w["B"]
+        X0, V0, lead_xf, timed_xf, mus = w["start"](B, np.random.default_rng(0))
+        L = len(lead_xf) if lead_xf is not None else 2
+        e.alloc_batch(B, L + K)
+        if mus is not None:
+            e.set_mu(mus)
+        e.set_state(0, X0, V0)
+        if lead_xf is not None:
+            e.set_fixed_point_schedule(0, np.concatenate([lead_xf, timed_xf(K)]))
+        e.rollout_forward(0, L)
+        e.seed_gradient(L, None, 1e-4); e.rollout_backward(L, 1); e.sync(); e.kernel_times(reset=True)
+        t0 = time.perf_counter()
+        e.rollout_forward(L, K); e.seed_gradient(L + K, None, 2.0 / ((K + 1) * e.N)); e.rollout_backward(L + K, K); e.sync()
+        dt = time.perf_counter() - t0
+        kt = e.kernel_times()
+        fs = [e.get_stats(s) for s in range(L + 1, L + K + 1)]
+        mean = lambda side, f: float(np.mean([st[side][f].mean() for st in fs]))      # noqa: E731
+        per_rollout_adj = np.sum([st[1]["adjoint_iters"] for st in fs], axis=0) / K
+        pd = mean(0, "pd_iters")
+        out = {"workload": w["name"], "N": e.N, "rollouts": B, "steps": K, "lead_in_steps": L, "workgroups_per_rollout": e.cluster(),
+               "rollout_steps_per_s": B * K / dt, "ms_per_batch_step": dt / K * 1e3, "fwd_ms_per_step": kt["fwd_ms"] / K, "bwd_ms_per_step": kt["bwd_ms"] / K,
+               "mean_prim_contacts_per_step": mean(0, "prim_contacts"), "mean_self_contacts_per_step": mean(0, "self_contacts"),
+               "mean_pd_iters_per_step": pd, "mean_cg_iters_per_pd_iter": mean(0, "cg_iters") / max(pd, 1e-30),
+               "mean_adjoint_iters_per_step": mean(1, "adjoint_iters"), "slowest_rollout_adjoint_iters_per_step": float(per_rollout_adj.max()),
+               "fp64_fallback_iters_per_step": mean(1, "fp64_iters"),
+               "forward_converged_fraction": float(np.mean([(st[0]["converged"] > 0).mean() for st in fs])),
+               "adjoint_converged_fraction": float(np.mean([(st[1]["converged"] != 0).mean() for st in fs])),
+               "fwd_tol": w["fwd_tol"], "adjoint_rel_tol": 1e-6}
+        dx, dv, _ = e.get_gradient()
+        out["gradients_finite"] = bool(np.isfinite(dx).all() and np.isfinite(dv).all())
+        e.close()
+        return out
+    except Exception as ex:      # secondary information must never take the headline down
+        return {"workload": key, "error": f"{type(ex).__name__}: {ex}"}
 
 
 def config_key(args, B, K, W, N):
@@ -197,6 +226,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=-1,
                     help="steps of the CPU baseline sample (rollout 0 from its state after the warm-up steps); -1 = the timed steps, 0 disables")
     ap.add_argument("--tshirt", type=int, default=1, help="also time evaluation 0 of the reference's T-shirt L-BFGS run (secondary line; 0 = skip)")
+    ap.add_argument("--secondary", type=str, default="hat,sock,dress,perf_fabric",
+                    help="other BASELINE.json configurations in loaded contact states, 10 fwd+bwd steps each (N = 1 only; '' = skip)")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0: min(host cores, 32), the fastest setting measured on the MI355X host)")
     args = ap.parse_args()
@@ -289,13 +320,13 @@ def main():
 
     kt = e.kernel_times()
     # iteration statistics of the timed steps (needed for the byte / cycle models)
-    pd = cg_f = adj = cg_b = selfc = cyc = it64 = 0.0
+    pd = cg_f = adj = cg_b = selfc = primc = cyc = it64 = 0.0
     conv = 0
     cg_per_rollout = np.zeros(B); adj_per_rollout = np.zeros(B)       # load balance: a launch lasts as long as its slowest rollout
     for s in range(W + 1, W + K + 1):
         fs, bs = e.get_stats(s)
         pd += fs["pd_iters"].sum(); cg_f += fs["cg_iters"].sum(); conv += int((fs["converged"] > 0).sum())
-        selfc += fs["self_contacts"].sum()
+        selfc += fs["self_contacts"].sum(); primc += fs["prim_contacts"].sum()
         adj += bs["adjoint_iters"].sum(); cg_b += bs["cg_iters"].sum(); cyc += bs["refine_cycles"].sum(); it64 += bs["fp64_iters"].sum()
         cg_per_rollout += fs["cg_iters"]; adj_per_rollout += bs["adjoint_iters"]
     N, T, E = e.N, e.T, e.E
@@ -376,7 +407,12 @@ def main():
                          {"issue_floor_cycles_per_cu": issue_floor_cycles,
                           "issue_frac": issue_floor_cycles / max(kt["fwd_ms"] * 1e-3 * clock_hz, 1e-30),
                           "issue_model": "VALU / LDS issue floor of the PCG products alone: 6 instructions per non-zero x 4 cycles per wave-instruction and SIMD, over the launch time",
-                          "streaming_model_bytes": bytes_fwd_stream, "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
+                          "streaming_model_bytes": bytes_fwd_stream,
+                          # SURVEY.md section 8d's figure taken as a rate, side by side with `frac`: NOT a roof for this design — the CG vectors
+                          # it counts never pass through HBM (they live in LDS / registers), so the value exceeds 1
+                          "frac_streaming_model": bytes_fwd_stream / max(kt["fwd_ms"] * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                          "frac_streaming_model_note": "SURVEY 8d bytes (108 I_pd + 132 I_cg) N over the launch time and 8 TB/s; not a roof: the resident PCG moves none of the 132 I_cg N through HBM",
+                          "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
                           "model": "compulsory HBM bytes of the resident design: (108 I_pd + 64 per step) N; CG vectors never leave the CU"})
     k_bwd = kernel_entry("k_adjoint_step_cl" if cl > 1 else "k_adjoint_step", bytes_bwd, lds_cycles_bwd, kt["bwd_ms"], kt["bwd_launches"],
                          {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + 48.0 * cyc + 60.0 * B * K) * N,
@@ -394,6 +430,9 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "state, tape and solver vectors fp32; the forward PCG's search direction is stored as power-of-two-scaled fp16 at 20 rows per thread "
+                          "(the N = 10 000 instance: iterates, residuals and all sums stay fp32, step length = exact line search along the stored direction); "
+                          "fp64 for element strains, the adjoint's residual / fall-back and all gradient sums",
             "config": {"workload": f"C4 grid {args.grid}x{args.grid} cloth (N={N}, T={e.T}, E={e.E}) on sphere r=2, "
                                    f"h=1/{round(1 / args.h)}, primitive Signorini-Coulomb contact"
                                    + (" + self-collision" if args.selfcollision else "")
@@ -401,7 +440,7 @@ def main():
                        "config_key": key, "rollouts_per_gpu": B, "rollouts_total": total, "workgroups_per_rollout": cl,
                        "fwd_tol": args.fwd_tol, "bwd_tol": args.bwd_tol, "cg_rel_tol": args.cg_tol, "adjoint_mode": args.adjoint_mode,
                        "adjoint_rel_tol": args.adjoint_rel_tol, "adjoint_block_precond": args.block_precond, "selfcollision": bool(args.selfcollision),
-                       "mean_self_contacts_per_step": selfc / (B * K),
+                       "mean_self_contacts_per_step": selfc / (B * K), "mean_prim_contacts_per_step": primc / (B * K),
                        "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
                        "mean_adjoint_iters_per_step": adj / (B * K), "mean_fp32_solves_per_adjoint": cyc / (B * K),
                        "fp64_fallback_iters": it64, "adjoint_precision": "mixed: fp32 BiCGSTAB corrections of the fp64 residual",
@@ -427,6 +466,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, V, F, center, field, xw[0], vw[0], MU[0, 0], ncpu, gscale)
         if world == 1 and args.tshirt:
             out["secondary"] = tshirt_evaluation0()
+        if world == 1 and args.secondary:
+            e.close()          # the headline's 40 GB of tape go back before the other configurations allocate theirs
+            out["secondary_configs"] = [secondary_config(local_rank, k.strip()) for k in args.secondary.split(",") if k.strip()]
         line = json.dumps(out)
     else:
         line = None

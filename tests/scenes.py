@@ -1,83 +1,9 @@
-"""Scene construction for the tests (test infrastructure): restates the reference's model-mesh normalisation
-(Simulation::createClothMeshFromModel, Simulation.cpp:2170-2226), attachment search (createAttachments,
-:2258-2310) and demo tables (OptimizationTaskConfigurations.cpp) so the oracle can be fed the same scenes as the
-product's C++ host class (diffcloth_amd/csrc/host), which implements them independently.
-"""
+"""Scene construction for the tests: model-mesh normalisation, attachment search, demo tables and primitive placement are defined in
+diffcloth_amd/workloads.py (they restate Simulation.cpp:2170-2226, :2258-2310, :1894-1944 and OptimizationTaskConfigurations.cpp so the
+oracle can be fed the same scenes as the product's C++ host class, which implements them independently); re-exported here."""
 import os
+import sys
 
-import numpy as np
-
-import meshes
-
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-def load_mesh(name):
-    z = np.load(os.path.join(GOLDEN, "meshes.npz"))
-    return z[name + "_v"].copy(), z[name + "_f"].copy()
-
-
-def normalise_model(V, orientation, cloth_dim, up_vector=(0, 1, 0)):
-    """Returns (rest positions, restShapeMinDim, restShapeMaxDim)."""
-    P = meshes.orient(V.copy(), orientation, up_vector)
-    mn, mx = P.min(axis=0), P.max(axis=0)
-    dim = mx - mn
-    scale = dim.max() / cloth_dim
-    rest_max = dim / scale
-    rest_min = np.zeros(3)
-    tr = rest_max / 2.0
-    rest_min = rest_min - tr
-    rest_max = rest_max - tr
-    P = (P - mn) / scale - rest_max
-    return P, rest_min, rest_max
-
-
-def corner_attachments(P, rest_min, rest_max):
-    """LEFT_RIGHT_CORNERS_2 on a model mesh: the vertices closest to the upper-left / upper-right goal points."""
-    zmid = (rest_min[2] + rest_max[2]) / 2.0
-    goals = [np.array([rest_min[0], rest_max[1], zmid]), np.array([rest_max[0], rest_max[1], zmid])]
-    out = []
-    for g in goals:
-        best = 0
-        for i in range(len(P)):
-            if np.linalg.norm(P[i] - g) < np.linalg.norm(P[best] - g):
-                best = i
-        out.append(best)
-    return out
-
-
-TSHIRT = dict(mesh="tshirt", orientation="BACK", cloth_dim=6.0, k_stretch=550.0, k_bend=0.01, density=0.124,
-              h=1.0 / 90, steps=250, fwd_tol=1e-8, bwd_tol=5e-4)
-HAT = dict(mesh="hat", orientation="FRONT", cloth_dim=6.0, k_stretch=1200.0, k_bend=120.0, density=0.224,
-           h=1.0 / 100, steps=400, fwd_tol=1e-8, bwd_tol=5e-4, attachments=[394, 32], sphere_radius=2.1, sphere_mu=0.1)
-SOCK = dict(mesh="sock", orientation="CUSTOM", cloth_dim=5.0, k_stretch=600.0, k_bend=1.0, density=0.224,
-            h=1.0 / 160, steps=400, fwd_tol=1e-9, bwd_tol=5e-4, attachments=[14, 30, 3, 81])
-
-
-def hat_head_center(rest_min, rest_max, radius=2.1):
-    """sphere_head placement of PLANE_BUST_WEARHAT (Simulation.cpp:1932-1944)."""
-    low = 0.5 * (rest_min + rest_max)
-    low[1] = rest_min[1]
-    plane = low - np.array([0, 0.5, 0]) - np.array([0, 0, 4.0])
-    return plane + np.array([0, radius + 0.5, -4.0])
-
-
-def sock_leg(rest_min, rest_max):
-    """LowerLeg of the FOOT scene (Simulation.cpp:1916-1925, Primitive.h:350-374): centre and (kind, centerInit,
-    topOffset, radius, length) of joint sphere, foot capsule, leg capsule."""
-    high = 0.5 * (rest_min + rest_max)
-    high[1] = rest_max[1]
-    center = high + np.array([0, 3.0, -4.0])
-    radius, foot_len, leg_len = 0.8, 4.0, 5.0
-    axis = np.array([0.0, 1.0, 0.0])
-    foot_rot = meshes.axis_to_rotation(axis, (0, 1, 0))
-    foot_global = meshes.axis_to_rotation(foot_rot @ np.array([0, 1.0, 0]), (0, 1, 0))
-    leg_center = foot_rot @ np.array([0, foot_len, 0])
-    leg_rot = meshes.axis_to_rotation((0, 0.7, 0.3), (0, 1, 0))
-    leg_global = meshes.axis_to_rotation(leg_rot @ axis, (0, 1, 0))
-    children = [
-        (0, leg_center, np.zeros(3), radius + 0.05, 0.0),
-        (1, np.zeros(3), foot_global @ np.array([0, foot_len, 0]), radius, foot_len),
-        (1, leg_center, leg_global @ np.array([0, leg_len, 0]), radius, leg_len),
-    ]
-    return center, children
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffcloth_amd.workloads import (DRESS, GOLDEN, HAT, PERF_FABRIC, SOCK, TSHIRT, corner_attachments, hat_head_center, load_mesh,  # noqa: E402,F401
+                                     normalise_model, slope_plane, sock_leg)

@@ -10,6 +10,7 @@ import os
 import numpy as np
 import pytest
 
+import ledger
 import meshes
 import orc
 import records
@@ -25,6 +26,11 @@ def f32(a):
 
 def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+# Hard ceiling of the end-to-end gate where it is widened by the oracle's measured sensitivity: whatever the rule says, an
+# end-to-end difference above this fails. Measured over rounds 4-6 (profiles/r06_parity_ledger.json): worst 3.1e-3 (pressed-on hat).
+E2E_CAP = 8e-3
 
 
 def engine_for(P, F, cfg, prims, att, selfcollision, fwd_tol, adjoint_rel_tol=1e-7):
@@ -49,7 +55,7 @@ def settle(o, x, v, xf, steps, tol=1e-6):
     return f32(x), f32(v)
 
 
-def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, conditioning=False, h=None, same_record_tol=1e-4):
+def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, conditioning=False, h=None, same_record_tol=1e-4, scene="?"):
     """One forward + backward step of the batch; the sampled rollouts against their own fp64 oracle run. Three statements per rollout:
 
     (1) END TO END: contact sets identical, positions within pos_tol, every gradient output (dL_dx, dL_dv, dL_dxfixed, dL_dmu) within
@@ -105,6 +111,7 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
         return rel(g["dL_dx"][b], r["dL_dx"]), rel(g["dL_dv"][b], r["dL_dv"]), ef, em
 
     recs, refs_b = [], []
+    led = {}
     for b in sample:
         set_mus(b)
         ref = o.step(X0[b], V0[b], None if XF is None else XF[b])
@@ -133,11 +140,12 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
             assert abs(int(st["pd_iters"][b]) - int(ref["iters"])) <= 2
             egx, egv, egf, egm = e_same
         gate_b = grad_tol
+        sens = None
         if conditioning:
             o.override_record(ref["id"], x=f32(ref["x"]))
             rb2 = o.step_backward(ref["id"], gx[b], gv[b], is_start=False, direct=True)
             sens = max(rel(rb2["dL_dx"], rb["dL_dx"]), rel(rb2["dL_dv"], rb["dL_dv"]))
-            gate_b = max(grad_tol, min(3.0 * sens, 2e-2))
+            gate_b = max(grad_tol, min(3.0 * sens, E2E_CAP))
             print(f"\n[config] rollout {b}: the oracle's own gradient moves by {sens:.2e} when its x_new is rounded to float32 (end-to-end gate {gate_b:.1e})")
             if sens > grad_tol:
                 ill.append(b)
@@ -152,6 +160,7 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
               f"BiCGSTAB {gb['adjoint_iters'][b]} in {gb['refine_cycles'][b]} fp32 solves (+ {gb['fp64_iters'][b]} fp64 iterations), residual {gb['last_udiff'][b]:.1e} "
               f"({'fp64-evaluated' if gb['residual_verified'][b] else 'bound'}); gradient rel err END TO END dx {egx:.2e} dv {egv:.2e} dxfixed {egf:.2e} dmu {egm:.2e} | "
               f"SAME RECORD (oracle adopts the engine's) dx {ea[0]:.2e} dv {ea[1]:.2e} dxfixed {ea[2]:.2e} dmu {ea[3]:.2e}")
+        led[b] = ledger.add("test_gpu_configs.check_rollouts", scene, b, max(egx, egv, egf, egm), sensitivity=sens, gate=gate_b, same_record_adopt=max(ea))
         assert max(ea) <= same_record_tol, (b, ea)
         if conditioning:
             assert max(egx, egv, egf, egm) <= gate_b, (b, egx, egv, egf, egm, gate_b)
@@ -172,6 +181,7 @@ def check_rollouts(o, e, X0, V0, XF, sample, pos_tol, grad_tol=1e-4, mus=None, c
         same["forced"] = max(same["forced"], *et)
         print(f"\n[config] rollout {b}: TEACHER FORCED (the engine differentiates the oracle's record) dx {et[0]:.2e} dv {et[1]:.2e} dxfixed {et[2]:.2e} dmu {et[3]:.2e}; "
               f"BiCGSTAB {gt['adjoint_iters'][k]} (+ {gt['fp64_iters'][k]} fp64), residual {gt['last_udiff'][k]:.1e}")
+        led[b]["same_record_forced"] = float(max(et))
         assert max(et) <= same_record_tol, (b, et)
     print(f"\n[config] B={B} sampled {list(sample)} pd iters {st['pd_iters'].min()}..{st['pd_iters'].max()} contacts prim "
           f"{st['prim_contacts'].min()}..{st['prim_contacts'].max()} self {st['self_contacts'].max()} | worst max|dx| {worst['dx']:.2e} "
@@ -230,7 +240,8 @@ def test_c3_hat_batch_64(lowering_steps, fwd_tol):
     V0 = np.stack([f32(v + 0.01 * rng.standard_normal(x.size)) for _ in range(B)])
     XF = np.stack([f32(xf + np.tile([0.0, -0.05, -0.3], 2) + 0.02 * rng.standard_normal(6)) for _ in range(B)])
     mus = f32(rng.uniform(0.05, 0.6, (B, 1)))
-    st = check_rollouts(o, e, X0, V0, XF, sample=(0, 9, 17, 30, 45, 63) if pressed else (0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus, conditioning=True)
+    st = check_rollouts(o, e, X0, V0, XF, sample=(0, 9, 17, 30, 45, 63) if pressed else (0, 17, 63), pos_tol=6e-5, grad_tol=1e-4, mus=mus, conditioning=True,
+                        scene="hat-pressed" if pressed else "hat-first-touch")
     if pressed:
         print(f"[hat] rollouts gated by the oracle's own float32-state sensitivity: {st['ill_conditioned']}")
         print(f"[hat] contacts per rollout in the compared step: min {st['prim_contacts'].min()} median {np.median(st['prim_contacts']):.0f} max {st['prim_contacts'].max()}")
@@ -276,7 +287,7 @@ def test_c5_sock_batch_512():
     V0 = np.stack([f32(v + 0.01 * rng.standard_normal(x.size)) for _ in range(B)])
     XF = np.stack([f32(xf + np.tile(dirn * 0.04, len(att)) + 0.01 * rng.standard_normal(3 * len(att))) for _ in range(B)])
     mus = f32(rng.uniform(0.2, 0.9, (B, 1)))
-    st = check_rollouts(o, e, X0, V0, XF, sample=(0, 255, 511), pos_tol=5e-5, mus=mus)
+    st = check_rollouts(o, e, X0, V0, XF, sample=(0, 255, 511), pos_tol=5e-5, mus=mus, scene="sock-512")
     assert st["prim_contacts"].min() > 0
 
 
@@ -304,7 +315,7 @@ def test_c4_dress_self_contact_batch(B, sample, mesh="dress"):
     X0 = np.stack([f32((X + 0.0005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
     V0 = np.stack([f32((vel + 0.005 * rng.standard_normal(X.shape)).reshape(-1)) for _ in range(B)])
     XF = np.stack([f32(X[top].reshape(-1)) for _ in range(B)])
-    st = check_rollouts(o, e, X0, V0, XF, sample=sample, pos_tol=8e-5, grad_tol=1e-4, conditioning=(B == 256))
+    st = check_rollouts(o, e, X0, V0, XF, sample=sample, pos_tol=8e-5, grad_tol=1e-4, conditioning=(B == 256), scene=f"{mesh}-{B}")
     assert st["self_contacts"].min() > 20
 
 
@@ -395,6 +406,8 @@ def test_dress_7742_vertices_forward_step_and_adjoint_fallback():
     rbs = o.step_backward_lu(ref["id"], gx[0], gv[0], is_start=False)
     sens = max(rel(rbs["dL_dx"], rb["dL_dx"]), rel(rbs["dL_dv"], rb["dL_dv"]), rel(rbs["dL_dxfixed"], rb["dL_dxfixed"]))
     print(f"[dress 7742] END TO END {ee:.2e}; the oracle's own gradient under a float32 rounding of its x_new moves by {sens:.2e}")
+    ledger.add("test_dress_7742_vertices_forward_step_and_adjoint_fallback", "dress7k-1", 0, ee, sensitivity=sens, gate=max(1e-4, min(3 * sens, 2e-3)),
+               same_record_adopt=ea, same_record_forced=et)
     assert ee <= max(1e-4, min(3 * sens, 2e-3))
 
 

@@ -15,6 +15,7 @@ import pytest
 
 import meshes
 import orc
+import ledger
 import records
 import scenes
 from diffcloth_amd import capi
@@ -93,7 +94,9 @@ def compare_step(o, e, x0, v0, xf, tag, pos_tol, min_prim=0, min_self=0):
           f"{gb['last_udiff'][0]:.1e}; gradient rel err END TO END {ee:.2e} (the oracle's own under a float32 rounding of its x_new: {sens:.2e}) | SAME RECORD: "
           f"oracle adopts the engine's {ea:.2e}, engine differentiates the oracle's {et:.2e}")
     assert ea <= 1e-4 and et <= 1e-4
-    assert ee <= max(1e-4, min(3 * sens, 2e-2))      # (the conditioning rule and cap of tests/test_gpu_configs.py::check_rollouts)
+    gate = max(1e-4, min(3 * sens, 8e-3))      # (the conditioning rule and hard ceiling of tests/test_gpu_configs.py::check_rollouts)
+    ledger.add("test_gpu_garments10k.check_step", tag, 0, ee, sensitivity=sens, gate=gate, same_record_adopt=ea, same_record_forced=et)
+    assert ee <= gate
     return st
 
 

@@ -1,0 +1,42 @@
+"""Collected LAST (file name): the rules of the parity ledger over everything the run compared (tests/ledger.py).
+
+  * every same-record error (the oracle differentiates the engine's record / the engine differentiates the oracle's) <= 1e-4, flat;
+  * on the scenes whose end-to-end gate is widened by the conditioning rule — pressed-on hat, first-touch hat, dress x 256, dress 7 742 —
+    the end-to-end error <= max(1e-4, 1.0 x the oracle's own sensitivity): 1 x, not the 3 x of the per-test gates, so that the slack in
+    the rule is itself a measured statement;
+  * everywhere else <= the entry's gate, and no gate above its test's hard ceiling.
+
+Skips when the run compared nothing (a filtered run)."""
+import pytest
+
+import ledger
+
+pytestmark = pytest.mark.gpu
+
+STRICT_SCENES = ("hat-pressed", "hat-first-touch", "dress-256", "dress7k-1")
+SLACK = 1.0
+
+
+def test_parity_ledger_rules():
+    ents = ledger.ENTRIES
+    if not ents:
+        pytest.skip("no parity comparison ran in this process")
+    worst_same = 0.0
+    rows = []
+    for e in ents:
+        for k in ("same_record_adopt", "same_record_forced"):
+            if e[k] is not None:
+                worst_same = max(worst_same, e[k])
+                assert e[k] <= 1e-4, e
+        if e["e2e_err"] is None:
+            continue
+        if e["gate"] is not None:
+            assert e["e2e_err"] <= e["gate"] and e["gate"] <= 8e-3, e
+        if e["scene"] in STRICT_SCENES and e["sensitivity"] is not None:
+            bound = max(1e-4, SLACK * e["sensitivity"])
+            rows.append((e["scene"], e["rollout"], e["e2e_err"], e["sensitivity"], e["e2e_err"] / max(e["sensitivity"], 1e-30)))
+            assert e["e2e_err"] <= bound, e
+    widened = [e for e in ents if e["gate"] is not None and e["gate"] > 1e-4]
+    print(f"\n[ledger] {len(ents)} comparisons, worst same-record error {worst_same:.2e}; {len(widened)} end-to-end gates widened by the oracle's sensitivity; "
+          "strict scenes (scene, rollout, end to end, sensitivity, ratio): " + "; ".join(f"{s} {r}: {a:.2e} / {b:.2e} = {c:.2f}" for s, r, a, b, c in rows))
+    ledger.flush()
