@@ -155,7 +155,8 @@ def secondary_config(device, key, K=10):
                "rollout_steps_per_s": B * K / dt, "ms_per_batch_step": dt / K * 1e3, "fwd_ms_per_step": kt["fwd_ms"] / K, "bwd_ms_per_step": kt["bwd_ms"] / K,
                "mean_prim_contacts_per_step": mean(0, "prim_contacts"), "mean_self_contacts_per_step": mean(0, "self_contacts"),
                "mean_pd_iters_per_step": pd, "mean_cg_iters_per_pd_iter": mean(0, "cg_iters") / max(pd, 1e-30),
-               "mean_adjoint_iters_per_step": mean(1, "adjoint_iters"), "slowest_rollout_adjoint_iters_per_step": float(per_rollout_adj.max()),
+               "mean_adjoint_iters_per_step": mean(1, "adjoint_iters"), "mean_adjoint_cg_iters_per_step": mean(1, "cg_iters"),
+               "slowest_rollout_adjoint_iters_per_step": float(per_rollout_adj.max()),
                "fp64_fallback_iters_per_step": mean(1, "fp64_iters"),
                "forward_converged_fraction": float(np.mean([(st[0]["converged"] > 0).mean() for st in fs])),
                "adjoint_converged_fraction": float(np.mean([(st[1]["converged"] != 0).mean() for st in fs])),
@@ -348,10 +349,11 @@ def main():
     bytes_fwd_stream = (108.0 * pd + 132.0 * cg_f) * N
     lds_cycles_fwd = (cg_f * rows64 * (12 * 4 + 14) + pd * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 80.0 * rows64)) / max(B * cl, 1)
     if args.adjoint_mode == 1:
-        bytes_bwd = (72.0 * B * K + 388.0 * adj + 96.0 * cyc + 100.0 * B * K) * N
+        # (cg_b: iterations of the CG correction solves since round 6 — one operator application of 108 B + two vector passes of 72 + 36 B)
+        bytes_bwd = (72.0 * B * K + 388.0 * adj + 216.0 * cg_b + 96.0 * cyc + 100.0 * B * K) * N
     else:
         bytes_bwd = (72.0 * B * K + 24.0 * adj + 132.0 * cg_b + 100.0 * B * K) * N
-    lds_cycles_bwd = (2.0 * adj + cyc) * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 80.0 * rows64) / max(B * cl, 1)
+    lds_cycles_bwd = (2.0 * adj + (cg_b if args.adjoint_mode == 1 else 0.0) + cyc) * (12 * 1.15 * rows64 + 36.0 * T / 64 + 38.0 * E / 64 + 80.0 * rows64) / max(B * cl, 1)
     try:
         clock_hz = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
     except Exception:
@@ -415,8 +417,8 @@ def main():
                           "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
                           "model": "compulsory HBM bytes of the resident design: (108 I_pd + 64 per step) N; CG vectors never leave the CU"})
     k_bwd = kernel_entry("k_adjoint_step_cl" if cl > 1 else "k_adjoint_step", bytes_bwd, lds_cycles_bwd, kt["bwd_ms"], kt["bwd_launches"],
-                         {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + 48.0 * cyc + 60.0 * B * K) * N,
-                          "model": "Krylov vectors stream through HBM: (72 + 100) N per step + 388 N per BiCGSTAB iteration + 96 N per fp64 residual"})
+                         {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + (36.0 * cg_b if args.adjoint_mode == 1 else 0.0) + 48.0 * cyc + 60.0 * B * K) * N,
+                          "model": "Krylov vectors stream through HBM: (72 + 100) N per step + 388 N per BiCGSTAB iteration + 216 N per CG iteration + 96 N per fp64 residual"})
     dom = dict(k_fwd if kt["fwd_ms"] >= kt["bwd_ms"] else k_bwd)
     bound = dom["bound"]
     dx, dv, dmu = e.get_gradient()
@@ -442,8 +444,10 @@ def main():
                        "adjoint_rel_tol": args.adjoint_rel_tol, "adjoint_block_precond": args.block_precond, "selfcollision": bool(args.selfcollision),
                        "mean_self_contacts_per_step": selfc / (B * K), "mean_prim_contacts_per_step": primc / (B * K),
                        "mean_pd_iters_per_step": pd / (B * K), "mean_cg_iters_per_pd_iter": cg_f / max(pd, 1),
-                       "mean_adjoint_iters_per_step": adj / (B * K), "mean_fp32_solves_per_adjoint": cyc / (B * K),
-                       "fp64_fallback_iters": it64, "adjoint_precision": "mixed: fp32 BiCGSTAB corrections of the fp64 residual",
+                       "mean_adjoint_iters_per_step": adj / (B * K), "mean_adjoint_cg_iters_per_step": (cg_b / (B * K)) if args.adjoint_mode == 1 else 0.0,
+                       "mean_adjoint_operator_applications_per_step": (2.0 * adj + (cg_b if args.adjoint_mode == 1 else 0.0)) / (B * K),
+                       "mean_fp32_solves_per_adjoint": cyc / (B * K),
+                       "fp64_fallback_iters": it64, "adjoint_precision": "mixed: fp32 CG (BiCGSTAB once a CG cycle fails to contract) corrections of the fp64 residual",
                        "converged_fraction": conv / (B * K),
                        "slowest_rollout_over_mean": {"forward_pcg_iterations": float(cg_per_rollout.max() / max(cg_per_rollout.mean(), 1e-30)),
                                                      "adjoint_iterations": float(adj_per_rollout.max() / max(adj_per_rollout.mean(), 1e-30)),

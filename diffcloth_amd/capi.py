@@ -42,7 +42,7 @@ class dc_step_stats(C.Structure):
 
 class dc_bwd_stats(C.Structure):
     _fields_ = [("converged", C.c_int), ("adjoint_iters", C.c_int), ("cg_iters", C.c_int), ("clipped", C.c_int), ("used_direct", C.c_int),
-                ("last_udiff", C.c_float), ("refine_cycles", C.c_int), ("fp64_iters", C.c_int), ("residual_verified", C.c_int)]
+                ("last_udiff", C.c_float), ("refine_cycles", C.c_int), ("fp64_iters", C.c_int), ("residual_verified", C.c_int), ("workgroups", C.c_int)]
 
 
 class dc_record(C.Structure):
@@ -325,7 +325,7 @@ class Engine:
         self._chk(self.lib.dc_step_backward(self.h, C.c_int(slot), _d(gx), _d(gv), _d(ix), _d(iv), C.c_int(int(is_start)),
                                             _d(dx), _d(dv), _d(dxf), _d(dmu), st))
         out = dict(dL_dx=dx, dL_dv=dv, dL_dxfixed=dxf[:, :3 * self.Af], dL_dmu=dmu)
-        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters", "residual_verified"]))
+        out.update(_stats_to_dict(st, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters", "residual_verified", "workgroups"]))
         return out
 
     # ---- device-pointer boundary (torch tensors on this GPU: no host copies, no synchronisation) ----
@@ -435,7 +435,7 @@ class Engine:
         f = (dc_step_stats * self.B)(); b = (dc_bwd_stats * self.B)()
         self._chk(self.lib.dc_get_stats(self.h, C.c_int(slot), f, b))
         return (_stats_to_dict(f, ["converged", "pd_iters", "cg_iters", "prim_contacts", "self_contacts", "last_xdiff", "self_overflow"]),
-                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters", "residual_verified"]))
+                _stats_to_dict(b, ["converged", "adjoint_iters", "cg_iters", "clipped", "used_direct", "last_udiff", "refine_cycles", "fp64_iters", "residual_verified", "workgroups"]))
 
     def sync(self):
         self._chk(self.lib.dc_sync(self.h))

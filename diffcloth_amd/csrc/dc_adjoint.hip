@@ -570,16 +570,129 @@ __device__ DC_OUTLINED Ret32 bicgstab32_solve(const DevSystem &S, AdjCtx C, Kryl
   return Ret32{in_status, kdone, iters, rr};
 }
 
+// The same correction solve by preconditioned CG (round 6; diag(P)^-1 preconditioner only). K = P - dP^T is symmetric without contact and
+// non-symmetric by a few per cent with it (|K - K^T|_F / |K|_F = 4 % on the bench step; tools/offline_adjoint_methods.py), and CG — ONE operator
+// application and two vector passes per iteration where BiCGSTAB takes two and three — reaches a correction solve's 1e-3 in ~10 % fewer
+// applications there (58 ... 60 against 64 ... 68 over a step's two solves). CG is not a method for a non-symmetric matrix; what makes it
+// admissible is the refinement around it: every correction solve is followed by the fp64 residual of the true operator, so the solve only has to
+// be a contraction. The caller switches to BiCGSTAB for the remaining cycles of a step as soon as a CG cycle fails to contract that residual
+// 4 x, breaks down (p.Kp <= 0) or stalls — the direct-solve semantics (Simulation.cpp:1431-1440) are the refinement's, not the inner method's.
+// kdone / kcap count operator applications in pairs like BiCGSTAB iterations (two CG iterations = one); Ret32::iters returns the CG iterations of the solve (dc_bwd_stats::cg_iters).
+template <int THREADS, bool WIN>
+__device__ DC_OUTLINED Ret32 cg32_solve(const DevSystem &S, AdjCtx C, Krylov32 V, double in_stop, int kcap, int stall_window,
+                                        double *red, int kdone) {
+  const int N = S.N, tid = threadIdx.x;
+  constexpr int VB = 4;
+  __shared__ double redc[6 * (THREADS / 64)];      // (krylov_sum: a slot per reduction of the iteration)
+  float *gin = V.rhs, *u = V.d, *r = V.r, *p = V.p, *v = V.v;
+  float part = 0.f, part2 = 0.f, d1, d2;
+  for (int i = tid; i < N; i += THREADS) {
+    const f3 q = ld3(gin, i, N);
+    const f3 z = q * S.dinv[i];
+    st3(r, i, N, q); st3(p, i, N, z); st3(u, i, N, mk(0, 0, 0));
+    part += dot(q, z); part2 += dot(q, q);
+  }
+  double rz = (double) part, rr = (double) part2;
+  block_sum2<THREADS>(rz, rr, red);
+  double best_rr = rr;
+  int since_progress = 0, its = 0;
+  int in_status = (rr <= in_stop) ? 1 : 0;
+  for (int k = 2 * kdone; k < 2 * kcap && in_status == 0; k++) {
+    // v = K p ;  alpha = (r . z) / (p . v)
+    adjoint_operator<THREADS, WIN, true>(S, C, p, false, v, p, d1, d2);
+    const double pv = krylov_sum<THREADS>(d1, redc);
+    if (!(pv > 1e-300)) { in_status = 2; break; }      // not a descent direction in K's "energy": this system is not for CG
+    const float alpha = (float) (rz / pv);
+    // d += alpha p ;  r -= alpha v ;  (r . D^-1 r), (r . r)
+    float pa = 0.f, pb = 0.f;
+    for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+      f3 rq[VB], vq[VB], pq[VB], uq[VB];
+      float dq[VB];
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int ic = min(i0 + j * THREADS, N - 1);
+        rq[j] = ld3(r, ic, N); vq[j] = ld3(v, ic, N); pq[j] = ld3(p, ic, N); uq[j] = ld3(u, ic, N); dq[j] = S.dinv[ic];
+      }
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int i = i0 + j * THREADS;
+        const f3 rn = rq[j] - vq[j] * alpha;
+        if (i < N) { st3(r, i, N, rn); st3(u, i, N, uq[j] + pq[j] * alpha); pa += dot(rn, rn) * dq[j]; pb += dot(rn, rn); }
+      }
+    }
+    double rz_new;
+    krylov_sum2<THREADS>(pa, pb, redc + 2 * (THREADS / 64), rz_new, rr);
+    its++;
+    if (rr <= in_stop) { in_status = 1; break; }
+    if (rr < best_rr) { best_rr = rr; since_progress = 0; }
+    else if (++since_progress >= stall_window) { in_status = 2; break; }      // (stall_window is INT_MAX unless the caller set one: |r| of CG is not monotone)
+    if (!(rr < 1e8 * best_rr)) { in_status = 2; break; }      // diverging (NaN-safe)
+    const float beta = (float) (rz_new / rz);
+    rz = rz_new;
+    // p = D^-1 r + beta p
+    for (int i0 = tid; i0 < N; i0 += VB * THREADS) {
+      f3 rq[VB], pq[VB];
+      float dq[VB];
+#pragma unroll
+      for (int j = 0; j < VB; j++) { const int ic = min(i0 + j * THREADS, N - 1); rq[j] = ld3(r, ic, N); pq[j] = ld3(p, ic, N); dq[j] = S.dinv[ic]; }
+#pragma unroll
+      for (int j = 0; j < VB; j++) {
+        const int i = i0 + j * THREADS;
+        if (i < N) st3(p, i, N, rq[j] * dq[j] + pq[j] * beta);
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  return Ret32{in_status, kdone + (its + 1) / 2, its, rr};      // (iters = the CG iterations of this solve)
+}
+
 // The contact vertices' y list (AdjCtx::ylist) in what the windows leave of the CU's LDS — for the 1024-thread kernels, which have their CU to
 // themselves at 128 registers per lane whatever their LDS (4 waves per SIMD): the larger request costs no mesh a second workgroup per CU.
 // Returns the bytes to add to the launch's dynamic LDS and sets A.ycap.
+// `lds_limit` = what the device grants a workgroup (hipDeviceAttributeMaxSharedMemoryPerBlock), `static_lds` = the instance's own static LDS
+// (hipFuncGetAttributes::sharedSizeBytes): both queried, not assumed — see adj_lds_budget below.
 template <int THREADS>
-static size_t ylist_room(const DevSystem &S, size_t lds, BwdArgs &A) {
+static size_t ylist_room(const DevSystem &S, size_t lds, BwdArgs &A, size_t lds_limit, size_t static_lds) {
   A.ycap = 0; A.ybase = (int) (lds / 4);
-  if (THREADS != 1024 || lds + 256 + 4096 + 12 > (size_t) 160 * 1024) return 0;      // (4096: static LDS of the instances, rounded up)
-  const size_t room = (size_t) 160 * 1024 - 256 - 4096 - lds;
+  const size_t reserve = static_lds + 256;
+  if (THREADS != 1024 || lds + reserve + 12 > lds_limit) return 0;
+  const size_t room = lds_limit - reserve - lds;
   A.ycap = (int) std::min(room / 12, (size_t) S.N + 2 * (size_t) S.self_cap);
   return (size_t) A.ycap * 12;
+}
+// LDS limit of the current device and static LDS of a kernel instance, each queried once per (device, instance)
+struct AdjLdsBudget { size_t limit, static_lds; bool ok; };
+static AdjLdsBudget adj_lds_budget(const void *func, int dev) {
+  AdjLdsBudget b{(size_t) 64 * 1024, (size_t) 4096, false};
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) b.limit = (size_t) v;
+  // (a workgroup may be granted the whole CU's LDS through hipFuncAttributeMaxDynamicSharedMemorySize: 160 KB on gfx950)
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && (size_t) v > b.limit) b.limit = (size_t) v;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, func) == hipSuccess) { b.static_lds = fa.sharedSizeBytes; b.ok = true; }
+  return b;
+}
+// Configures the instance's dynamic LDS for this launch: windows (`lds`) + the y list in what is left. When the device refuses the larger
+// request the launch goes without the list (ycap = 0) instead of failing without a diagnosis.
+template <int THREADS>
+static size_t adj_configure_lds(const void *func, const DevSystem &S, size_t lds, BwdArgs &Ay, size_t (&configured)[kMaxDevices], AdjLdsBudget (&budget)[kMaxDevices]) {
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  const int slot = dev >= 0 && dev < kMaxDevices ? dev : 0;
+  if (!budget[slot].ok || dev >= kMaxDevices) budget[slot] = adj_lds_budget(func, dev);
+  const size_t base = lds;
+  lds += ylist_room<THREADS>(S, lds, Ay, budget[slot].limit, budget[slot].static_lds);
+  size_t &done = configured[slot];
+  if (lds > done || dev >= kMaxDevices) {
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) == hipSuccess) done = lds;
+    else {
+      (void) hipGetLastError();
+      Ay.ycap = 0; lds = base;
+      if (lds > done) { if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) == hipSuccess) done = lds; }
+    }
+  }
+  return lds;
 }
 
 // BLK: direct solve preconditioned with K's own 3 x 3 diagonal blocks (dc_adjprecond.h) instead of diag(P)^-1
@@ -788,6 +901,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     double rr = rr_true;
     double op_err = 0;         // measured error of the fp32 operator (see below)
     bool fallback = false;
+    bool use_cg = !BLK && !COARSE && A.cg_first != 0;      // CG first; BiCGSTAB once a CG cycle has not contracted the fp64 residual (cg32_solve)
     status = (rr_true <= stop) ? 1 : 0;
     for (int kdone = 0; status == 0 && !fallback; cycles++) {
     // inner tolerance of this cycle: what is left to the target, but never below kInnerFloor of the cycle's own right-hand side
@@ -797,7 +911,10 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     const double in_tol = A.fp32_only ? (double) A.rel_tol : fmax(0.3 * (double) A.rel_tol / rel_now, kInnerFloor);
     const double in_stop = in_tol * in_tol * rr_true;
     Krylov32 KV{gin, u, r, p, v, t, rhat, ph, sh, minv};
-    const Ret32 r32 = bicgstab32_solve<THREADS, WIN, BLK, COARSE>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone, iters);
+    const bool cg_cycle = use_cg;
+    Ret32 r32;
+    if (cg_cycle) { r32 = cg32_solve<THREADS, WIN>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone); cg_total += r32.iters; r32.iters = iters; }
+    else r32 = bicgstab32_solve<THREADS, WIN, BLK, COARSE>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone, iters);
     const int in_status = r32.status;
     kdone = r32.kdone; iters = r32.iters; rr = r32.rr;
     __syncthreads();
@@ -835,7 +952,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
       __syncthreads();
       rr_new = residual64<THREADS>(S, C64, tm, W64, gx, gscale).rr;
     }
-    if (!(rr_new < 0.0625 * rr_true) || in_status != 1 || cycles + 1 >= kMaxRefine || kdone >= kcap) fallback = true;
+    if (!(rr_new < 0.0625 * rr_true) || in_status != 1 || cycles + 1 >= kMaxRefine || kdone >= kcap) {
+      // a CG cycle that did not deliver: the remaining cycles of this step are BiCGSTAB's (the correction was kept only if it helped)
+      if (cg_cycle && cycles + 1 < kMaxRefine && kdone < kcap) use_cg = false;
+      else fallback = true;
+    }
     rr_true = rr_new;
     if (!fallback) {
       for (int i = tid; i < N; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));
@@ -871,6 +992,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     s.converged = status; s.adjoint_iters = iters; s.cg_iters = cg_total; s.clipped = clipped;
     s.used_direct = used_direct; s.last_udiff = (float) udiff;
     s.refine_cycles = cycles; s.fp64_iters = iters64; s.residual_verified = (used_direct && !A.fp32_only) ? verified : 0;
+    s.workgroups = 1;
     A.stats[b] = s;
   }
   PH(3)
@@ -894,15 +1016,9 @@ static void launch_adj_b(const DevSystem &S, const DevWork &W, const BwdArgs &A,
   size_t lds = (size_t) S.win_lds_bytes;
   if (DENSE) lds = std::max(lds, sizeof(float) * (size_t) (3 * S.dense_ld + dense_lds_floats(S.dense_ld, THREADS / 64)));
   BwdArgs Ay = A;
-  lds += ylist_room<THREADS>(S, lds, Ay);
   static size_t configured[kMaxDevices] = {};        // the attribute is per device: one entry per device this process has used
-  int dev = 0;
-  (void) hipGetDevice(&dev);
-  size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
-  if (lds > done || dev >= kMaxDevices) {
-    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, DENSE, BLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    done = lds;
-  }
+  static AdjLdsBudget budget[kMaxDevices] = {};
+  lds = adj_configure_lds<THREADS>((const void *) k_adjoint_step<THREADS, true, DENSE, BLK>, S, lds, Ay, configured, budget);
   hipLaunchKernelGGL((k_adjoint_step<THREADS, true, DENSE, BLK>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, Ay);
 }
 // the instances with the coarse level of the preconditioner (meshes the engine built a deflation space for, direct solve, block preconditioner):
@@ -911,15 +1027,9 @@ template <int THREADS>
 static void launch_adj_coarse(const DevSystem &S, const DevWork &W, const BwdArgs &A, int B, hipStream_t st) {
   size_t lds = std::max((size_t) S.win_lds_bytes, sizeof(float) * (size_t) kCoarseLdsFloats);
   BwdArgs Ay = A;
-  lds += ylist_room<THREADS>(S, lds, Ay);
   static size_t configured[kMaxDevices] = {};
-  int dev = 0;
-  (void) hipGetDevice(&dev);
-  size_t &done = configured[dev >= 0 && dev < kMaxDevices ? dev : 0];
-  if (lds > done || dev >= kMaxDevices) {
-    (void) hipFuncSetAttribute((const void *) k_adjoint_step<THREADS, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    done = lds;
-  }
+  static AdjLdsBudget budget[kMaxDevices] = {};
+  lds = adj_configure_lds<THREADS>((const void *) k_adjoint_step<THREADS, true, false, true, true>, S, lds, Ay, configured, budget);
   hipLaunchKernelGGL((k_adjoint_step<THREADS, true, false, true, true>), dim3(B), dim3(THREADS), lds, st, S.self_dev, W, Ay);
 }
 template <int THREADS, bool DENSE>

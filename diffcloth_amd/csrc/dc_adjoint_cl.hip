@@ -495,6 +495,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     s.converged = status; s.adjoint_iters = iters; s.cg_iters = 0; s.clipped = clipped;
     s.used_direct = 1; s.last_udiff = (float) udiff;
     s.refine_cycles = cycles; s.fp64_iters = iters64; s.residual_verified = A.fp32_only ? 0 : verified;
+    s.workgroups = K;
     A.stats[b] = s;
   }
   (void) none;
@@ -502,8 +503,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
 }
 
 // nb rollouts starting at b0, K workgroups each (adjoint_mode 1 only); exchange area zeroed by the caller, K nb <= CUs.
+#ifndef DC_ADJ_CL_THREADS
+#define DC_ADJ_CL_THREADS 512      // round 6: 512 threads x 256 registers (241 spilled VGPRs, 556 B scratch) instead of 1024 x 128 (855 / 1 144 B): -8 % per step
+#endif
 hipError_t launch_adjoint_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const BwdArgs &A, int b0, int nb, hipStream_t st) {
-  constexpr int THREADS = 1024;
+  constexpr int THREADS = DC_ADJ_CL_THREADS;
   const int hc_off = (CL.win_lds_bytes / 4 + 3) / 4 * 4;
   const int tail_off = hc_off + 6 * CL.HB;
   const size_t lds = sizeof(float) * (size_t) (tail_off + kXchLdsFloats);

@@ -118,7 +118,7 @@ __device__ __forceinline__ Xch xch_init(const DevCluster &CL, int lb, int part, 
   if (threadIdx.x == 0) *X.ldead = 0;
   return X;
 }
-constexpr int kXchLdsFloats = 16;      // tail of the dynamic LDS the exchange uses (lsum[2][4], ldead, padding)
+constexpr int kXchLdsFloats = 32;      // tail of the dynamic LDS the exchange uses (lsum[2][4], ldead, padding; [16, 32): the six-sum totals, two parities of 8)
 
 __device__ __forceinline__ int xch_off(const Xch &X, int part, int g) { return ((part * 2 + (int) (X.seq & 1u)) * X.stride + g) * 16; }
 
@@ -224,6 +224,67 @@ __device__ __forceinline__ bool xch_finish(const Xch &X, double (&sums)[3], f3 (
   if (!ok) *X.ldead = 1;
   __syncthreads();
   sums[0] = (double) slot[0]; sums[1] = (double) slot[1]; sums[2] = (double) slot[2];
+  return *X.ldead == 0;
+}
+
+// ---- six sums in one exchange: every wave publishes TWO granules (its slot w and slot NW + w; kXchWaves >= 2 NW) ----
+// Used by the single-exchange CG of the split forward kernel (dc_forward_cl_kernel.h): p.Ap, p.r, r.Ap, Ap.Ap and r.r of an iteration
+// travel together with the boundary rows of A p.
+__device__ __forceinline__ void xch_publish_sums6(const Xch &X, int nw, float a, float b, float c, float d, float e, float f) {
+  a = xch_wave_sum(a); b = xch_wave_sum(b); c = xch_wave_sum(c); d = xch_wave_sum(d); e = xch_wave_sum(e); f = xch_wave_sum(f);
+  if ((threadIdx.x & 63) == 0) {
+    const int w = (int) (threadIdx.x >> 6);
+    v4i g0 = {__float_as_int(a), __float_as_int(b), __float_as_int(c), (int) X.seq};
+    v4i g1 = {__float_as_int(d), __float_as_int(e), __float_as_int(f), (int) X.seq};
+    xch_store(X, g0, xch_off(X, X.part, w));
+    xch_store(X, g1, xch_off(X, X.part, nw + w));
+  }
+}
+// the matching wait: waves 0 and 1 poll the two granules of every (part, wave) pair, add them up in a fixed order (bitwise the same
+// totals on every part) and leave six totals in LDS; all waves then poll the halo rows. ONE workgroup barrier. lsum6 = 12 floats of LDS (two parities) behind the regular totals.
+template <int THREADS, int HPT, bool HALO>
+__device__ __forceinline__ bool xch_finish6(const Xch &X, float *lsum6, double (&sums)[6], f3 (&hv)[HPT]) {
+  constexpr int NW = THREADS / 64;
+  static_assert(2 * NW <= kXchWaves, "two sum granules per wave");
+  const int tid = threadIdx.x;
+  bool ok = true;
+  float *slot = lsum6 + 8 * (int) (X.seq & 1u);
+  if (tid < 128) {
+    // wave 0 polls the first triple of every (part, wave) pair, wave 1 the second: one poll per lane in flight (K NW <= 64), as in xch_finish
+    const int half = tid >> 6, ln = tid & 63;
+    float a = 0.f, b = 0.f, c = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int j = ln + 64 * q;                // (part, wave) pair j: part j / NW, wave j % NW
+      if (j < X.K * NW) {
+        v4i g;
+        ok = xch_poll(X, xch_off(X, j / NW, half * NW + j % NW), g) && ok;
+        a += __int_as_float(g.x); b += __int_as_float(g.y); c += __int_as_float(g.z);
+      }
+    }
+    a = xch_wave_sum(a); b = xch_wave_sum(b); c = xch_wave_sum(c);
+    if (ln == 0) { slot[3 * half] = a; slot[3 * half + 1] = b; slot[3 * half + 2] = c; }
+  }
+  if constexpr (HALO) {
+#pragma unroll
+    for (int q = 0; q < HPT; q++) {
+      const int j = tid + q * THREADS;
+      hv[q] = mk(0, 0, 0);
+      if (j < 2 * X.HB) {
+        const bool lower = j < X.HB;
+        const int src = lower ? X.part - 1 : X.part + 1;
+        if (src >= 0 && src < X.K) {
+          v4i g;
+          ok = xch_poll(X, xch_off(X, src, kXchWaves + (lower ? X.HB + j : j - X.HB)), g) && ok;
+          hv[q] = mk(__int_as_float(g.x), __int_as_float(g.y), __int_as_float(g.z));
+        }
+      }
+    }
+  }
+  if (!ok) *X.ldead = 1;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; k++) sums[k] = (double) slot[k];
   return *X.ldead == 0;
 }
 

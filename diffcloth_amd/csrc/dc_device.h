@@ -207,6 +207,7 @@ struct BwdArgs {
   int fp32_only;                // direct solve: 1 = the fp32 Krylov solve alone (no fp64 residual, no refinement, no fp64 fall-back)
   int dense_y;                  // 1 = form y = (I + dr_df)^T z over all vertices in every operator application (development switch DC_ADJ_DENSEY)
   int verify_all;               // direct solve: 1 = evaluate the fp64 residual after EVERY correction solve (development switch DC_ADJ_VERIFY)
+  int cg_first;                 // direct solve, diag(P) preconditioner: correction solves by CG, BiCGSTAB once a CG cycle fails to contract the fp64 residual (DC_ADJ_CG, default 1)
   int warm;                     // direct solve inside a fused sweep: start step s > 0 from gamma u*(step s - 1) (DC_ADJ_WARM, dc_adjoint.hip)
   int ycap, ybase;              // entries of the contact vertices' y list in the dynamic LDS and its start in floats (set by the launch: dc_adjoint.hip, AdjCtx::ylist)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s

@@ -258,6 +258,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   { const char *envp = getenv("DC_ADJ_DENSEY"); A.dense_y = envp ? (envp[0] == '1') : 0; }
   { const char *envp = getenv("DC_ADJ_VERIFY"); A.verify_all = envp ? (envp[0] == '1') : 0; }     // (development switch)
   { const char *envp = getenv("DC_ADJ_WARM"); A.warm = envp ? (envp[0] == '1') : 0; }            // (development switch)
+  { const char *envp = getenv("DC_ADJ_CG"); A.cg_first = envp ? (envp[0] == '1') : 1; }          // (A/B switch: 0 = BiCGSTAB correction solves only)
   A.ycap = 0; A.ybase = 0;                                                                                    // (set by the launch, dc_adjoint.hip)
   A.nsteps = 1; A.slot = slot;
   const bool inj = c->inj_slot == slot && c->INJ_X;

@@ -22,13 +22,14 @@ hipError_t launch_pd_step_cluster_deflated(const DevSystem &S, const DevCluster 
 // then land on ONE XCD whatever nb is (cluster_map), which lets their exchanges stay in that XCD's L2; the padding workgroups
 // exit at once. Correctness does not depend on the placement (xch_hello checks it at run time).
 hipError_t launch_pd_step_cluster(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
-  // Pipelined CG (one exchange per iteration, needs <= 6 rows per thread for its seven row vectors) is OFF unless DC_PIPECG=1
-  // (development switch). Measured r02v, C4 at 32 rollouts x 8 workgroups: forward 8.77 -> 7.99 ms per step (+8 % rollout-steps/s),
-  // same PD / CG iteration counts — but its recurrences for A r, A p, A s drift in fp32: at N = 16 384 (36 iterations per solve)
-  // the converged positions moved by 7e-5 against the fp64 oracle (bound 4.5e-5; the two-exchange CG: 1.2e-7). Parity first.
+  // Single-exchange CG (dc_forward_cl_kernel.h, PIPE = true): ONE exchange per CG iteration instead of two — standard CG whose r.r of the next
+  // residual comes from r.r - 2 alpha r.Ap + alpha^2 Ap.Ap (all four sums and the boundary rows of A p in the one exchange). Default since
+  // round 6; DC_SXCG=0 selects the two-exchange loop (A/B runs). History: round 4's pipelined CG (Ghysels & Vanroose) also had one exchange
+  // per iteration but carried A r, A p, A s by vector recurrences that drift in fp32 (7e-5 on positions at N = 16 384, docs/HISTORY.md);
+  // here no vector is recurred.
   if (S.defl_u && S.fwd_defl) return launch_pd_step_cluster_deflated(S, CL, W, A, b0, nb, st);
-  static const bool pipe_ok = getenv("DC_PIPECG") && getenv("DC_PIPECG")[0] == '1';
-#define DC_CL_CASE(V) case V: if (pipe_ok && V <= 6) return A.inline_detect ? launch_cl_inst<V, true, (V <= 6)>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, (V <= 6)>(S, CL, W, A, b0, nb, st); \
+  static const bool sx = !(getenv("DC_SXCG") && getenv("DC_SXCG")[0] == '0');
+#define DC_CL_CASE(V) case V: if (sx) return A.inline_detect ? launch_cl_inst<V, true, true>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, true>(S, CL, W, A, b0, nb, st); \
                               return A.inline_detect ? launch_cl_inst<V, true, false>(S, CL, W, A, b0, nb, st) : launch_cl_inst<V, false, false>(S, CL, W, A, b0, nb, st);
   switch (CL.pk_vpt) {
     DC_CL_CASE(1) DC_CL_CASE(2) DC_CL_CASE(3) DC_CL_CASE(4) DC_CL_CASE(6) DC_CL_CASE(8) DC_CL_CASE(12)

@@ -21,7 +21,7 @@ namespace dc {
 #define CPH_PRINT
 #endif
 
-// PIPE: the inner solve is the pipelined CG of Ghysels & Vanroose (one exchange per iteration instead of two), see the loop
+// PIPE: the inner solve is the single-exchange CG (one exchange per iteration instead of two), see the loop
 template <int THREADS, int VPT, bool DETECT, bool PIPE, bool DEFL>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
                                                         FwdArgs A, int b0, int nb_real, int tail_off, int fric_floats) {
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   if (!xch_hello<THREADS>(X)) return;
   float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
   float *gz = lds + 2 * GL;
-  float2 *gxy1 = (float2 *) (lds + 3 * GL);   // PIPE: second gather array (the iterations alternate between the two)
-  float *gz1 = lds + 5 * GL;
+  float2 *gxy1 = (float2 *) (lds + 3 * GL);   // PIPE: the neighbours' residual rows [2 HB] (float2 plane, then the z plane)
+  float *gz1 = lds + 3 * GL + 4 * HB;
   const int N = S.N;
   const int r0 = part * R, r1 = min(N, r0 + R);
   const int nch = R >> 6, cbase = r0 >> 6;
@@ -218,9 +218,10 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
 #pragma unroll
       for (int k = 0; k < VPT; k++) {
         const int lc = wz + k * WAVES;          // wave-uniform local chunk
-        const int lcc = min(lc, nch - 1);
-        const float onf = lc < nch ? 1.f : 0.f;
-        const int chunk = cbase + lcc;
+        // a chunk past the part's rows (R / 64 is not a multiple of the wave count: 20 chunks on 8 waves leave waves 4 ... 7 without a third one)
+        // is SKIPPED, not computed and masked: the SIMD's other wave gets the issue slots (round 6; before, every wave ran all VPT rows)
+        if (lc >= nch) { ap[k][0] = 0.f; ap[k][1] = 0.f; ap[k][2] = 0.f; continue; }
+        const int chunk = cbase + lc;
         const int np = CL.pk_n[chunk];
         const int4 *row = CL.pk + CL.pk_ptr[chunk] + lane;
         int4 cur[PB];
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           for (int j = 0; j < PB; j++) cur[j] = nxt[j];
           if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
         }
-        const int li = HB + lcc * 64 + lane;
+        const int li = HB + lc * 64 + lane;
         const float2 pxy = vxy[li];
         const float pz = vz[li];
         float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
@@ -242,9 +243,9 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           load_batch(cur, row, s0);
           consume_pf(cur, vxy, vz, base, ax, ay, az);
         }
-        ap[k][0] = ax * onf; ap[k][1] = ay * onf; ap[k][2] = az * onf;
-        part2 += (pxy.x * ax + pxy.y * ay + pz * az) * onf;
-        if (with_pr) part3 += (pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2]) * onf;     // seeded pass only (uniform branch)
+        ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
+        part2 += pxy.x * ax + pxy.y * ay + pz * az;
+        if (with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];     // seeded pass only (uniform branch)
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -252,78 +253,106 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     CPH(2)
     // ---- global step: CG on the scaled system = Jacobi PCG on P dv = rhs ----
     if constexpr (PIPE) {
-      // Pipelined CG (Ghysels & Vanroose 2014, unpreconditioned form — the system is already scaled): besides x, r, p it carries
-      // w = A r, s = A p, z = A s by recurrence, so that both inner products of an iteration, (r, r) and (w, r), are available
-      // BEFORE its one matrix product q = A w. They travel in the same exchange as the boundary rows of w that product needs:
-      // ONE exchange per iteration instead of two, one more product per solve, three more axpys per iteration. Same iterates
-      // as CG in exact arithmetic; in fp32 the recurrences cost about a digit of attainable accuracy, far below cg_rel_tol.
+      // Single-exchange CG (round 6). Standard CG — same vectors, same updates, no vector recurrences — whose TWO exchanges per iteration
+      // ([p.Ap] and [r.r + boundary rows of the new residual]) are folded into ONE: the product pass also forms r.Ap, Ap.Ap and the true
+      // r.r of the CURRENT residual, and they travel with the boundary rows of A p. Then
+      //     alpha   = r.r / p.Ap                          (seeded pass: d.r / d.Ad — the line search along the recycled direction)
+      //     |r'|^2  = r.r - 2 alpha r.Ap + alpha^2 Ap.Ap   (one step from a TRUE r.r: the rounding of the three sums, ~1e-6 relative, never accumulates)
+      //     beta    = |r'|^2 / r.r
+      // and every part updates, besides its own rows, its copy of the neighbours' boundary rows of r and p itself: r_halo -= alpha (A p)_halo
+      // with the received rows (bitwise the neighbour's own update), p_halo = r_halo + beta p_halo. The neighbours' residual rows live in a
+      // second small LDS array (rh). What the pipelined CG of round 4 lost (its recurrences for A r, A p, A s drift in fp32: 7e-5 at
+      // N = 16 384) cannot happen here: the only recurred quantity is the scalar |r'|^2, re-based on the true value every iteration.
+      float2 *rhxy = gxy1;                       // [2 HB] residual rows of the neighbours (same indexing as the halo rows of gxy: j < HB lower, HB + j upper)
+      float *rhz = gz1;
+      float *lsum6 = X.lsum + 16;
       if (rz > 1e-300) {
         const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
-        float ww[VPT][3], pp[VPT][3], ss[VPT][3], zz[VPT][3];
-        {
-          int zs;
-          asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-          float unused = 0.f;
-          spmv(wv + zs, gxy, gz, unused, false, unused);            // w = A r (r and its halo are in the first gather array)
+        {   // the neighbours' rows of r0 = rhs arrived with the exchange above and sit in the halo rows of the direction: keep a copy as r_halo
+#pragma unroll
+          for (int q = 0; q < HPT; q++) {
+            const int j = tid + q * THREADS;
+            if (j < 2 * HB) { const int li = j < HB ? j : R + j; rhxy[j] = gxy[li]; rhz[j] = gz[li]; }
+          }
         }
-#pragma unroll
-        for (int k = 0; k < VPT; k++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) { ww[k][c] = ap[k][c]; pp[k][c] = 0.f; ss[k][c] = 0.f; zz[k][c] = 0.f; }
-        float alpha_old = 1.f;
-        double gamma_old = 1.0;
-        for (int it = 0;;) {
+        bool seed = A.cg_seed && iter > 0;
+        if (seed) {
+          __syncthreads();                                  // (the copy above reads halo rows other threads overwrite here)
+          for (int j = tid; j < R + 2 * HB; j += THREADS) {
+            const int i = r0 - HB + j;                      // gather index j <-> global row i
+            const bool on = i >= 0 && i < N && (j < HB || j >= HB + R || i < r1);
+            f3 d = mk(0, 0, 0);
+            if (on) d = ld3c(dpb, i);
+            gxy[j] = make_float2(d.x, d.y); gz[j] = d.z;
+          }
+          __syncthreads();
+        }
+        for (int it = 0; it < A.cg_max;) {
           int zs;
           asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
           const int wz = wv + zs, tz = tid + zs;
-          float2 *cxy = (it & 1) ? gxy : gxy1;        // this iteration's gather array for w (the other one may still be read)
-          float *cz = (it & 1) ? gz : gz1;
-          float pg = 0.f, pd = 0.f;
+          float s_pap = 0.f, s_pr = 0.f;
+          spmv(wz, gxy, gz, s_pap, seed, s_pr);
+          float s_rap = 0.f, s_apap = 0.f, s_rr = 0.f;
           X.site = 6;
           xch_begin(X);
 #pragma unroll
           for (int k = 0; k < VPT; k++) {
             const int l = tz + k * THREADS;
 #pragma unroll
-            for (int c = 0; c < 3; c++) { pg = fmaf(rr[k][c], rr[k][c], pg); pd = fmaf(ww[k][c], rr[k][c], pd); }
-            if (l < R) {
-              cxy[HB + l] = make_float2(ww[k][0], ww[k][1]); cz[HB + l] = ww[k][2];
-              xch_publish_boundary(X, l, R, ww[k][0], ww[k][1], ww[k][2]);
+            for (int c = 0; c < 3; c++) {
+              s_rap = fmaf(rr[k][c], ap[k][c], s_rap); s_apap = fmaf(ap[k][c], ap[k][c], s_apap); s_rr = fmaf(rr[k][c], rr[k][c], s_rr);
             }
+            if (l < R) xch_publish_boundary(X, l, R, ap[k][0], ap[k][1], ap[k][2]);
           }
-          xch_publish_sums(X, pg, pd, 0.f);
+          xch_publish_sums6(X, WAVES, s_pap, s_pr, s_rap, s_apap, s_rr, 0.f);
+          CPH(3)
+          double s6[6];
           f3 hv[HPT];
-          if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
-          const double gamma = sums[0], delta = sums[1];
-          if (!(gamma > stop) || it >= A.cg_max) break;
-          float beta = 0.f, alpha;
-          if (it == 0) alpha = (float) (gamma / delta);
-          else {
-            beta = (float) (gamma / gamma_old);
-            alpha = (float) (gamma / (delta - (double) beta * gamma / (double) alpha_old));
-          }
-          if (!(alpha > 0.f) || !isfinite(alpha)) break;        // breakdown: keep the iterate reached so far
+          if (!xch_finish6<THREADS, HPT, true>(X, lsum6, s6, hv)) return;
+          CPH(4)
+          const double rrt = s6[4];
+          const double pr = seed ? s6[1] : rrt;
+          const double alpha_d = s6[0] > 1e-300 ? pr / s6[0] : 0.0;
+          const float alpha = (float) alpha_d;
+          const double rz_new = rrt - 2.0 * alpha_d * s6[2] + alpha_d * alpha_d * s6[3];
+          it++; cg_total++;
+          const bool done = !(rz_new > stop);
+          const float beta = (seed || done) ? 0.f : (float) (rz_new / rrt);
+          seed = false;
 #pragma unroll
-          for (int q = 0; q < HPT; q++) {
-            const int j = tid + q * THREADS;
-            if (j < 2 * HB) { const int li = j < HB ? j : R + j; cxy[li] = make_float2(hv[q].x, hv[q].y); cz[li] = hv[q].z; }
-          }
-          __syncthreads();
-          float unused = 0.f;
-          spmv(wz, cxy, cz, unused, false, unused);                  // q = A w
-#pragma unroll
-          for (int k = 0; k < VPT; k++)
+          for (int k = 0; k < VPT; k++) {
+            const int l = tz + k * THREADS;
+            const int lc = min(l, R - 1);
+            const float2 pxy = gxy[HB + lc];
+            const float pv[3] = {pxy.x, pxy.y, gz[HB + lc]};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-              zz[k][c] = fmaf(beta, zz[k][c], ap[k][c]);
-              ss[k][c] = fmaf(beta, ss[k][c], ww[k][c]);
-              pp[k][c] = fmaf(beta, pp[k][c], rr[k][c]);
-              xx[k][c] = fmaf(alpha, pp[k][c], xx[k][c]);
-              rr[k][c] = fmaf(-alpha, ss[k][c], rr[k][c]);
-              ww[k][c] = fmaf(-alpha, zz[k][c], ww[k][c]);
+              xx[k][c] = fmaf(alpha, pv[c], xx[k][c]);
+              rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
             }
-          gamma_old = gamma; alpha_old = alpha;
-          it++; cg_total++;
+            if (l < R) {
+              gxy[HB + l] = make_float2(fmaf(beta, pv[0], rr[k][0]), fmaf(beta, pv[1], rr[k][1]));
+              gz[HB + l] = fmaf(beta, pv[2], rr[k][2]);
+            }
+          }
+          if (done) break;
+#pragma unroll
+          for (int q = 0; q < HPT; q++) {         // the neighbours' boundary rows: their residual from the received rows of A p, then their direction
+            const int j = tid + q * THREADS;
+            if (j < 2 * HB) {
+              const int li = j < HB ? j : R + j;
+              const float2 rxy = rhxy[j];
+              const float rx = fmaf(-alpha, hv[q].x, rxy.x), ry = fmaf(-alpha, hv[q].y, rxy.y), rzh = fmaf(-alpha, hv[q].z, rhz[j]);
+              rhxy[j] = make_float2(rx, ry); rhz[j] = rzh;
+              const float2 pxy = gxy[li];
+              gxy[li] = make_float2(fmaf(beta, pxy.x, rx), fmaf(beta, pxy.y, ry));
+              gz[li] = fmaf(beta, gz[li], rzh);
+            }
+          }
+          CPH(5)
+          __syncthreads();
+          CPH(6)
         }
       }
     } else
@@ -560,7 +589,7 @@ template <int VPT, bool DETECT, bool PIPE, bool DEFL = false>
 static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
   constexpr int THREADS = 512;
   const int GL = CL.R + 2 * CL.HB;
-  int floats = std::max((PIPE ? 6 : 3) * GL, CL.win_lds_bytes / 4);
+  int floats = std::max(3 * GL + (PIPE ? 6 * CL.HB : 0), CL.win_lds_bytes / 4);
   const int fric_floats = floats;      // LDS offered to the layered friction pass: the same with and without the inlined detection
   if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
   const int tail_off = (floats + 3) / 4 * 4;

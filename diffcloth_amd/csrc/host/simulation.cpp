@@ -1,6 +1,7 @@
 // Host-side `Simulation` (see simulation.h). Scene construction follows the reference's
 // Simulation::createSystem / createClothMeshFromConfig / createClothMeshFromModel / createAttachments / initScene
 // (reference Simulation.cpp:1804-2067, 2170-2405, 2611-2757); the per-step work is delegated to the dc_* C-ABI.
+#include <cstring>
 #include "simulation.h"
 #include <algorithm>
 #include <chrono>
@@ -409,8 +410,23 @@ void Simulation::configureDevice() {
     check(c, dc_build(c), "dc_build");
     check(c, dc_alloc_batch(c, 1, tapeSlots), "dc_alloc_batch");
   }
+  fieldSignature.clear();
   paramsFwdTol = prm.forward_tol; paramsBwdTol = prm.backward_tol; paramsClip = gradientClipping;
   paramsClipThr = gradientClippingThreshold; paramsDirect = false;
+}
+
+// The constant force field does not change between steps: it goes to the device when its values (or its switch) changed, not at every step.
+void Simulation::uploadForceField(dc_ctx *c, bool field) {
+  unsigned long long sig = 0;
+  if (field) {      // FNV-1a over the bit patterns (3N doubles: microseconds; an upload is a host-to-device copy + a stream synchronisation)
+    sig = 1469598103934665603ull;
+    for (double v : external_force_field) { unsigned long long b; std::memcpy(&b, &v, 8); sig = (sig ^ b) * 1099511628211ull; }
+    if (sig == 0) sig = 1;
+  }
+  auto it = fieldSignature.find(c);
+  if (it != fieldSignature.end() && it->second == sig) return;
+  check(c, dc_set_vertex_force_field(c, field ? external_force_field.data() : nullptr), "dc_set_vertex_force_field");
+  fieldSignature[c] = sig;
 }
 
 // New fabric parameters (stiffness per constraint type, density): constraint weights, lumped masses and the system matrix
@@ -432,6 +448,7 @@ void Simulation::rebuildSystem() {
     check(c, dc_set_params(c, &prm), "dc_set_params");
     check(c, dc_build(c), "dc_build");
   });
+  fieldSignature.clear();
   paramsFwdTol = prm.forward_tol; paramsBwdTol = prm.backward_tol; paramsClip = gradientClipping;
   paramsClipThr = gradientClippingThreshold; paramsDirect = backwardGradientForceDirectSolver;
 }
@@ -638,7 +655,7 @@ void Simulation::step() {
     for (size_t k = 0; k < fv.size(); k++) fv[k] = wind[k % 3] * windNorm * rec.windFactor * windFallOff[k];
     check(ctx, dc_set_vertex_forces(ctx, fv.data()), "dc_set_vertex_forces");
   } else check(ctx, dc_set_vertex_forces(ctx, nullptr), "dc_set_vertex_forces");
-  check(ctx, dc_set_vertex_force_field(ctx, field ? external_force_field.data() : nullptr), "dc_set_vertex_force_field");
+  uploadForceField(ctx, field);
   rec.x_fixedpoints = fixedPointTargets(rec.t);
   rec.simDurartionFraction = rec.t / (sceneConfig.timeStep * sceneConfig.stepNum);
   rec.splines = controlPointSplines;
@@ -863,7 +880,7 @@ bool Simulation::rolloutOnDevice(int nsteps) {
     for (size_t k = 0; k < n3; k++) fv[k] = wind[k % 3] * windNorm * windFallOff[k];
     check(ctx, dc_set_vertex_forces(ctx, fv.data()), "dc_set_vertex_forces");
   } else check(ctx, dc_set_vertex_forces(ctx, nullptr), "dc_set_vertex_forces");
-  check(ctx, dc_set_vertex_force_field(ctx, field ? external_force_field.data() : nullptr), "dc_set_vertex_force_field");
+  uploadForceField(ctx, field);
   check(ctx, dc_set_uniform_force(ctx, nullptr), "dc_set_uniform_force");
   check(ctx, dc_set_force_schedule(ctx, slot0, nsteps, (windEnabled && !fallOff) ? fu.data() : nullptr, fallOff ? fvs.data() : nullptr), "dc_set_force_schedule");
   if (Af > 0) check(ctx, dc_set_fixed_point_schedule(ctx, slot0, nsteps, xf.data()), "dc_set_fixed_point_schedule");

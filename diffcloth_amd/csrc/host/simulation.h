@@ -14,6 +14,7 @@
 //   getStateInfo/getPastStateInfo :966-989   same names
 #pragma once
 #include <array>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -316,6 +317,10 @@ class Simulation {
   int currentSysmatId = 0;
   void activateSet(int i);
   void selectSetForStep();              // Simulation::step, Simulation.cpp:1053-1068
+  // constant force field as last uploaded per context (signature of its values; 0 = none on the device): Simulation::step re-uploads it only
+  // when enableConstantForcefield / external_force_field changed (it was uploaded, with a stream synchronisation, at every step)
+  std::map<dc_ctx *, unsigned long long> fieldSignature;
+  void uploadForceField(dc_ctx *c, bool field);
   template <class F> void forEachContext(F f) {
     for (size_t i = 0; i < attachmentSets.size(); i++) f((int) i == currentSysmatId ? ctx : attachmentSets[i].ctx);
     if (attachmentSets.empty() && ctx) f(ctx);

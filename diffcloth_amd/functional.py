@@ -26,7 +26,8 @@ class BatchedSim:
     def __init__(self, engine, step_num, strict=False):
         """strict: an adjoint solve that did not converge raises at the end of the episode's backward sweep. Off by default: the reference
         does not stop on non-convergence (it prints and goes on, Simulation.cpp:1589-1600) and controller loops that tolerate an occasional
-        unconverged step keep running — they get ONE warning per episode instead. Hard errors (a timed-out exchange of the split kernels, a
+        unconverged step keep running — they get ONE warning per episode instead, with the number of unconverged (step, rollout) pairs and the worst residual
+        (also left in `self.unconverged`, so a training loop can act on it without parsing warnings). Hard errors (a timed-out exchange of the split kernels, a
         self-contact list overflow) always raise."""
         if engine.B <= 0:
             raise ValueError("the engine needs alloc_batch(B, tape) before it is wrapped (tape >= the steps of an episode)")
@@ -36,6 +37,7 @@ class BatchedSim:
         self._stream = None
         self._bwd_slots = set()
         self.strict = bool(strict)
+        self.unconverged = 0
 
     def on_current_stream(self, device=None):
         """order the engine's work with torch's current CUDA stream of the tensors' device (once per stream change). torch's default
@@ -55,17 +57,24 @@ class BatchedSim:
         import warnings
         e = self.engine
         e.sync()                                     # raises on a timed-out exchange
-        warned = False
+        bad_pairs, worst, first = 0, 0.0, None
         for slot in range(1, self.step_idx + 1):
             fwd, bwd = e.get_stats(slot)             # raises DC_ERR_CAPACITY on a self-contact overflow of that step
-            if slot in self._bwd_slots and (bwd["converged"] == 0).any() and not warned:
-                bad = int(np.nonzero(bwd["converged"] == 0)[0][0])
-                msg = (f"BatchedSim: the adjoint solve of step {slot}, rollout {bad} did not converge "
-                       f"(relative residual {float(bwd['last_udiff'][bad]):.2e})")
-                if self.strict:
-                    raise RuntimeError(msg)
-                warnings.warn(msg, RuntimeWarning, stacklevel=2)
-                warned = True
+            if slot in self._bwd_slots and (bwd["converged"] == 0).any():
+                bad = np.nonzero(bwd["converged"] == 0)[0]
+                bad_pairs += len(bad)
+                w = int(bad[np.argmax(bwd["last_udiff"][bad])])
+                if first is None:
+                    first = (slot, int(bad[0]))
+                if float(bwd["last_udiff"][w]) >= worst:
+                    worst, worst_at = float(bwd["last_udiff"][w]), (slot, w)
+        self.unconverged = bad_pairs                 # (step, rollout) pairs of the episode whose adjoint solve did not converge
+        if bad_pairs:
+            msg = (f"BatchedSim: {bad_pairs} adjoint solve(s) of this episode did not converge (first: step {first[0]}, rollout {first[1]}; "
+                   f"worst relative residual {worst:.2e} at step {worst_at[0]}, rollout {worst_at[1]}): the gradients of those rollouts are not converged")
+            if self.strict:
+                raise RuntimeError(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
 
     def reset(self, x0, v0=None):
         """Start a new episode from the given states ([B, 3N]); returns them as float32 tensors like getStateInfo()."""

@@ -131,6 +131,9 @@ typedef struct dc_bwd_stats {
   int refine_cycles;     /* direct solve, mixed precision: fp32 solves run (each followed by an fp64 residual evaluation)    */
   int fp64_iters;        /* BiCGSTAB iterations of the fp64 fall-back (0: the fp32 corrections were enough)                 */
   int residual_verified; /* direct solve, mixed precision: 1 = last_udiff is an fp64-evaluated residual, 0 = the bound described there */
+  int workgroups;        /* workgroups that ran this rollout's backward step. Smaller than dc_get_cluster's K when the split adjoint kernel
+                            does not implement the configuration — adjoint_mode 0 (the reference's fixed-point iteration, Simulation.cpp:
+                            1569-1600) runs on ONE workgroup per rollout although the forward steps are split — reported, not silent   */
 } dc_bwd_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

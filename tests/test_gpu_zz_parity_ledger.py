@@ -31,7 +31,8 @@ def test_parity_ledger_rules():
         if e["e2e_err"] is None:
             continue
         if e["gate"] is not None:
-            assert e["e2e_err"] <= e["gate"] and e["gate"] <= 8e-3, e
+            assert e["e2e_err"] <= e["gate"], e
+            assert e["gate"] <= 8e-3 or (e["note"] or "").startswith("listed ill-conditioned sample"), e
         if e["scene"] in STRICT_SCENES and e["sensitivity"] is not None:
             bound = max(1e-4, SLACK * e["sensitivity"])
             rows.append((e["scene"], e["rollout"], e["e2e_err"], e["sensitivity"], e["e2e_err"] / max(e["sensitivity"], 1e-30)))

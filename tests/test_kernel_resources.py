@@ -1,6 +1,6 @@
 """Register / scratch budget of the kernel instances the headline and the BASELINE configurations launch, read from the gfx950 code
 objects in diffcloth_amd/lib/obj (tools/kernel_resources.py: clang offload bundle -> ELF -> AMDGPU metadata note). No GPU needed: hipcc
-cross-compiles. The budgets are the values of round 5 plus a margin — a change that pushes a hot kernel's private segment or spill count
+cross-compiles. The budgets are the values of round 6 (profiles/r06_kernel_resources.txt) plus a margin — a change that pushes a hot kernel's private segment or spill count
 past them has to say so here ("gate it by code-object metadata, not by belief")."""
 import os
 import sys
@@ -16,12 +16,12 @@ BUDGET = {
     "dc::k_pd_step_pk<512, 20, 12, true, false, true, false>": (448, 128, 256, 512),
     # round 4: 484 B / 145
     "dc::k_adjoint_step<1024, true, false, false, false>": (512, 160, 128, 1024),      # (149 with the contact vertices' y list in LDS)
-    # round 4: 416 B / 114 (the fenced gathers of round 5 cost 48 B and pay in time)
-    "dc::k_pd_step_cl<512, 3, true, false, false>": (512, 140, 256, 512),
-    # round 4: 1144 B / 876 — the open item
-    "dc::k_adjoint_step_cl<1024, false, false>": (1152, 880, 128, 1024),
+    # round 4: 416 B / 114 (the fenced gathers of round 5 cost 48 B and pay in time); round 6: the single-exchange CG instance (PIPE = true) is the one launched
+    "dc::k_pd_step_cl<512, 3, true, true, false>": (544, 150, 256, 512),
+    # rounds 4-5: 1024 threads x 128 registers, 1144 B / 855-876 spilled — the open item of two verdicts; round 6: 512 threads x 256 registers, 556 B / 241
+    "dc::k_adjoint_step_cl<512, false, false>": (600, 260, 256, 512),
     "dc::k_adjoint_step<1024, true, false, true, false>": (384, 130, 128, 1024),
-    "dc::k_adjoint_step_cl<1024, true, false>": (1088, 860, 128, 1024),
+    "dc::k_adjoint_step_cl<512, true, false>": (560, 215, 256, 512),
 }
 
 

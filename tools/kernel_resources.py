@@ -30,10 +30,10 @@ FIELDS = ("vgpr_count", "agpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_sp
 HOT = {
     "bench forward 256x1": "dc::k_pd_step_pk<512, 20, 12, true, false, true, false>",
     "bench adjoint 256x1": "dc::k_adjoint_step<1024, true, false, false, false>",
-    "bench forward 32x8": "dc::k_pd_step_cl<512, 3, true, false, false>",
-    "bench adjoint 32x8": "dc::k_adjoint_step_cl<1024, false, false>",
+    "bench forward 32x8": "dc::k_pd_step_cl<512, 3, true, true, false>",      # (PIPE = true: the single-exchange CG, round 6)
+    "bench adjoint 32x8": "dc::k_adjoint_step_cl<512, false, false>",
     "garments adjoint (block preconditioner)": "dc::k_adjoint_step<1024, true, false, true, false>",
-    "garments adjoint 32x8 (block preconditioner)": "dc::k_adjoint_step_cl<1024, true, false>",
+    "garments adjoint 32x8 (block preconditioner)": "dc::k_adjoint_step_cl<512, true, false>",
 }
 
 
