@@ -597,7 +597,13 @@ __device__ DC_OUTLINED Ret32 cg32_solve(const DevSystem &S, AdjCtx C, Krylov32 V
   double best_rr = rr;
   int since_progress = 0, its = 0;
   int in_status = (rr <= in_stop) ? 1 : 0;
-  for (int k = 2 * kdone; k < 2 * kcap && in_status == 0; k++) {
+  // CG on a slightly non-symmetric K either converges like on its symmetric part or stagnates (measured r06 on the bench workload: median 65
+  // applications per step against BiCGSTAB's 76, but 1 % of the steps beyond 478 and up to the cap of 3 200 — a launch waits for its slowest
+  // rollout: 80 ms per batch step instead of 12). Hence a short leash: no new minimum of |r| for kCgStall iterations, or kCgCycleCap iterations in one
+  // solve, ends the solve unconverged (status 0) and the caller hands the rest of the step to BiCGSTAB; the correction reached so far is kept
+  // if the fp64 residual says it helped.
+  constexpr int kCgStall = 10, kCgCycleCap = 64;
+  for (int k = 2 * kdone; k < 2 * kcap && in_status == 0 && its < kCgCycleCap; k++) {
     // v = K p ;  alpha = (r . z) / (p . v)
     adjoint_operator<THREADS, WIN, true>(S, C, p, false, v, p, d1, d2);
     const double pv = krylov_sum<THREADS>(d1, redc);
@@ -625,7 +631,7 @@ __device__ DC_OUTLINED Ret32 cg32_solve(const DevSystem &S, AdjCtx C, Krylov32 V
     its++;
     if (rr <= in_stop) { in_status = 1; break; }
     if (rr < best_rr) { best_rr = rr; since_progress = 0; }
-    else if (++since_progress >= stall_window) { in_status = 2; break; }      // (stall_window is INT_MAX unless the caller set one: |r| of CG is not monotone)
+    else if (++since_progress >= min(stall_window, kCgStall)) { in_status = 2; break; }      // (|r| of CG is not monotone: a few iterations without a new minimum are normal)
     if (!(rr < 1e8 * best_rr)) { in_status = 2; break; }      // diverging (NaN-safe)
     const float beta = (float) (rz_new / rz);
     rz = rz_new;

@@ -12,16 +12,10 @@
 
 namespace dc {
 
-// Single-reduction CG iteration of the one-workgroup kernel (see the loop): measured r06 on the headline instance (H16, 20 rows per thread)
-// and NOT kept there — forward 15.5 -> 16.1 ms per batch step: the kernel is VALU-bound (0.54 busy), the three extra dot products per row and
-// the two extra wave reductions cost more issue slots than the saved barrier gives back (the waves of a workgroup arrive within a few hundred
-// cycles of each other). The split kernels, whose "reduction" is an inter-workgroup exchange of ~2.5 k cycles, do use it (dc_forward_cl_kernel.h).
-// -DDC_PK_SXCG=1 builds it in for A/B runs.
-#ifndef DC_PK_SXCG
-#define DC_PK_SXCG 0
-#endif
-constexpr bool kPkSingleReduction = DC_PK_SXCG != 0;
-
+// (Round 6, measured and not kept here: the single-reduction CG iteration the split kernels use — r.Ad, Ad.Ad and the true r.r formed in the product
+// pass, |r'|^2 = r.r - 2 alpha r.Ad + alpha^2 Ad.Ad, one barrier less per iteration. This kernel is VALU-bound (0.54 busy): the three extra dot
+// products per row and two more wave reductions cost more issue slots than the barrier gives back — headline forward 15.5 -> 16.1 ms, sock
+// 24.9 -> 25.8 ms, dress 35.0 -> 35.8 ms per batch step. docs/HISTORY.md "Round 6".)
 #ifdef DC_PROFILE_PHASES
 #define PH_DECL long long ph_t = clock64(); long long ph_acc[6] = {0, 0, 0, 0, 0, 0}; if (blockIdx.x == 0 && threadIdx.x == 0) { g_win_ph[0] = g_win_ph[1] = g_win_ph[2] = g_win_ph[3] = 0; }
 #define PH(k) { long long n_ = clock64(); ph_acc[k] += n_ - ph_t; ph_t = n_; }
@@ -55,7 +49,6 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
   float *ldense = lp + 3 * THREADS * (VPT + XL);      // DENSE: partial sums of the product with the explicit inverse
   __shared__ double red[THREADS / 64];
   __shared__ double red2[H16 ? 2 * (THREADS / 64) : 1];
-  __shared__ float red5[(!DEFL && !DENSE && kPkSingleReduction) ? 5 * (THREADS / 64) : 1];      // single-barrier CG iteration: five wave sums per wave
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = S.N, T = S.T, E = S.E, NC = S.NC;
@@ -529,74 +522,6 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_pk(const DevSystem *__restr
           else { ((float2 *) lp)[i] = make_float2(d0, d1); lp[2 * NP + i] = d2; }
         }
       }
-      if constexpr (!DEFL && kPkSingleReduction) {
-      // One reduction per CG iteration (round 6): the product pass also forms r.Ad, Ad.Ad and the true r.r of the CURRENT residual; with
-      // alpha = d.r / d.Ad the next residual's norm is |r'|^2 = r.r - 2 alpha r.Ad + alpha^2 Ad.Ad — one step from a TRUE r.r, so the
-      // rounding of the sums (~1e-6 relative) never accumulates — and the updates of x, r and of the direction run as ONE row loop behind
-      // the one barrier: 2 barriers and 1 reduction per iteration (H16 before: 3 and 2; the fp32-plane instances: 5 and 2 ... 3), and the
-      // direction's own entry is read once. (The deflated instances keep the loop below: their projection sits between the updates.)
-      for (int it = 0; it < A.cg_max;) {
-        __syncthreads();
-        float sv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // d.Ad, d.r, r.Ad, Ad.Ad, r.r
-        int zs;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
-        const int wz = wv + zs, tz = tid + zs;
-        spmv(wz, sv[0], H16 || seed, sv[1]);
-#pragma unroll
-        for (int k = 0; k < VPT; k++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) { sv[2] = fmaf(rr[k][c], ap[k][c], sv[2]); sv[3] = fmaf(ap[k][c], ap[k][c], sv[3]); sv[4] = fmaf(rr[k][c], rr[k][c], sv[4]); }
-        PH(2)
-        double s5[5];
-        block_sum5_f_nb<THREADS>(sv, red5, s5);
-        PH(3)
-        // H16: exact line search along the ROUNDED direction, d.r from the product pass; fp32 planes: d.r = r.r except along the recycled direction
-        const double dr = (H16 || seed) ? s5[1] : s5[4];
-        const double alpha_d = s5[0] > 1e-300 ? dr / s5[0] : 0.0;
-        const float alpha = (float) alpha_d;
-        const double rz_new = s5[4] - 2.0 * alpha_d * s5[2] + alpha_d * alpha_d * s5[3];
-        it++; cg_total++;
-        const bool done = !(rz_new > stop);
-        const float beta = (seed || done) ? 0.f : (float) (rz_new / s5[4]);
-        seed = false;
-        if constexpr (H16) {
-        // d_new = r + beta d_old in true units; in LDS units: hs_new r + (beta hs_new / hs_old) d~_old, entries bounded by |r|_2 + beta * bound_old
-        pn = sqrtf((float) fmax(rz_new, 0.0)) + beta * pn;
-        const float hs_new = half_scale(pn), c2 = beta * hs_new / hs;
-        hs = hs_new;
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int i = tz + k * THREADS;
-          const h4 q = lh[i];
-          const float pv[3] = {(float) q.x, (float) q.y, (float) q.z};
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            if (k < XR) xx[k < XR ? k : 0][c] = fmaf(alpha, pv[c], xx[k < XR ? k : 0][c]);
-            else lx[((k - XR) * 3 + c) * THREADS + tz] = fmaf(alpha, pv[c], lx[((k - XR) * 3 + c) * THREADS + tz]);
-            rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
-          }
-          lh[i] = pack_h4(fmaf(c2, pv[0], rr[k][0] * hs), fmaf(c2, pv[1], rr[k][1] * hs), fmaf(c2, pv[2], rr[k][2] * hs));
-        }
-        } else {
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-          const int i = tz + k * THREADS;
-          const float2 pxy = ((const float2 *) lp)[i];
-          const float pv[3] = {pxy.x, pxy.y, lp[2 * NP + i]};
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            if (k < XR) xx[k < XR ? k : 0][c] = fmaf(alpha, pv[c], xx[k < XR ? k : 0][c]);
-            else lx[((k - XR) * 3 + c) * THREADS + tz] = fmaf(alpha, pv[c], lx[((k - XR) * 3 + c) * THREADS + tz]);
-            rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
-          }
-          ((float2 *) lp)[i] = make_float2(fmaf(beta, pv[0], rr[k][0]), fmaf(beta, pv[1], rr[k][1]));
-          lp[2 * NP + i] = fmaf(beta, pv[2], rr[k][2]);
-        }
-        }
-        PH(4)
-        if (done) break;
-      }
-      } else
       for (int it = 0; it < A.cg_max;) {
         __syncthreads();
         float part2 = 0.f, part3 = 0.f;

@@ -213,29 +213,6 @@ __device__ __forceinline__ void block_sum2_f_nb(float &a, float &b, double *red,
   for (int k = 0; k < NW; k++) { sa += red[k]; sb += red[NW + k]; }
 }
 
-// five block sums behind ONE barrier (the single-reduction CG iteration of dc_forward_pk_kernel.h): fp32 inside a wave (DPP), the wave sums
-// as floats in LDS, fp64 across the waves. `redf` [5][THREADS / 64] is written once per iteration; its previous reads lie before the barrier
-// that opens the iteration, so one buffer suffices.
-template <int THREADS>
-__device__ __forceinline__ void block_sum5_f_nb(float (&v)[5], float *redf, double (&s)[5]) {
-  constexpr int NW = THREADS / 64;
-#pragma unroll
-  for (int k = 0; k < 5; k++) v[k] = wave_sum_f(v[k]);
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  if (l == 0) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) redf[k * NW + w] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 5; k++) {
-    double t = 0;
-#pragma unroll
-    for (int j = 0; j < NW; j++) t += (double) redf[k * NW + j];
-    s[k] = t;
-  }
-}
-
 template <int NP>
 __device__ __forceinline__ void consume(const int4 (&e)[PB], const float *lp, int base, float &ax, float &ay, float &az) {
   consume_p(e, (const float2 *) lp, lp + 2 * NP, base, ax, ay, az);
