@@ -251,7 +251,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   int clipped = 0;
   if (A.clip && gnorm > (double) A.clip_thr * N) { gscale = (float) ((double) A.clip_thr * N / gnorm); clipped = 1; gnorm = (double) A.clip_thr * N; }
   int status = gnorm > 0 ? 0 : 1;          // 1 converged (a zero gradient has the solution u = 0), 2 stalled at the fp32 floor / breakdown, 0 cap hit
-  int iters = 0;
+  int iters = 0, cg_total = 0;
   double udiff = 0;
   for (int i = r0 + tid; i < r1; i += THREADS) { st3(gin, i, N, ld3(gx, i, N) * gscale); st3(u, i, N, mk(0, 0, 0)); }
   // fp64 side (dc_adjoint64.h): true residual of the mixed-precision refinement, fall-back solve, gradient assembly — the same
@@ -285,10 +285,97 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     bool fallback = false;
     double rr = rr_true;
     double op_err = 0;         // measured error of the fp32 operator (see below)
+    bool use_cg = !BLK && !COARSE && A.cg_first != 0;      // correction solves by CG first, BiCGSTAB once a CG cycle has not delivered (dc_adjoint.hip: cg32_solve)
     status = (rr_true <= stop) ? 1 : 0;
     for (int kdone = 0; status == 0 && !fallback; cycles++) {
     const double rel_now = sqrt(rr_true) / gnorm;
     const double in_tol = A.fp32_only ? (double) A.rel_tol : fmax(0.3 * (double) A.rel_tol / rel_now, kInnerFloor);
+    const bool cg_cycle = use_cg;
+    int in_status = 0;
+    if (cg_cycle) {
+      // ---- preconditioned CG (diag(P)^-1) on K d = rhs, on a short leash (dc_adjoint.hip: cg32_solve): one operator application and three
+      //      exchanges per iteration (p.Kp; r.D^-1 r and r.r; the boundary rows of the new p) where BiCGSTAB takes two and five ----
+      constexpr int kCgStall = 10, kCgCycleCap = 64;
+      xch_begin(X);
+      part_s = 0.f;
+      float part_z = 0.f;
+      for (int l = tid; l < R; l += THREADS) {
+        const int i = r0 + l;
+        f3 z = mk(0, 0, 0);
+        if (i < N) {
+          const f3 q = ld3(gin, i, N);
+          z = q * S.dinv[i];
+          st3(r, i, N, q); st3(p, i, N, z); st3(u, i, N, mk(0, 0, 0));
+          part_s += dot(q, q); part_z += dot(q, z);
+        }
+        xch_publish_boundary(X, l, R, z.x, z.y, z.z);      // the operator's input: p = D^-1 r
+      }
+      xch_publish_sums(X, part_s, part_z, 0.f);
+      if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+      halo_to_cache<THREADS, HPT>(C, hv);
+      __syncthreads();
+      rr = sums[0];
+      double rz = sums[1];
+      const double in_stop = in_tol * in_tol * rr;
+      double best_rr = rr;
+      int since_progress = 0, its = 0;
+      in_status = (rr <= in_stop || !(rr > 0)) ? 1 : 0;
+      for (int k = 2 * kdone; k < 2 * kcap && in_status == 0 && its < kCgCycleCap; k++) {
+        float d1, d2;
+        if (!adjoint_operator_cl<THREADS>(S, CL, C, X, p, false, v, p, d1, d2)) return;
+        if (!xch_allsum<THREADS>(X, d1, 0.f, 0.f, sums)) return;
+        const double pv = sums[0];
+        if (!(pv > 1e-300)) { in_status = 2; break; }
+        const float alpha = (float) (rz / pv);
+        float pa = 0.f, pb = 0.f;
+        for (int l0 = tid; l0 < R; l0 += VB * THREADS) {
+          f3 rq[VB], vq[VB], pq[VB], uq[VB];
+          float dq[VB];
+#pragma unroll
+          for (int j = 0; j < VB; j++) {
+            const int ic = min(r0 + l0 + j * THREADS, r1 - 1);
+            rq[j] = ld3(r, ic, N); vq[j] = ld3(v, ic, N); pq[j] = ld3(p, ic, N); uq[j] = ld3(u, ic, N); dq[j] = S.dinv[ic];
+          }
+#pragma unroll
+          for (int j = 0; j < VB; j++) {
+            const int i = r0 + l0 + j * THREADS;
+            const f3 rn = rq[j] - vq[j] * alpha;
+            if (i < r1) { st3(r, i, N, rn); st3(u, i, N, uq[j] + pq[j] * alpha); pa += dot(rn, rn) * dq[j]; pb += dot(rn, rn); }
+          }
+        }
+        if (!xch_allsum<THREADS>(X, pa, pb, 0.f, sums)) return;
+        const double rz_new = sums[0];
+        rr = sums[1];
+        its++;
+        if (rr <= in_stop) { in_status = 1; break; }
+        if (rr < best_rr) { best_rr = rr; since_progress = 0; }
+        else if (++since_progress >= min(A.stall_window, kCgStall)) { in_status = 2; break; }
+        if (!(rr < 1e8 * best_rr)) { in_status = 2; break; }
+        const float beta = (float) (rz_new / rz);
+        rz = rz_new;
+        xch_begin(X);
+        for (int l0 = tid; l0 < R; l0 += VB * THREADS) {
+          f3 rq[VB], pq[VB];
+          float dq[VB];
+#pragma unroll
+          for (int j = 0; j < VB; j++) { const int ic = min(r0 + l0 + j * THREADS, r1 - 1); rq[j] = ld3(r, ic, N); pq[j] = ld3(p, ic, N); dq[j] = S.dinv[ic]; }
+#pragma unroll
+          for (int j = 0; j < VB; j++) {
+            const int l = l0 + j * THREADS, i = r0 + l;
+            f3 pn = rq[j] * dq[j] + pq[j] * beta;
+            if (i >= r1) pn = mk(0, 0, 0);
+            if (i < r1) st3(p, i, N, pn);
+            if (l < R) xch_publish_boundary(X, l, R, pn.x, pn.y, pn.z);
+          }
+        }
+        xch_publish_sums(X, 0.f, 0.f, 0.f);
+        if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+        halo_to_cache<THREADS, HPT>(C, hv);
+        __syncthreads();
+      }
+      cg_total += its;
+      kdone += (its + 1) / 2;
+    } else {
     // r = rhat = p = rhs (gin: g, later the fp64 residual rounded to fp32), d = 0; the operator's input travels to the neighbours
     xch_begin(X);
     part_s = 0.f;
@@ -312,7 +399,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     const double in_stop = in_tol * in_tol * rho;
     double best_rr = rr;
     int since_progress = 0;
-    int in_status = (rr <= in_stop || !(rr > 0)) ? 1 : 0;
+    in_status = (rr <= in_stop || !(rr > 0)) ? 1 : 0;
     for (int k = kdone; k < kcap && in_status == 0; k++, kdone++) {
       float d1, d2;
       // v = K M^-1 p ;  alpha = rho / (rhat . v)
@@ -407,6 +494,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       halo_to_cache<THREADS, HPT>(C, hv);
       __syncthreads();
     }
+    }      // (BiCGSTAB cycle)
     __syncthreads();
     // u += d (fp64)
     for (int i = r0 + tid; i < r1; i += THREADS) st3d(W64.u, i, N, ld3d(W64.u, i, N) + tod(ld3(u, i, N)));
@@ -446,7 +534,10 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       if (rs.res < 0) return;
       rr_new = rs.rr;
     }
-    if (!(rr_new < 0.0625 * rr_true) || in_status != 1 || cycles + 1 >= kMaxRefine || kdone >= kcap) fallback = true;
+    if (!(rr_new < 0.0625 * rr_true) || in_status != 1 || cycles + 1 >= kMaxRefine || kdone >= kcap) {
+      if (cg_cycle && cycles + 1 < kMaxRefine && kdone < kcap) use_cg = false;      // a CG cycle that did not deliver: BiCGSTAB for the rest of the step
+      else fallback = true;
+    }
     rr_true = rr_new;
     if (!fallback) {
       for (int i = r0 + tid; i < r1; i += THREADS) st3(gin, i, N, tof(ld3d(W64.r, i, N)));
@@ -492,7 +583,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
   CAPH_PRINT
   if (tid == 0 && part == 0) {
     dc_bwd_stats s;
-    s.converged = status; s.adjoint_iters = iters; s.cg_iters = 0; s.clipped = clipped;
+    s.converged = status; s.adjoint_iters = iters; s.cg_iters = cg_total; s.clipped = clipped;
     s.used_direct = 1; s.last_udiff = (float) udiff;
     s.refine_cycles = cycles; s.fp64_iters = iters64; s.residual_verified = A.fp32_only ? 0 : verified;
     s.workgroups = K;

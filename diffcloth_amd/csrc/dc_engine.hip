@@ -420,7 +420,9 @@ int choose_cluster(dc_ctx *c) {
   // Fewer rollouts than CUs: as many parts as fit (B K <= CUs), up to 8 — a rollout's speed-up grows with K (measured on C4: 1.3 /
   // 1.9 / 3.0 x at K = 2 / 4 / 8). A mesh too large for one workgroup needs kmin parts; when that oversubscribes the device the
   // batch runs in several launches and K is the one that wastes the least: score = fraction of the CUs busy x per-CU efficiency.
-  static const double eff[9] = {0, 1.0, 0.65, 0.55, 0.48, 0.44, 0.42, 0.40, 0.38};
+  // per-CU efficiency of K parts against one workgroup per rollout, re-measured in round 6 on the C4 workload (bench.py --total-batch 128 / 64 / 32
+  // against 256: 6 032 / 5 031 / 4 003 against 9 880 rollout-steps/s -> 0.61 / 0.51 / 0.405 at K = 2 / 4 / 8; K = 3, 5, 6, 7 interpolated)
+  static const double eff[9] = {0, 1.0, 0.61, 0.56, 0.51, 0.48, 0.45, 0.43, 0.405};
   const int kmin = (!c->S.pk_ok || !c->S.win_ok) ? std::max(2, std::min(8, (c->host.N + 6143) / 6144)) : 1;
   int K = 1;
   if (forced >= 2) K = std::min(forced, 8);

@@ -42,8 +42,14 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   if (!xch_hello<THREADS>(X)) return;
   float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
   float *gz = lds + 2 * GL;
-  float2 *gxy1 = (float2 *) (lds + 3 * GL);   // PIPE: the neighbours' residual rows [2 HB] (float2 plane, then the z plane)
-  float *gz1 = lds + 3 * GL + 4 * HB;
+  // PIPE instances keep the direction as four halves per row (H16, dc_pklib.h: one ds_read_b64 and three v_fma_mix per non-zero, as the
+  // 10 000-vertex one-workgroup kernel does) scaled by a power of two per iteration: 2 GL floats; behind it the neighbours' residual rows
+  // [2 HB] in fp32 (float2 plane, then the z plane)
+  constexpr bool H16 = PIPE;
+  h4 *lh = (h4 *) lds;
+  const unsigned lh_addr = lds_byte_address(lds);
+  float2 *gxy1 = (float2 *) (lds + (H16 ? 2 : 3) * GL);
+  float *gz1 = lds + (H16 ? 2 : 3) * GL + 4 * HB;
   const int N = S.N;
   const int r0 = part * R, r1 = min(N, r0 + R);
   const int nch = R >> 6, cbase = r0 >> 6;
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   bool improved = false, converged = false, stalled = false, best_is_current = false;
   int iters = 0, cg_total = 0, since_progress = 0;
   double xdiff = 0;
+  float dnorm = 0.f;                        // H16: |d_prev|_2 over the rollout, the scaled correction of the previous PD iteration (scale of the recycled direction)
 
   CPH_DECL
   for (int iter = 0; iter < A.pd_cap; iter++) {
@@ -185,21 +192,40 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
 #pragma unroll
       for (int c = 0; c < 3; c++) xx[k][c] = 0.f;
       if (l < R) {
-        gxy[HB + l] = make_float2(rr[k][0], rr[k][1]); gz[HB + l] = rr[k][2];
+        if constexpr (!H16) { gxy[HB + l] = make_float2(rr[k][0], rr[k][1]); gz[HB + l] = rr[k][2]; }
         xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
       }
     }
     double rz;
+    float hs = 1.f, pn = 0.f;               // H16: scale of the direction in LDS (a power of two) and the bound on its entries it comes from
     {
       xch_publish_sums(X, psum, 0.f, 0.f);
       f3 hv[HPT];
       if (!xch_finish<THREADS, HPT, true>(X, sums, hv)) return;
+      rz = sums[0];
+      if constexpr (H16) {                  // first direction d = r (|r|_inf <= |r|_2 = sqrt(rz)), rounded to halves; the neighbours' rows of r kept in fp32
+        pn = sqrtf((float) rz); hs = half_scale(pn);
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+          const int l = tq + k * THREADS;
+          if (l < R) lh[HB + l] = pack_h4(rr[k][0] * hs, rr[k][1] * hs, rr[k][2] * hs);
+        }
+#pragma unroll
+        for (int q = 0; q < HPT; q++) {
+          const int j = tid + q * THREADS;
+          if (j < 2 * HB) {
+            const int li = j < HB ? j : R + j;
+            lh[li] = pack_h4(hv[q].x * hs, hv[q].y * hs, hv[q].z * hs);
+            gxy1[j] = make_float2(hv[q].x, hv[q].y); gz1[j] = hv[q].z;
+          }
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < HPT; q++) {
         const int j = tid + q * THREADS;
         if (j < 2 * HB) { const int li = j < HB ? j : R + j; gxy[li] = make_float2(hv[q].x, hv[q].y); gz[li] = hv[q].z; }
       }
-      rz = sums[0];
+      }
     }
     // With few rows per thread the first packet batch of every row (16 registers per row) stays in registers for the whole solve:
     // the matrix is the same in all ~25 iterations, and a part that is only a few rows deep cannot hide the L2 latency of
@@ -234,6 +260,20 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           if (k + 1 < VPT) load_batch(nxt, CL.pk + CL.pk_ptr[cbase + min(lc + WAVES, nch - 1)] + lane, 0);
         }
         const int li = HB + lc * 64 + lane;
+        if constexpr (H16) {
+          unsigned rowbase = lh_addr + 8u * (unsigned) (li - 512);
+          asm volatile("" : "+v"(rowbase));      // opaque: one register per row (dc_forward_pk_kernel.h)
+          float ax, ay, az;
+          pk_v2i own;
+          consume_h_row(cur, rowbase, ax, ay, az, own);      // gathers + own entry in one group, own entry enters last (dc_pklib.h)
+          for (int s0 = PB; s0 < np; s0 += PB) {        // rows wider than one batch
+            load_batch(cur, row, s0);
+            consume_h(cur, rowbase, ax, ay, az);
+          }
+          ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
+          dot3_h(ax, ay, az, own, part2);
+          dot3_h(rr[k][0], rr[k][1], rr[k][2], own, part3);      // d.r along the ROUNDED direction: the exact line search needs it in every iteration
+        } else {
         const float2 pxy = vxy[li];
         const float pz = vz[li];
         float ax = pxy.x, ay = pxy.y, az = pz;        // unit diagonal
@@ -246,6 +286,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         ap[k][0] = ax; ap[k][1] = ay; ap[k][2] = az;
         part2 += pxy.x * ax + pxy.y * ay + pz * az;
         if (with_pr) part3 += pxy.x * rr[k][0] + pxy.y * rr[k][1] + pz * rr[k][2];     // seeded pass only (uniform branch)
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -263,12 +304,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       // with the received rows (bitwise the neighbour's own update), p_halo = r_halo + beta p_halo. The neighbours' residual rows live in a
       // second small LDS array (rh). What the pipelined CG of round 4 lost (its recurrences for A r, A p, A s drift in fp32: 7e-5 at
       // N = 16 384) cannot happen here: the only recurred quantity is the scalar |r'|^2, re-based on the true value every iteration.
-      float2 *rhxy = gxy1;                       // [2 HB] residual rows of the neighbours (same indexing as the halo rows of gxy: j < HB lower, HB + j upper)
+      float2 *rhxy = gxy1;                       // [2 HB] residual rows of the neighbours (same indexing as the halo rows of the direction: j < HB lower, HB + j upper)
       float *rhz = gz1;
       float *lsum6 = X.lsum + 16;
       if (rz > 1e-300) {
         const double stop = (double) A.cg_tol * (double) A.cg_tol * rz;
-        {   // the neighbours' rows of r0 = rhs arrived with the exchange above and sit in the halo rows of the direction: keep a copy as r_halo
+        // (the neighbours' rows of r0 = rhs arrived with the exchange above: they are in rh already — H16 — or copied from the direction's halo rows now)
+        if constexpr (!H16) {
 #pragma unroll
           for (int q = 0; q < HPT; q++) {
             const int j = tid + q * THREADS;
@@ -277,13 +319,15 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         }
         bool seed = A.cg_seed && iter > 0;
         if (seed) {
-          __syncthreads();                                  // (the copy above reads halo rows other threads overwrite here)
+          __syncthreads();                                  // (the direction's rows are rewritten by other threads than the ones that wrote / copied them)
+          if constexpr (H16) hs = half_scale(dnorm);        // |d_prev|_2 of the rollout, from the exchange that ended the previous PD iteration
           for (int j = tid; j < R + 2 * HB; j += THREADS) {
             const int i = r0 - HB + j;                      // gather index j <-> global row i
             const bool on = i >= 0 && i < N && (j < HB || j >= HB + R || i < r1);
             f3 d = mk(0, 0, 0);
             if (on) d = ld3c(dpb, i);
-            gxy[j] = make_float2(d.x, d.y); gz[j] = d.z;
+            if constexpr (H16) lh[j] = pack_h4(d.x * hs, d.y * hs, d.z * hs);
+            else { gxy[j] = make_float2(d.x, d.y); gz[j] = d.z; }
           }
           __syncthreads();
         }
@@ -312,7 +356,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           if (!xch_finish6<THREADS, HPT, true>(X, lsum6, s6, hv)) return;
           CPH(4)
           const double rrt = s6[4];
-          const double pr = seed ? s6[1] : rrt;
+          const double pr = (H16 || seed) ? s6[1] : rrt;      // H16: exact line search along the rounded direction
           const double alpha_d = s6[0] > 1e-300 ? pr / s6[0] : 0.0;
           const float alpha = (float) alpha_d;
           const double rz_new = rrt - 2.0 * alpha_d * s6[2] + alpha_d * alpha_d * s6[3];
@@ -320,6 +364,38 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
           const bool done = !(rz_new > stop);
           const float beta = (seed || done) ? 0.f : (float) (rz_new / rrt);
           seed = false;
+          if constexpr (H16) {
+            // d_new = r + beta d_old in true units; in LDS units: hs_new r + (beta hs_new / hs_old) d~_old, entries bounded by |r|_2 + beta * bound_old
+            pn = sqrtf((float) fmax(rz_new, 0.0)) + beta * pn;
+            const float hs_new = half_scale(pn), c2 = beta * hs_new / hs;
+            hs = hs_new;
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+              const int l = tz + k * THREADS;
+              const int lc = min(l, R - 1);
+              const h4 q = lh[HB + lc];
+              const float pv[3] = {(float) q.x, (float) q.y, (float) q.z};
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                xx[k][c] = fmaf(alpha, pv[c], xx[k][c]);
+                rr[k][c] = fmaf(-alpha, ap[k][c], rr[k][c]);
+              }
+              if (l < R) lh[HB + l] = pack_h4(fmaf(c2, pv[0], rr[k][0] * hs), fmaf(c2, pv[1], rr[k][1] * hs), fmaf(c2, pv[2], rr[k][2] * hs));
+            }
+            if (done) break;
+#pragma unroll
+            for (int q = 0; q < HPT; q++) {         // the neighbours' boundary rows: their residual from the received rows of A d, then their direction
+              const int j = tid + q * THREADS;
+              if (j < 2 * HB) {
+                const int li = j < HB ? j : R + j;
+                const float2 rxy = rhxy[j];
+                const float rx = fmaf(-alpha, hv[q].x, rxy.x), ry = fmaf(-alpha, hv[q].y, rxy.y), rzh = fmaf(-alpha, hv[q].z, rhz[j]);
+                rhxy[j] = make_float2(rx, ry); rhz[j] = rzh;
+                const h4 p4 = lh[li];
+                lh[li] = pack_h4(fmaf(c2, (float) p4.x, rx * hs), fmaf(c2, (float) p4.y, ry * hs), fmaf(c2, (float) p4.z, rzh * hs));
+              }
+            }
+          } else {
 #pragma unroll
           for (int k = 0; k < VPT; k++) {
             const int l = tz + k * THREADS;
@@ -349,6 +425,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
               gxy[li] = make_float2(fmaf(beta, pxy.x, rx), fmaf(beta, pxy.y, ry));
               gz[li] = fmaf(beta, gz[li], rzh);
             }
+          }
           }
           CPH(5)
           __syncthreads();
@@ -525,6 +602,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     }
     // ---- update + convergence (Simulation.cpp:1268, 1310-1373); delta v replaces A p in its registers ----
     psum = 0.f;
+    float partd = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
       const int l = tq + k * THREADS, i = r0 + l;
@@ -537,11 +615,13 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
         if (A.cg_seed) st3c(dpb, i, mk(xx[k][0], xx[k][1], xx[k][2]));
         st3c(vnb, i, mk(vq.x + ap[k][0], vq.y + ap[k][1], vq.z + ap[k][2]));
         psum = fmaf(ap[k][0], ap[k][0], psum); psum = fmaf(ap[k][1], ap[k][1], psum); psum = fmaf(ap[k][2], ap[k][2], psum);
+        partd = fmaf(xx[k][0], xx[k][0], partd); partd = fmaf(xx[k][1], xx[k][1], partd); partd = fmaf(xx[k][2], xx[k][2], partd);
       }
     }
     X.site = 8;
     xch_drain();                                  // the new v must have left the CU before the norm (= its hand-over flag) is published
-    if (!xch_allsum<THREADS>(X, psum, 0.f, 0.f, sums)) return;
+    if (!xch_allsum<THREADS>(X, psum, partd, 0.f, sums)) return;
+    dnorm = sqrtf((float) sums[1]);
     xdiff = (double) h * sqrt(sums[0]) / (double) N;
     CPH(7)
     iters = iter + 1;
@@ -589,7 +669,7 @@ template <int VPT, bool DETECT, bool PIPE, bool DEFL = false>
 static hipError_t launch_cl_inst(const DevSystem &S, const DevCluster &CL, const DevWork &W, const FwdArgs &A, int b0, int nb, hipStream_t st) {
   constexpr int THREADS = 512;
   const int GL = CL.R + 2 * CL.HB;
-  int floats = std::max(3 * GL + (PIPE ? 6 * CL.HB : 0), CL.win_lds_bytes / 4);
+  int floats = std::max((PIPE ? 2 : 3) * GL + (PIPE ? 6 * CL.HB : 0), CL.win_lds_bytes / 4);      // (PIPE: direction as 8-byte rows + the neighbours' residual rows)
   const int fric_floats = floats;      // LDS offered to the layered friction pass: the same with and without the inlined detection
   if (DETECT) floats = std::max(floats, kSelfDetectLdsInts);
   const int tail_off = (floats + 3) / 4 * 4;
