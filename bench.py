@@ -228,7 +228,7 @@ def main():
                     help="steps of the CPU baseline sample (rollout 0 from its state after the warm-up steps); -1 = the timed steps, 0 disables")
     ap.add_argument("--tshirt", type=int, default=1, help="also time evaluation 0 of the reference's T-shirt L-BFGS run (secondary line; 0 = skip)")
     ap.add_argument("--secondary", type=str, default="hat,sock,dress,perf_fabric",
-                    help="other BASELINE.json configurations in loaded contact states, 10 fwd+bwd steps each (N = 1 only; '' = skip)")
+                    help="other BASELINE.json configurations in loaded contact states, 10 fwd+bwd steps each (N = 1 only; 'none' = skip)")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0: min(host cores, 32), the fastest setting measured on the MI355X host)")
     args = ap.parse_args()
@@ -373,7 +373,9 @@ def main():
                "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS,
                "lds_model_cycles_per_cu": lds_cycles, "lds_frac_model": lds_cycles / (sec * clock_hz), "clock_hz": clock_hz,
                "traffic": None, "traffic_frac": None, "traffic_source": None, "lds_frac": None, "lds_conflict_share": None,
-               "valu_frac": None, "wait_frac": None, "scratch_write_bytes": None}
+               "valu_frac": None, "wait_frac": None, "scratch_write_bytes": None,
+               "scratch_write_bytes_note": "measured WRITE_SIZE minus the modelled stores (compulsory_write_bytes): an upper bound on spill traffic, not a measurement of it — "
+                                           "profiles/r06_scratch_static.txt locates the scratch stores of the code objects (bench adjoint: none inside a loop; bench forward: 2)"}
         ent.update(extra)
         prof, exact = profile_for(profiles, key, name)
         if prof:
@@ -417,7 +419,7 @@ def main():
                           "compulsory_write_bytes": (60.0 * pd + 64.0 * B * K) * N,
                           "model": "compulsory HBM bytes of the resident design: (108 I_pd + 64 per step) N; CG vectors never leave the CU"})
     k_bwd = kernel_entry("k_adjoint_step_cl" if cl > 1 else "k_adjoint_step", bytes_bwd, lds_cycles_bwd, kt["bwd_ms"], kt["bwd_launches"],
-                         {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + (36.0 * cg_b if args.adjoint_mode == 1 else 0.0) + 48.0 * cyc + 60.0 * B * K) * N,
+                         {"streaming_model_bytes": bytes_bwd, "compulsory_write_bytes": (72.0 * adj + (48.0 * cg_b if args.adjoint_mode == 1 else 0.0) + 48.0 * cyc + 60.0 * B * K) * N,
                           "model": "Krylov vectors stream through HBM: (72 + 100) N per step + 388 N per BiCGSTAB iteration + 216 N per CG iteration + 96 N per fp64 residual"})
     dom = dict(k_fwd if kt["fwd_ms"] >= kt["bwd_ms"] else k_bwd)
     bound = dom["bound"]
@@ -470,7 +472,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, V, F, center, field, xw[0], vw[0], MU[0, 0], ncpu, gscale)
         if world == 1 and args.tshirt:
             out["secondary"] = tshirt_evaluation0()
-        if world == 1 and args.secondary:
+        if world == 1 and args.secondary and args.secondary.lower() not in ("none", "0", "off"):
             e.close()          # the headline's 40 GB of tape go back before the other configurations allocate theirs
             out["secondary_configs"] = [secondary_config(local_rank, k.strip()) for k in args.secondary.split(",") if k.strip()]
         line = json.dumps(out)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes implied by the C declarations (x86-64 SysV): guards the ctypes mirrors in capi.py
     assert ctypes.sizeof(capi.dc_primitive) == 4 + 4 + 24 + 24 + 24 + 8 + 8 + 8 + 8
-    assert ctypes.sizeof(capi.dc_step_stats) == 28 and ctypes.sizeof(capi.dc_bwd_stats) == 36      # (+ residual_verified, round 4)
+    assert ctypes.sizeof(capi.dc_step_stats) == 28 and ctypes.sizeof(capi.dc_bwd_stats) == 40      # (+ residual_verified, round 4; + workgroups, round 6)
     assert ctypes.sizeof(capi.dc_record) == 12 * 8                                                  # twelve pointers (dc_set_record)
     assert ctypes.sizeof(capi.dc_params) == 8 * 5 + 24 + 16 + 16 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
 

@@ -1,7 +1,7 @@
 # developer script: L2 hit / miss counters of the step kernels (one rocprofv3 --pmc pass)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $R/gpurun_out/pmc_l2 -o x --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --cpu-steps 0 > $R/gpurun_out/pmc_l2.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $R/gpurun_out/pmc_l2 -o x --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --cpu-steps 0 --tshirt 0 --secondary none > $R/gpurun_out/pmc_l2.log 2>&1
 python - <<PY
 import csv, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
