@@ -169,3 +169,35 @@ def test_every_rows_per_thread_instance_of_the_packet_kernel(nx, vpt, monkeypatc
     assert abs(int(st["pd_iters"][1]) - ref["iters"]) <= 1
     assert dx <= 4.5e-5
     assert rel(gb["dL_dx"][1], rb["dL_dx"]) <= 1e-4 and rel(gb["dL_dv"][1], rb["dL_dv"]) <= 1e-4
+
+
+@pytest.mark.parametrize("B,split", [(8, False), (8, True)], ids=["one-workgroup", "split"])
+def test_cg_first_and_bicgstab_correction_solves_give_the_same_adjoint(monkeypatch, B, split):
+    """Round 6: the correction solves of the mixed-precision direct adjoint solve are CG first (diag(P) preconditioner instances), BiCGSTAB once a CG
+    cycle stalls or fails to contract the fp64 residual (dc_adjoint.hip: cg32_solve; the split kernel: dc_adjoint_cl.hip). What makes CG admissible on
+    the slightly non-symmetric K is the refinement around it — so the RESULT must not depend on the inner method: same step, DC_ADJ_CG=1 against
+    DC_ADJ_CG=0, both converged to 1e-8 in the fp64-evaluated residual, gradients equal to 1e-6; the statistics say which method ran."""
+    monkeypatch.setenv("DC_CLUSTER", "8" if split else "1")
+    V, F, e, o = scene(64, selfcollision=False, fwd_tol=1e-8)
+    e.set_params(adjoint_block_precond=0); e.build()
+    X, MU = start_states(V, B, twins=())
+    e.alloc_batch(B, 6)
+    assert e.cluster() == (8 if split else 1)
+    e.set_mu(MU)
+    e.set_state(0, X, np.zeros_like(X))
+    e.rollout_forward(0, 6)
+    rng = np.random.default_rng(11)
+    gx = f32(rng.standard_normal(X.shape)); gv = f32(0.01 * rng.standard_normal(X.shape))
+    out = {}
+    for cg in ("1", "0"):
+        monkeypatch.setenv("DC_ADJ_CG", cg)
+        out[cg] = e.step_backward(6, gx, gv, is_start=False)
+        assert np.all(out[cg]["converged"] == 1) and out[cg]["last_udiff"].max() <= 1.01e-8
+    a, b = out["1"], out["0"]
+    assert a["cg_iters"].min() > 0 and b["cg_iters"].max() == 0 and b["adjoint_iters"].min() > 0
+    apps_cg = (a["cg_iters"] + 2 * a["adjoint_iters"]).mean(); apps_bi = (2 * b["adjoint_iters"]).mean()
+    ex, ev = rel(a["dL_dx"], b["dL_dx"]), rel(a["dL_dv"], b["dL_dv"])
+    print(f"\n[CG-first vs BiCGSTAB, {'split x 8' if split else 'one workgroup'}] operator applications per step {apps_cg:.1f} / {apps_bi:.1f}; "
+          f"gradients differ by dx {ex:.2e} dv {ev:.2e}; workgroups {a['workgroups'][0]}")
+    assert ex <= 1e-6 and ev <= 1e-6
+    assert np.all(a["workgroups"] == (8 if split else 1))
