@@ -241,12 +241,13 @@ __device__ __forceinline__ f3 prim_vout(const DevPrim &p, f3 n) {
 // On entry: cg_r = rhs, cg_p = D^-1 rhs, cg_x = 0 and rz = rhs . D^-1 rhs (already reduced).
 // Replaces SimplicialLLT::solve of Simulation.cpp:1267 / :1577.
 // ---------------------------------------------------------------------------------------------------
+// rz_stop: the r . D^-1 r the relative tolerance refers to (the right-hand side's; differs from rz after a deflation projection).
 template <int THREADS>
 __device__ __forceinline__ int block_pcg(const DevSystem &S, float *cg_r, float *cg_p, float *cg_ap, float *cg_x,
-                                         double rz, float rel_tol, int max_iter, double *red) {
+                                         double rz, float rel_tol, int max_iter, double *red, double rz_stop = -1.0) {
   const int N = S.N, tid = threadIdx.x;
-  const double stop = (double) rel_tol * (double) rel_tol * rz;
-  if (!(rz > 1e-300)) return 0;
+  const double stop = (double) rel_tol * (double) rel_tol * (rz_stop >= 0 ? rz_stop : rz);
+  if (!(rz > 1e-300) || !(rz > stop)) return 0;
   int it = 0;
   __syncthreads();
   for (; it < max_iter;) {
@@ -292,6 +293,76 @@ __device__ __forceinline__ int block_pcg(const DevSystem &S, float *cg_r, float 
     __syncthreads();
   }
   return it;
+}
+
+// Spectral deflation for the global-memory solve (round 6; dc_deflate.h — the resident kernels have their own versions): Galerkin projection of
+// the residual onto the 16 lowest eigenvectors U of the SCALED matrix Ahat = D^-1/2 P D^-1/2, in the unscaled variables block_pcg works in:
+//   rhat = D^-1/2 r,  c = (U^T Ahat U)^-1 U^T rhat per coordinate,  x += D^-1/2 U c,  r -= D^1/2 (Ahat U) c,  p = D^-1 r.
+// The meshes that end up on this kernel are the ones too wide for the packet tables — the reference's 17 562-vertex dress — and exactly the
+// irregular garments whose Jacobi-PCG needs hundreds of iterations (355 per PD iteration there). Returns the new r . D^-1 r. `scr` = 64 * 48 + 96
+// floats of LDS. All threads call; ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ double deflate_global(const DevSystem &S, float *cg_r, float *cg_p, float *cg_x, float *scr, double *red) {
+  constexpr int DK = 16, NV = 3 * DK, NW = THREADS / 64;
+  const int N = S.N, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float4 DC_G *U4 = (const float4 DC_G *) S.defl_u;
+  const float4 DC_G *AU4 = (const float4 DC_G *) S.defl_au;
+  float *wsum = scr, *tv = scr + NW * NV, *cv = tv + NV;      // [NW][48] wave sums, [48] U^T rhat, [48] c
+  __syncthreads();
+#pragma unroll 1
+  for (int j4 = 0; j4 < DK / 4; j4++) {
+    float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < N; i += THREADS) {
+      const float4 u = U4[(size_t) i * (DK / 4) + j4];
+      const float sq = S.sq_dinv[i];
+      const f3 q = ld3(cg_r, i, N) * sq;
+      acc[0] = fmaf(u.x, q.x, acc[0]); acc[1] = fmaf(u.x, q.y, acc[1]); acc[2] = fmaf(u.x, q.z, acc[2]);
+      acc[3] = fmaf(u.y, q.x, acc[3]); acc[4] = fmaf(u.y, q.y, acc[4]); acc[5] = fmaf(u.y, q.z, acc[5]);
+      acc[6] = fmaf(u.z, q.x, acc[6]); acc[7] = fmaf(u.z, q.y, acc[7]); acc[8] = fmaf(u.z, q.z, acc[8]);
+      acc[9] = fmaf(u.w, q.x, acc[9]); acc[10] = fmaf(u.w, q.y, acc[10]); acc[11] = fmaf(u.w, q.z, acc[11]);
+    }
+#pragma unroll
+    for (int m = 0; m < 12; m++) {
+      float v = acc[m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) wsum[wv * NV + j4 * 12 + m] = v;      // entry (vector 4 j4 + m / 3, coordinate m % 3)
+    }
+  }
+  __syncthreads();
+  if (tid < NV) {
+    float t = 0.f;
+    for (int w = 0; w < NW; w++) t += wsum[w * NV + tid];
+    tv[tid] = t;
+  }
+  __syncthreads();
+  if (tid < NV) {
+    const int j = tid / 3, c = tid - 3 * j;
+    float sacc = 0.f;
+    for (int l = 0; l < DK; l++) sacc = fmaf(S.defl_g[j * DK + l], tv[l * 3 + c], sacc);
+    cv[tid] = sacc;
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int i = tid; i < N; i += THREADS) {
+    float dx[3] = {0.f, 0.f, 0.f}, dr[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int j4 = 0; j4 < DK / 4; j4++) {
+      const float4 u = U4[(size_t) i * (DK / 4) + j4], a = AU4[(size_t) i * (DK / 4) + j4];
+      const float *c = cv + j4 * 12;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        dx[k] += u.x * c[k] + u.y * c[3 + k] + u.z * c[6 + k] + u.w * c[9 + k];
+        dr[k] += a.x * c[k] + a.y * c[3 + k] + a.z * c[6 + k] + a.w * c[9 + k];
+      }
+    }
+    const float sq = S.sq_dinv[i], isq = 1.0f / sq, di = S.dinv[i];
+    const f3 x = ld3(cg_x, i, N) + mk(dx[0], dx[1], dx[2]) * sq;
+    const f3 r = ld3(cg_r, i, N) - mk(dr[0], dr[1], dr[2]) * isq;
+    st3(cg_x, i, N, x); st3(cg_r, i, N, r); st3(cg_p, i, N, r * di);
+    part += dot(r, r) * di;
+  }
+  return block_sum<THREADS>((double) part, red);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -818,7 +818,8 @@ int dc_build(dc_ctx *c) {
       if ((rc = upload<float>(c, &S.defl_au, HD.AU))) return rc;
       if ((rc = upload<float>(c, &S.defl_g, HD.G))) return rc;
       c->defl_k = HD.k;
-      S.fwd_defl = (S.pk_ok && S.pk_threads == 512 && S.pk_vpt >= 4) ? 1 : 0;
+      // (round 6: a mesh without packet tables runs the global-memory kernel, which projects too — dc_devlib.h: deflate_global)
+      S.fwd_defl = ((S.pk_ok && S.pk_threads == 512 && S.pk_vpt >= 4) || !S.pk_ok) ? 1 : 0;
     }
     static const char *envc = getenv("DC_ADJ_COARSE");      // development switch: 0 = block preconditioner only in the adjoint's fall-back
     S.adj_coarse = (S.defl_u && !(envc && atoi(envc) == 0)) ? 1 : 0;

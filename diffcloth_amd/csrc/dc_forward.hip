@@ -25,6 +25,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict__ Sp, DevWork W, FwdArgs A) {
   const DevSystem &S = *Sp;
   __shared__ double red[THREADS / 64];
+  __shared__ float defl_scr[(THREADS / 64) * 48 + 96];      // deflate_global (irregular garments beyond the packet tables)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = S.N, T = S.T, E = S.E, NC = S.NC;
   const size_t off = (size_t) b * 3 * N;
@@ -135,9 +136,11 @@ __global__ __launch_bounds__(THREADS) void k_pd_step(const DevSystem *__restrict
         part += dot(rhs, rhs) * di;
       }
     }
-    const double rz = block_sum<THREADS>((double) part, red);
+    double rz = block_sum<THREADS>((double) part, red);
     // ---- global step: P dv = rhs (Simulation.cpp:1267) ----
-    cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red);
+    const double rz_rhs = rz;
+    if (S.defl_u && S.fwd_defl && rz > 1e-300) rz = deflate_global<THREADS>(S, cg_r, cg_p, cg_x, defl_scr, red);      // irregular garments (dc_devlib.h)
+    cg_total += block_pcg<THREADS>(S, cg_r, cg_p, cg_ap, cg_x, rz, A.cg_tol, A.cg_max, red, rz_rhs);
     // ---- update + convergence (Simulation.cpp:1268, 1310-1373) ----
     part = 0.f;
     for (int i = tid; i < N; i += THREADS) {
