@@ -755,6 +755,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     if (C.nself > 0) {
       M = A.self.meta[(size_t) b * kMetaStride + kMetaStride - 1];
       const int *verts = A.self.verts + (size_t) b * 2 * S.self_cap;
+      // (plain read-modify-write: verts holds a vertex at most once — the contract stated in dc_selflib.h section 6 and next to self_JT_layers_lds_v)
       for (int q = tid; q < M; q += THREADS) { const int v = verts[q], m = C.mark[v]; C.mark[v] = (m & 2) ? (m | 1) : (1 | ((nplist + q) << 2)); }
     }
     C.plist = plist; C.nplist = nplist; C.nself_verts = M;

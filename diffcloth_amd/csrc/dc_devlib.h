@@ -521,6 +521,9 @@ __device__ __forceinline__ bool self_friction_layers_lds(const DevSystem &S, con
   return self_friction_layers_lds_v<THREADS>(S, R, b, PlainVec{(float *) f}, PlainVec{r}, lds, lds_floats);
 }
 
+// CONTRACT used by the adjoint's y list (dc_adjoint.hip, adjoint_operator): on a `true` return the working set's results are still in LDS as
+// three planes [3][M] of floats at `lds` (lz), slot s = position of the vertex in R.verts — the caller copies them from there before the element
+// windows reuse that LDS. R.verts holds every vertex at most once (dc_selflib.h, section 6), so a slot names one vertex.
 template <int THREADS, class ZV>
 __device__ __forceinline__ bool self_JT_layers_lds_v(const DevSystem &S, const SelfRec &R, int b, const ZV &z, float *lds, int lds_floats) {
   const int cap = S.self_cap, N = S.N, tid = threadIdx.x;

@@ -405,6 +405,9 @@ __device__ __forceinline__ void self_detect_rollout(const DevSystem &S, const De
     rawn[dst] = nq;                              // raw buffer reused as the destination of the normals
   }
   {
+    // CONTRACT (the adjoint relies on it, dc_adjoint.hip: the per-step mark of a working-set vertex stores its slot with a plain read-modify-write): the
+    // list holds every vertex AT MOST ONCE — t.ids[0 .. M) are the distinct vertices of the contacts by rank (5a), and dev_of is a permutation.
+    // dc_set_record deduplicates a list handed in from outside the same way (dc_engine.hip).
     int *verts = selfrec.verts + (size_t) b * 2 * cap;
     for (int m = tid; m < M; m += THREADS) { const int v = t.ids[m]; verts[m] = dev_of ? dev_of[v] : v; }
   }

@@ -163,7 +163,7 @@ def test_optimize_helper_rollout_loss_and_gradient_sphere_demo():
     # per-step dL/dmu is pinned to 5e-3 against the oracle in test_gpu_parity.py
     assert g[0] * fd > 0 and 0.5 <= g[0] / fd <= 2.0
     # Round 6 (VERDICT r05 "weak" 11): the factor of two above is the FINITE DIFFERENCE's noise, not the adjoint's — at 200 steps it moves between 0.57 and
-    # 1.58 of the adjoint value with its step size (0.002 ... 0.02; tools/r06_sphere_fd.py). On horizons where the finite difference is itself stable
+    # 1.58 of the adjoint value with its step size (0.002 ... 0.02; tools/r06_ab/r06_sphere_fd.py). On horizons where the finite difference is itself stable
     # in its step size (30 and 50 steps: the cloth has landed, 1 ... 2 % spread over eps) the rollout-level adjoint agrees with it to a few per cent
     # (measured 1.04 ... 1.05 at mu = 0.55, 0.93 ... 0.95 at mu = 0.15 after 30 steps — the remainder is the derivative of a PD loop truncated at its
     # tolerance, which the adjoint of the converged fixed point does not see): gated at 10 %.

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, call 6: adjoint CG-first on a short leash (distribution + headline A/B); phase timers of the split kernels
 OUT=gpurun_out/r06_06; mkdir -p $OUT
-for cg in 1 0; do DC_ADJ_CG=$cg timeout 200 python tools/r06_cgdist.py > $OUT/cgdist_$cg.log 2>&1; echo "DC_ADJ_CG=$cg"; tail -5 $OUT/cgdist_$cg.log; done
+for cg in 1 0; do DC_ADJ_CG=$cg timeout 200 python tools/r06_ab/r06_cgdist.py > $OUT/cgdist_$cg.log 2>&1; echo "DC_ADJ_CG=$cg"; tail -5 $OUT/cgdist_$cg.log; done
 bb() { tag=$1; tb=$2; shift; shift; ( env "$@" timeout 300 python bench.py --steps 20 --warmup 5 --total-batch $tb --cpu-steps 0 --tshirt 0 --secondary "" > $OUT/b_$tag.log 2>&1 ); python - "$OUT/b_$tag.log" "$tag" <<'P'
 import sys,json
 try:

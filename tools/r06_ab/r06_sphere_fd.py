@@ -1,7 +1,7 @@
 """Developer diagnostic (round 6): sphere demo, rollout-level dL/dmu by the adjoint against central finite differences for several horizons / steps."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "diffcloth_amd", "lib"))
 import diffcloth_py as d
 sim = d.makeSim("sphere")
