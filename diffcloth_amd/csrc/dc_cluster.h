@@ -51,6 +51,7 @@ struct DevCluster {
   v4i *xch;                    // [nb][K][2][xch_stride] granules, zeroed before every launch
   unsigned *err;               // [4] sticky: [0] != 0 -> an exchange timed out
   long long spin_limit;        // bound of every spin in ticks of the 100 MHz wall clock (kSpinLimit; tests shorten it: DC_TEST_SPIN_MS)
+  int redundant_self;          // forward: every part evaluates the layered self friction itself when the rollout's parts share an XCD (DC_SELF_REDUNDANT=0: part 0 alone, rounds 2-5)
   int test_drop;               // test hook (DC_TEST_DROP_PART=1): the last part of the launch's first rollout leaves at once — its peers must time out cleanly
   const DevCluster *self_dev;
 };
@@ -347,6 +348,23 @@ __device__ __forceinline__ bool xch_hello(Xch &X) {
   if (!xch_allsum<THREADS>(X, one ? id : 0.f, one ? id * id : 0.f, 0.f, s)) return false;
   X.same_xcd = (s[0] * s[0] == (double) X.K * s[1]);       // sum^2 == K * sum of squares  <=>  all equal
   return true;
+}
+
+// ---- L1-bypassing (sc1) loads of small shared tables another part wrote (the self-contact lists of part 0's detection) ----
+// Valid as a visibility path only when all parts of the rollout run on ONE XCD (Xch::same_xcd): the writer's plain stores have reached that
+// XCD's L2 once its vmcnt has drained, and an sc1 load is served by that L2, never by this CU's (possibly stale) L1.
+struct Sc1Table {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ int ldi(int idx) const { return __builtin_amdgcn_raw_buffer_load_b32(rs, idx * 4, 0, 16); }
+  __device__ __forceinline__ float4 ld4(int idx) const {
+    const v4i q = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16, 0, 16);
+    return make_float4(__int_as_float(q.x), __int_as_float(q.y), __int_as_float(q.z), __int_as_float(q.w));
+  }
+};
+__device__ __forceinline__ Sc1Table sc1_table(const void *p, size_t bytes) {
+  Sc1Table t;
+  t.rs = __builtin_amdgcn_make_buffer_rsrc((void *) p, 0, (int) bytes, 0x00020000);
+  return t;
 }
 
 // every store of the workgroup so far has left the CU (needed before granules that tell others "my sc1 stores are done")

@@ -341,6 +341,7 @@ int build_cluster(dc_ctx *c, int K, bool forced) {
   std::memset(&D, 0, sizeof(D));
   D.K = K; D.R = R; D.HB = HB; D.wpp = wpp; D.xch_stride = kXchWaves + 2 * HB; D.pk_vpt = vpt;
   D.spin_limit = kSpinLimit; D.test_drop = 0;
+  { const char *ev = getenv("DC_SELF_REDUNDANT"); D.redundant_self = ev ? (ev[0] == '1') : 1; }
   if (const char *ev = getenv("DC_TEST_SPIN_MS")) { const long long ms = atoll(ev); if (ms > 0) D.spin_limit = ms * 100000ll; }      // test hooks
   if (const char *ev = getenv("DC_TEST_DROP_PART")) D.test_drop = ev[0] == '1';
   int rc;

@@ -21,6 +21,78 @@ namespace dc {
 #define CPH_PRINT
 #endif
 
+// Layered self friction (Simulation.cpp:655-678) evaluated REDUNDANTLY by every part of a split rollout (round 6): each part stages the working set
+// of the contacts (f, r of its ~2 x nself vertices through the sc1 path, the contact lists of part 0's detection through Sc1Table), walks the
+// layers in its own LDS — identical inputs, identical arithmetic, identical results in every part — and then writes r and re-forms the right-hand
+// side for ITS OWN rows of the working set only. Before: part 0 alone ran the layers between two cross-part barriers and every part re-formed the
+// right-hand side of all its rows from global memory afterwards; the second barrier and that pass are gone. Returns false (nothing done) when the
+// working set does not fit the LDS offered — a function of values every part reads identically, so all parts take the same branch.
+// Only called when Xch::same_xcd holds (dc_cluster.h: Sc1Table). Same LDS layout and contact code as self_friction_layers_lds_v (dc_devlib.h).
+template <int THREADS, class FV, class RV, class RHS>
+__device__ __forceinline__ bool self_friction_layers_parts(const DevSystem &S, const SelfRec &R, int b, const FV &f, const RV &r, float *lds, int lds_floats,
+                                                           int r0, int r1, bool write_d, RHS rhs_of) {
+  const int cap = S.self_cap, N = S.N, tid = threadIdx.x;
+  const Sc1Table meta = sc1_table(R.meta + (size_t) b * kMetaStride, sizeof(int) * (size_t) kMetaStride);
+  const Sc1Table nrm = sc1_table(R.nrm + (size_t) b * cap, sizeof(float4) * (size_t) cap);
+  const Sc1Table verts = sc1_table(R.verts + (size_t) b * 2 * cap, sizeof(int) * 2 * (size_t) cap);
+  const int C = min(meta.ldi(0), cap), nl = meta.ldi(1), M = meta.ldi(kMetaStride - 1);
+  if (!S.self_lds || self_lds_need(M, C, nl) > lds_floats || nl + 2 >= kMetaStride - 4) return false;
+  float4 *dvec = R.dvec + (size_t) b * cap;
+  float *lf = lds, *lr = lds + 3 * M, *lim = lds + 6 * M;
+  float4 *ln = (float4 *) (lds + 7 * M + ((4 - (7 * M) % 4) % 4));       // 16-byte aligned
+  float4 *ld = ln + C;
+  int *loff = (int *) (ld + C);
+  for (int s = tid; s < M; s += THREADS) {
+    const int v = verts.ldi(s);
+    lf[s] = f.ld(v); lf[M + s] = f.ld(N + v); lf[2 * M + s] = f.ld(2 * N + v);
+    lr[s] = r.ld(v); lr[M + s] = r.ld(N + v); lr[2 * M + s] = r.ld(2 * N + v);
+    lim[s] = 1.0f / S.mass[v];
+  }
+  for (int k = tid; k < C; k += THREADS) ln[k] = nrm.ld4(k);
+  for (int l = tid; l <= nl; l += THREADS) loff[l] = meta.ldi(2 + l);
+  __syncthreads();
+  auto contact = [&](int k) {
+    const float4 n4 = ln[k];
+    const int sl = __float_as_int(n4.w), sa = sl & 0xffff, sb = sl >> 16;
+    const f3 n = mk(n4.x, n4.y, n4.z);
+    const float iA = lim[sa], iB = lim[sb];
+    f3 rA = mk(lr[sa], lr[M + sa], lr[2 * M + sa]), rB = mk(lr[sb], lr[M + sb], lr[2 * M + sb]);
+    f3 d = (mk(lf[sa], lf[M + sa], lf[2 * M + sa]) + rA) * iA - (mk(lf[sb], lf[M + sb], lf[2 * M + sb]) + rB) * iB;
+    ld[k] = make_float4(d.x, d.y, d.z, 0.f);
+    f3 ri = dry_friction(n, d, kClothMu) * (1.0f / (iA + iB));           // k = mA mB / (mA + mB)
+    rA = rA + ri; rB = rB - ri;
+    lr[sa] = rA.x; lr[M + sa] = rA.y; lr[2 * M + sa] = rA.z;
+    lr[sb] = rB.x; lr[M + sb] = rB.y; lr[2 * M + sb] = rB.z;
+  };
+  if (nl <= kWideLayers) {
+    for (int l = 0; l < nl; l++) {
+      const int k1 = loff[l + 1];
+      for (int k = loff[l] + tid; k < k1; k += THREADS) contact(k);
+      __syncthreads();
+    }
+  } else {
+    if (tid < 64) {
+      for (int l = 0; l < nl; l++) {
+        const int k1 = loff[l + 1];
+        for (int k = loff[l] + tid; k < k1; k += 64) contact(k);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");             // compiler: keep the layers' LDS accesses in order
+      }
+    }
+    __syncthreads();
+  }
+  for (int s = tid; s < M; s += THREADS) {
+    const int v = verts.ldi(s);
+    if (v >= r0 && v < r1) {
+      const f3 rv = mk(lr[s], lr[M + s], lr[2 * M + s]);
+      r.st(v, rv.x); r.st(N + v, rv.y); r.st(2 * N + v, rv.z);
+      rhs_of(v, mk(lf[s], lf[M + s], lf[2 * M + s]), rv);
+    }
+  }
+  if (write_d) for (int k = tid; k < C; k += THREADS) dvec[k] = ld[k];
+  __syncthreads();
+  return true;
+}
+
 // PIPE: the inner solve is the single-exchange CG (one exchange per iteration instead of two), see the loop
 template <int THREADS, int VPT, bool DETECT, bool PIPE, bool DEFL>
 __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restrict__ Sp, const DevCluster *__restrict__ Cp, DevWork W,
@@ -38,6 +110,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   if (lb >= nb_real) return;       // padding workgroups: the launch is rounded up to a multiple of 8 rollouts (see the launcher)
   if (CL.test_drop && lb == 0 && part == K - 1) return;      // test hook: a part that never arrives (tests/test_gpu_cluster.py)
   const int b = b0 + lb;
+  const bool redundant_layers = CL.redundant_self != 0;
   Xch X = xch_init(CL, lb, part, lds + tail_off);
   if (!xch_hello<THREADS>(X)) return;
   float2 *gxy = (float2 *) lds;            // search direction over rows [r0 - HB, r0 + R + HB): (x, y) plane, then the z plane
@@ -81,7 +154,11 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
   srec.meta += (size_t) step * A.slot_meta; srec.verts += (size_t) step * 2 * A.slot_self;
   if constexpr (DETECT) {                     // detection + layering of this step: part 0, then the lists change hands
     X.site = 2;
-    if (part == 0) { self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lds, A.fv2); __syncthreads(); }
+    if (part == 0) {
+      self_detect_rollout<THREADS>(S, W, b, A.x_in + so, A.v_in + so, A.rec_prim + (size_t) step * A.slot_prim, srec, fu_s, A.fv, fvs_s, (int *) lds, A.fv2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the lists have left the CU before the exchange below tells the other parts they exist
+      __syncthreads();
+    }
   }
   // number of self contacts of this step: part 0 knows it (its own detection, or the stand-alone detection kernel's record) and
   // hands it to the others inside an exchange, so that no part ever has to read it from memory another part wrote
@@ -157,31 +234,36 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
     auto vert = vert_noa([&](int i, f3 sum, f3) {      // (does not use input 1 at the vertex: dc_winlib.h, NOA)
       f3 rhs = vertex_body(i, sum);
       st3(scr, i, N, rhs);
-      psum += dot(rhs, rhs);
     });
     element_windows_t<THREADS, kFwdOpsPrecise>(CL, w0, w1, lds, In2Sc1{xnb}, In2Sc1{vnb}, fwd_tri_op(h, S.h64), fwd_bend_op(h, S.h64), vert);   // fp64-strain operators (dc_winlib.h)
     __syncthreads();
     CPH(0)
     X.site = 4;
-    if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) on part 0 over the rollout's f / r, then the right-hand side again
+    if (nself > 0) {   // layered self friction (Simulation.cpp:655-678) over the rollout's f / r, then the right-hand side of the vertices it touched
       if (!xch_barrier<THREADS>(X)) return;
-      if (part == 0) {
-        if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
+      bool redundant = false;
+      if (X.same_xcd && redundant_layers)      // every part for itself (self_friction_layers_parts above): no second barrier, no pass over all rows
+        redundant = self_friction_layers_parts<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats, r0, r1, part == 0, [&](int i, f3 fv, f3 rv) {
+          st3(scr, i, N, (fv + rv - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i]);
+        });
+      if (!redundant) {
+        if (part == 0) {
+          if (!self_friction_layers_lds_v<THREADS>(S, srec, b, rfb, rrb, lds, fric_floats)) self_friction_layers_v<THREADS>(S, srec, b, rfb, rrb);
+        }
+        if (!xch_barrier<THREADS>(X)) return;
+        for (int i = r0 + tid; i < r1; i += THREADS) {
+          f3 rhs = (ld3c(rfb, i) + ld3c(rrb, i) - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i];
+          st3(scr, i, N, rhs);
+        }
+        __syncthreads();
       }
-      if (!xch_barrier<THREADS>(X)) return;
-      psum = 0.f;
-      for (int i = r0 + tid; i < r1; i += THREADS) {
-        f3 rhs = (ld3c(rfb, i) + ld3c(rrb, i) - ld3c(vnb, i) * S.mass[i]) * CL.sq_dinv[i];
-        st3(scr, i, N, rhs);
-        psum += dot(rhs, rhs);
-      }
-      __syncthreads();
     }
     CPH(1)
     // ---- residual into registers, search direction p0 = r0 into the gather array, boundary rows to the neighbours ----
     float rr[VPT][3], ap[VPT][3], xx[VPT][3];
     X.site = 5;
     xch_begin(X);
+    psum = 0.f;
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
       const int l = tq + k * THREADS, i = r0 + l;
@@ -190,7 +272,7 @@ __global__ __launch_bounds__(THREADS) void k_pd_step_cl(const DevSystem *__restr
       const float okf = on ? 1.f : 0.f;
       rr[k][0] = scr[ic] * okf; rr[k][1] = scr[N + ic] * okf; rr[k][2] = scr[2 * N + ic] * okf;
 #pragma unroll
-      for (int c = 0; c < 3; c++) xx[k][c] = 0.f;
+      for (int c = 0; c < 3; c++) { xx[k][c] = 0.f; psum = fmaf(rr[k][c], rr[k][c], psum); }      // |rhs|^2 of the own rows (after the self-friction pass, if any)
       if (l < R) {
         if constexpr (!H16) { gxy[HB + l] = make_float2(rr[k][0], rr[k][1]); gz[HB + l] = rr[k][2]; }
         xch_publish_boundary(X, l, R, rr[k][0], rr[k][1], rr[k][2]);
