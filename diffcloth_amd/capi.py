@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "dc_seed_gradient", "dc_rollout_backward", "dc_get_gradient", "dc_get_param_gradients", "dc_get_stats", "dc_sync", "dc_timer_start",
     "dc_timer_stop", "dc_kernel_times", "dc_get_cluster", "dc_set_gradient", "dc_set_fixed_point_schedule", "dc_set_force_schedule",
     "dc_set_seed_schedule", "dc_clear_schedules", "dc_get_states", "dc_get_dxfixed", "dc_get_layout", "dc_comm_unique_id", "dc_comm_init", "dc_allreduce_sum", "dc_comm_destroy",
-    "dc_get_deflation", "dc_set_record", "dc_keep_force_gradients", "dc_get_force_gradients", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
+    "dc_get_deflation", "dc_set_record", "dc_set_trajectory_start", "dc_keep_force_gradients", "dc_get_force_gradients", "dc_use_stream", "dc_set_state_dev", "dc_get_state_dev", "dc_step_forward_dev", "dc_step_backward_dev",
 ]
 
 _lib = None
@@ -375,6 +375,10 @@ class Engine:
     def seed_gradient(self, slot, target=None, scale=1.0):
         t = None if target is None else _f64(target).reshape(-1)
         self._chk(self.lib.dc_seed_gradient(self.h, C.c_int(slot), _d(t), C.c_double(scale)))
+
+    def set_trajectory_start(self, start_slot):
+        """tape slot of the trajectory's initial state (default 0; -1: this tape holds a later segment — no backward step of it is the isStart step)"""
+        self._chk(self.lib.dc_set_trajectory_start(self.h, C.c_int(start_slot)))
 
     def rollout_backward(self, slot, nsteps):
         self._chk(self.lib.dc_rollout_backward(self.h, C.c_int(slot), C.c_int(nsteps)))

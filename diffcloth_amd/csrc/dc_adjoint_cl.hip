@@ -217,7 +217,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     if (A.d_xfixed) A.d_xfixed -= A.slot_xf;
     if (A.ix) A.ix -= A.slot_ix;
     if (A.iv) A.iv -= A.slot_ix;
-    A.is_start = (A.slot - step == 1) ? 1 : 0;            // isStart: Simulation.cpp:3947
+    A.is_start = (A.slot - step == A.start_at) ? 1 : 0;            // isStart: Simulation.cpp:3947
     A.inj_x = A.inj_f = A.inj_n = A.inj_sn = A.inj_sd = nullptr;      // (a record from outside is differentiated by a launch of its own)
     if (A.ys) A.ys -= A.slot_state;
   }

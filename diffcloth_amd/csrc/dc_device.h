@@ -212,6 +212,7 @@ struct BwdArgs {
   int ycap, ybase;              // entries of the contact vertices' y list in the dynamic LDS and its start in floats (set by the launch: dc_adjoint.hip, AdjCtx::ylist)
   // several consecutive steps of the backward sweep in one launch: step s differentiates tape slot `slot` - s
   int nsteps, slot;
+  int start_at;                 // the record whose backward step is the trajectory's isStart step (dc_set_trajectory_start: start slot + 1; 0 = none)
   size_t slot_state, slot_prim, slot_self, slot_meta, slot_param, slot_xf, slot_stats;   // per-slot strides (elements); d_xfixed steps by slot_xf too
   size_t slot_ix;               // seed schedule: ix / iv of step s are ix - s * slot_ix (0: none / the same buffer)
   // record handed in from outside (dc_set_record): the fp64 values of x_new, f, the primitive-contact normals ([B][3][N] planar) and of

@@ -83,6 +83,7 @@ struct dc_ctx {
   bool fv_set = false;
   float *fv2 = nullptr;             // [B][3][N] second per-vertex force term, factor 1 (dc_set_vertex_force_field)
   bool fv2_set = false;
+  int start_slot = 0;              // dc_set_trajectory_start: the tape slot of the trajectory's initial state (-1: none in this tape)
   float *GX = nullptr, *GV = nullptr, *IX = nullptr, *IV = nullptr, *DMU = nullptr, *target = nullptr;
   float *DXF = nullptr;             // [(tape+1)][B][3][Af] dL_dxfixed of the step that produced the slot
   // device-resident schedules of the fused rollouts (dc_set_*_schedule); flags per tape slot
@@ -250,6 +251,7 @@ BwdArgs bwd_args(dc_ctx *c, int slot, bool is_start, bool with_init) {
   A.it_cap = c->params.adjoint_iter_cap > 0 ? c->params.adjoint_iter_cap : 400;   // Simulation.cpp:1562
   A.cg_max = c->params.cg_max_iter > 0 ? c->params.cg_max_iter : 500;
   A.is_start = is_start; A.clip = c->params.gradient_clipping;
+  A.start_at = c->start_slot + 1;
   A.mode = c->params.adjoint_mode;
   A.rel_tol = (float) (c->params.adjoint_rel_tol > 0 ? c->params.adjoint_rel_tol : 1e-6);
   A.stall_window = c->params.stall_window > 0 ? c->params.stall_window : 0x7fffffff;   // off by default: reference semantics
@@ -948,7 +950,7 @@ int dc_alloc_batch(dc_ctx *c, int B, int tape) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   free_pool(c->batch_allocs);
-  c->B = B; c->tape = tape;
+  c->B = B; c->tape = tape; c->start_slot = 0;
   const int N = c->host.N, Af = (int) c->host.att_vertex.size(), NC = c->S.NC, G = c->S.ngroups;
   const size_t se = (size_t) B * 3 * N, slots = (size_t) tape + 1;
   auto &pool = c->batch_allocs;
@@ -1519,13 +1521,13 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   const bool inj_inside = c->inj_slot >= slot - nsteps + 1 && c->inj_slot <= slot;      // (dc_set_record: that step gets a launch of its own)
   const bool fused_bwd = fuse_ok && nsteps > 1 && !inj_inside;
   if (fused_bwd) {
-    BwdArgs A = bwd_args(c, slot, slot == 1, false);
+    BwdArgs A = bwd_args(c, slot, slot == c->start_slot + 1, false);
     A.nsteps = nsteps;                       // the whole sweep of a rollout in one launch
     if ((rc = enqueue_adjoint_step(c, A))) return rc;
   } else {
     for (int k = 0; k < nsteps; k++) {
       const int s = slot - k;
-      if ((rc = enqueue_adjoint_step(c, bwd_args(c, s, s == 1, false)))) return rc;   // isStart: Simulation.cpp:3947
+      if ((rc = enqueue_adjoint_step(c, bwd_args(c, s, s == c->start_slot + 1, false)))) return rc;   // isStart: Simulation.cpp:3947
     }
   }
   HIPCHK(c, hipEventRecord(c->ev_b, c->stream));
@@ -1536,6 +1538,13 @@ int dc_rollout_backward(dc_ctx *c, int slot, int nsteps) {
   const int chunks = use_cluster_bwd(c) ? (c->B + c->cl.nb - 1) / c->cl.nb : 1;
   c->bwd_ms += ms; c->bwd_launches += (fused_bwd ? 1 : nsteps) * chunks;
   return cluster_check(c);
+}
+
+int dc_set_trajectory_start(dc_ctx *c, int start_slot) {
+  if (!c) return DC_ERR_INVALID;
+  if (start_slot < -1) return fail(c, DC_ERR_INVALID, "dc_set_trajectory_start: start_slot must be >= -1");
+  c->start_slot = start_slot;
+  return DC_OK;
 }
 
 int dc_get_gradient(dc_ctx *c, double *dL_dx, double *dL_dv, double *dL_dmu) {

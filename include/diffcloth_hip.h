@@ -313,6 +313,12 @@ int dc_clear_schedules(dc_ctx *ctx);
 int dc_get_states(dc_ctx *ctx, int slot0, int nslots, double *x, double *v);
 /* dL_dxfixed of the steps through records slot0 .. slot0+nslots-1 of the last backward sweep / step (B*3Af each) */
 int dc_get_dxfixed(dc_ctx *ctx, int slot0, int nslots, double *dL_dxfixed /*nslots*B*3Af*/);
+/* Which tape slot holds the trajectory's INITIAL state (default 0): the backward step through record start_slot + 1 is the reference's isStart step
+ * (Simulation.cpp:3947, :1534: dL_dx of the initial state takes no dL_dv / h term) in dc_rollout_backward. -1: this tape holds a LATER segment of a
+ * trajectory — no step of it is the start. With it a trajectory can be run as a chain of fused segments over several contexts (e.g. one context per
+ * attachment set, SceneConfiguration::customAttachmentVertexIdx, Simulation.cpp:1053-1068): state handed on with dc_get_state_dev / dc_set_state_dev,
+ * the carried gradient on the way back with dc_get_gradient / dc_set_gradient (tests/test_gpu_schedules.py). dc_step_backward takes is_start itself. */
+int dc_set_trajectory_start(dc_ctx *ctx, int start_slot);
 int dc_get_stats(dc_ctx *ctx, int slot, dc_step_stats *fwd /*B or NULL*/, dc_bwd_stats *bwd /*B or NULL*/);
 int dc_sync(dc_ctx *ctx);
 /* Split execution: with fewer rollouts than compute units (BASELINE C4 sharded over 8 GPUs: 32 per GPU; hatController.py: 20 rollouts)

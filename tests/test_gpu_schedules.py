@@ -6,6 +6,7 @@ scheduled sweeps must reproduce the per-step calls that receive the same values 
 """
 import numpy as np
 import pytest
+import torch          # before the engine's library: both must share ONE HIP runtime (torch's), see tests/test_gpu_functional.py
 
 import meshes
 from diffcloth_amd import capi
@@ -175,3 +176,82 @@ def test_fused_backward_sweep_keeps_the_force_gradient_of_every_step(nx, cluster
     dx_s, dv_s, _ = e.get_gradient()
     np.testing.assert_array_equal(dx_f, dx_s); np.testing.assert_array_equal(dv_f, dv_s)
     assert np.abs(kept).max() > 0
+
+
+def test_several_attachment_sets_in_fused_batched_rollouts_by_composing_contexts():
+    """Several attachment sets (SceneConfiguration::customAttachmentVertexIdx with more than one entry, Simulation.cpp:1053-1068, :2371-2393: one
+    SystemMatrix per set, set i takes over at a given record) in the BATCHED, fused form: every set is its own system matrix, i.e. its own context,
+    and a rollout that switches sets is a chain of fused segments — the state is handed from context to context ON THE DEVICE (dc_get_state_dev /
+    dc_set_state_dev: no host copy), the carried gradient on the way back. The host class does the same per step for one rollout
+    (tests/test_gpu_pymodule.py::test_several_attachment_sets_switch_the_system_matrix, against two oracles); here: a batch of 4 rollouts, 2 steps
+    with set A then 3 steps with set B, each segment ONE launch per direction with its clip targets as a schedule — against the same chain driven
+    by per-step calls (forward bitwise, backward to solver tolerance) and with the segments' record types intact (dL_dxfixed of a step has the size
+    of ITS set)."""
+    nx = 24
+    setA, setB = (0, nx - 1), (nx * (nx - 1), nx * nx - 1, nx * nx // 2)
+    rng = np.random.default_rng(9)
+    B, SA, SB = 4, 2, 3
+    V, F, eA = scene(nx, setA)
+    _, _, eB = scene(nx, setB)
+    N = V.shape[0]
+    X0 = np.stack([f32((V + np.array([0.03 * b, -0.05, 0.02 * b])).reshape(-1)) for b in range(B)])
+    XFA = np.stack([np.stack([f32((V[list(setA)] + np.array([0.0, 0.01 * (s + 1), 0.005 * b])).reshape(-1)) for b in range(B)]) for s in range(SA)])
+    XFB = np.stack([np.stack([f32((V[list(setB)] + np.array([0.004 * b, 0.01 * (s + 1), 0.0])).reshape(-1)) for b in range(B)]) for s in range(SB)])
+    gx = f32(rng.standard_normal(X0.shape)); gv = f32(0.01 * rng.standard_normal(X0.shape))
+    dev = torch.device("cuda", 0)
+
+    def hand_over(src, slot, dst):
+        x = torch.empty(B * 3 * N, dtype=torch.float64, device=dev); v = torch.empty_like(x)
+        src.get_state_dev(slot, x, v)
+        dst.set_state_dev(0, x, v)
+        torch.cuda.synchronize()
+
+    def run(fused):
+        eA.alloc_batch(B, SA); eB.alloc_batch(B, SB)
+        eB.set_trajectory_start(-1)                # set B's tape holds the SECOND segment: none of its steps is the trajectory's isStart step
+        eA.set_state(0, X0, np.zeros_like(X0))
+        if fused:
+            eA.set_fixed_point_schedule(0, XFA); eA.rollout_forward(0, SA)
+        else:
+            for s in range(SA):
+                eA.step_forward(s, fixed_pts=XFA[s])
+        eA.sync()
+        hand_over(eA, SA, eB)
+        if fused:
+            eB.set_fixed_point_schedule(0, XFB); eB.rollout_forward(0, SB)
+        else:
+            for s in range(SB):
+                eB.step_forward(s, fixed_pts=XFB[s])
+        xe, ve = eB.get_state(SB)
+        stats = [eA.get_stats(s + 1)[0] for s in range(SA)] + [eB.get_stats(s + 1)[0] for s in range(SB)]
+        # backward: set B's segment, the carried gradient to set A's context, set A's segment
+        if fused:
+            eB.set_gradient(gx, gv); eB.rollout_backward(SB, SB)
+            dxB, dvB, _ = eB.get_gradient()
+            dxfB = eB.get_dxfixed(1, SB)
+            eA.set_gradient(dxB, dvB); eA.rollout_backward(SA, SA)
+            dx, dv, _ = eA.get_gradient()
+            dxfA = eA.get_dxfixed(1, SA)
+        else:
+            cx, cv = gx, gv
+            dxfB = np.zeros((SB, B, 3 * len(setB))); dxfA = np.zeros((SA, B, 3 * len(setA)))
+            for s in range(SB, 0, -1):
+                gb = eB.step_backward(s, cx, cv, is_start=False)
+                assert np.all(gb["converged"] == 1)
+                cx, cv = gb["dL_dx"], gb["dL_dv"]; dxfB[s - 1] = gb["dL_dxfixed"]
+            for s in range(SA, 0, -1):
+                gb = eA.step_backward(s, cx, cv, is_start=(s == 1))
+                assert np.all(gb["converged"] == 1)
+                cx, cv = gb["dL_dx"], gb["dL_dv"]; dxfA[s - 1] = gb["dL_dxfixed"]
+            dx, dv = cx, cv
+        eA.clear_schedules(); eB.clear_schedules()
+        return dict(x=xe, v=ve, dx=dx, dv=dv, dxfA=dxfA, dxfB=dxfB, conv=[np.all(st["converged"] == 1) for st in stats])
+
+    a, b = run(True), run(False)
+    assert all(a["conv"]) and all(b["conv"])
+    np.testing.assert_array_equal(a["x"], b["x"]); np.testing.assert_array_equal(a["v"], b["v"])      # fused = per-step, bit for bit, across the switch
+    assert a["dxfA"].shape == (SA, B, 6) and a["dxfB"].shape == (SB, B, 9)
+    e_dx, e_dv = rel(a["dx"], b["dx"]), rel(a["dv"], b["dv"])
+    e_fa, e_fb = rel(a["dxfA"], b["dxfA"]), rel(a["dxfB"], b["dxfB"])
+    print(f"\n[attachment sets, fused segments vs per-step calls] dL_dx {e_dx:.2e} dL_dv {e_dv:.2e} dL_dxfixed set A {e_fa:.2e} set B {e_fb:.2e}")
+    assert max(e_dx, e_dv, e_fa, e_fb) <= 1e-5 and np.linalg.norm(a["dxfA"]) > 0 and np.linalg.norm(a["dxfB"]) > 0
