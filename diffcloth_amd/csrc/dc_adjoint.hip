@@ -12,8 +12,9 @@
 //   mode 0  the reference's iteration (Simulation.cpp:1561-1600): u <- u + P^-1 (g - K u) with the block-Jacobi
 //           PCG of the forward pass for P^-1, stop on |u_new - u|_2 / N < backwardConvergenceThreshold; when the
 //           cap is reached it falls back to the direct solve, as the reference does with SparseLU (:1589-1594);
-//   mode 1  direct solve (semantics of backwardGradientForceDirectSolver / solveDirect, Simulation.cpp:1431-1440):
-//           block-Jacobi preconditioned BiCGSTAB on K itself, relative residual <= adjoint_rel_tol.
+//   mode 1  direct solve (semantics of backwardGradientForceDirectSolver / solveDirect, Simulation.cpp:1431-1440): mixed-precision refinement on K
+//           itself — fp32 correction solves (CG first with the diag(P) preconditioner, block-Jacobi preconditioned BiCGSTAB otherwise or once CG
+//           stalls) of a residual evaluated in fp64, fp64 BiCGSTAB fall-back — to a relative residual <= adjoint_rel_tol.
 #define DC_KERNEL_TU
 #include <cstdlib>
 #include "dc_devlib.h"
@@ -602,7 +603,6 @@ __device__ DC_OUTLINED Ret32 cg32_solve(const DevSystem &S, AdjCtx C, Krylov32 V
   // rollout: 80 ms per batch step instead of 12). Hence a short leash: no new minimum of |r| for kCgStall iterations, or kCgCycleCap iterations in one
   // solve, ends the solve unconverged (status 0) and the caller hands the rest of the step to BiCGSTAB; the correction reached so far is kept
   // if the fp64 residual says it helped.
-  constexpr int kCgStall = 10, kCgCycleCap = 64;
   for (int k = 2 * kdone; k < 2 * kcap && in_status == 0 && its < kCgCycleCap; k++) {
     // v = K p ;  alpha = (r . z) / (p . v)
     adjoint_operator<THREADS, WIN, true>(S, C, p, false, v, p, d1, d2);

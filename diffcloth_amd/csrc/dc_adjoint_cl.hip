@@ -1,11 +1,12 @@
 // CDNA4 (gfx950) adjoint step, split variant: one rollout is run by K workgroups (dc_cluster.h), part p owning the vertex rows
-// [p R, (p + 1) R). Same algorithm as dc_adjoint.hip, direct solve (adjoint_mode 1: block-Jacobi preconditioned BiCGSTAB on
+// [p R, (p + 1) R). Same algorithm as dc_adjoint.hip, direct solve (adjoint_mode 1: mixed-precision refinement whose fp32 correction solves are
+// preconditioned CG first — diag(P) instances — and block-Jacobi preconditioned BiCGSTAB otherwise, on
 // K = M + h^2 (A - dp/dx)^T A (I + dr_df)^T, the semantics of Simulation::solveDirect, Simulation.cpp:1431-1440, inside
 // Simulation::stepBackward, :1455-1780). The Krylov vectors stay in global memory and every part touches only its own rows of
 // them; what crosses the parts:
 //   * the input of an operator application over the reach of the element windows: its HB boundary rows travel as granules when
 //     the vector is written and land in a small LDS cache the window staging reads;
-//   * the partial sums of every dot product (five exchanges per BiCGSTAB iteration);
+//   * the partial sums of every dot product (three exchanges per CG iteration = per operator application, five per BiCGSTAB iteration = per two);
 //   * with self contacts (which couple arbitrary vertices) y = (I + dr_df)^T z is formed in global memory instead: own rows by
 //     every part, the layered transposed pass by part 0, fence barriers in between.
 #define DC_KERNEL_TU
@@ -295,7 +296,6 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
     if (cg_cycle) {
       // ---- preconditioned CG (diag(P)^-1) on K d = rhs, on a short leash (dc_adjoint.hip: cg32_solve): one operator application and three
       //      exchanges per iteration (p.Kp; r.D^-1 r and r.r; the boundary rows of the new p) where BiCGSTAB takes two and five ----
-      constexpr int kCgStall = 10, kCgCycleCap = 64;
       xch_begin(X);
       part_s = 0.f;
       float part_z = 0.f;

@@ -4,11 +4,12 @@
 // A p / iterate in registers, element windows in LDS); what is new is what crosses the parts:
 //   * PD level: the velocity iterate v is written and read write-through (sc1), its hand-over flag is the exchange that carries
 //     the convergence norm; per time step the tape state changes hands under an agent-scope release / acquire pair;
-//   * PCG level, two exchanges per iteration: [p.Ap partials] and [r.r partial + the HB boundary rows of the new residual]; every
-//     part keeps the neighbours' boundary rows of the search direction in its LDS gather array and updates them itself
-//     (p_halo = r_halo + beta p_halo), so the direction never travels;
-//   * self contacts couple arbitrary vertices: detection + layering and the layered friction pass of an iteration run on part 0
-//     over the rollout's global arrays, bracketed by fence barriers.
+//   * PCG level, ONE exchange per iteration (round 6, dc_forward_cl_kernel.h): [p.Ap, p.r, r.Ap, Ap.Ap, r.r partials + the HB boundary rows of A p];
+//     the next residual's norm is r.r - 2 alpha r.Ap + alpha^2 Ap.Ap, and every part keeps the neighbours' boundary rows of the residual AND of
+//     the search direction (stored as scaled halves) in its LDS and updates them itself (r_halo -= alpha (A p)_halo, p_halo = r_halo + beta p_halo),
+//     so neither travels. (DC_SXCG=0: the two-exchange fp32 loop of rounds 2-5 — [p.Ap] and [r.r + boundary rows of the new residual].)
+//   * self contacts couple arbitrary vertices: detection + layering run on part 0; the layered friction pass of an iteration is evaluated by every
+//     part in its own LDS when the parts share an XCD (the contact lists cross through L1-bypassing loads), else on part 0 between two barriers.
 // All parts take identical control-flow decisions: every scalar that steers a loop is a sum over the parts in part order.
 #define DC_KERNEL_TU
 #include "dc_forward_cl_kernel.h"

@@ -85,7 +85,7 @@ typedef struct dc_params {
    * from x_new every backward step (in-plane stiff / normal soft, sticking contacts decoupled); 0 = the forward solve's Jacobi
    * diag(P)^-1. Changes the iteration count only, not what the solve converges to.                                      */
   int adjoint_block_precond;
-  /* direct adjoint solve, precision: 0 (default) = mixed — fp32 BiCGSTAB solves for corrections of the residual g - K u evaluated
+  /* direct adjoint solve, precision: 0 (default) = mixed — fp32 Krylov solves (CG first, BiCGSTAB once CG stalls; round 6) for corrections of the residual g - K u evaluated
    * in fp64 from fp64 rest-shape tables, until |g - K u| <= adjoint_rel_tol |g| holds in fp64; when the fp32 solve makes no
    * progress (adjoint systems beyond fp32, e.g. a compressed fine garment) a block-Jacobi BiCGSTAB in fp64 on the same operator
    * takes over — the role of the reference's fp64 SparseLU (Simulation.cpp:1431-1440), which always returns a solution.
