@@ -169,6 +169,47 @@ def secondary_config(device, key, K=10):
         return {"workload": key, "error": f"{type(ex).__name__}: {ex}"}
 
 
+def c4_share_config(device, args, V, F, V0, flap, center, B=32):
+    """The headline workload at the per-GPU share of the 8-GPU job (256 rollouts sharded over 8 ranks = 32 per GPU): the engine splits every rollout over
+    8 workgroups (dc_get_cluster) — the figure one GPU can measure of BASELINE.json's "batch 256 sharded over 8 GPUs". Same steps, same settings."""
+    try:
+        K, W = args.steps, args.warmup
+        e = make_engine(device, args, V, F, center)
+        e.alloc_batch(B, W + K)
+        X0, MU = rollout_inputs(V0, np.arange(B))
+        e.set_mu(MU)
+        e.set_state(0, X0, np.zeros_like(X0))
+        if flap.any() and args.flap_force != 0:
+            e.set_vertex_forces(np.tile(flap_force(args, e.vertex_data()[0], flap), (B, 1)))
+        if W > 0:
+            e.rollout_forward(0, W)
+        gscale = 2.0 / ((K + 1) * e.N)
+        e.seed_gradient(W, None, gscale)
+        if W > 0:
+            e.rollout_backward(W, 1)
+        e.sync(); e.kernel_times(reset=True)
+        t0 = time.perf_counter()
+        e.rollout_forward(W, K); e.seed_gradient(W + K, None, gscale); e.rollout_backward(W + K, K)
+        dmu = e.get_mu_gradient().sum(axis=0)
+        dt = time.perf_counter() - t0
+        kt = e.kernel_times()
+        st = [e.get_stats(s) for s in range(W + 1, W + K + 1)]
+        pd = float(np.mean([q[0]["pd_iters"].mean() for q in st]))
+        out = {"workload": f"C4 (the headline workload) at {B} rollouts: one rank's share of the 8-GPU job, every rollout split over workgroups",
+               "rollouts": B, "steps": K, "workgroups_per_rollout": e.cluster(), "rollout_steps_per_s": B * K / dt, "ms_per_batch_step": dt / K * 1e3,
+               "fwd_ms_per_step": kt["fwd_ms"] / K, "bwd_ms_per_step": kt["bwd_ms"] / K, "mean_pd_iters_per_step": pd,
+               "mean_cg_iters_per_pd_iter": float(np.mean([q[0]["cg_iters"].mean() for q in st])) / max(pd, 1e-30),
+               "mean_adjoint_operator_applications_per_step": float(np.mean([(2 * q[1]["adjoint_iters"] + q[1]["cg_iters"]).mean() for q in st])),
+               "mean_self_contacts_per_step": float(np.mean([q[0]["self_contacts"].mean() for q in st])),
+               "backward_workgroups_per_rollout": int(st[0][1]["workgroups"].max()), "dL_dmu_sum": float(np.asarray(dmu).sum()),
+               "eight_gpu_projection_rollout_steps_per_s": 8.0 * B * K / dt,
+               "projection_note": "8 x this figure is what 8 such GPUs deliver on the 256-rollout job if the ranks run as this one does (no data-path collective; unmeasured)"}
+        e.close()
+        return out
+    except Exception as ex:      # secondary information must never take the headline down
+        return {"workload": "C4 at 32 rollouts", "error": f"{type(ex).__name__}: {ex}"}
+
+
 def config_key(args, B, K, W, N):
     return (f"N{N}_B{B}_K{K}_W{W}_fold{args.fold_rows}x{args.flap_force:g}_sc{args.selfcollision}_ft{args.fwd_tol:g}_cg{args.cg_tol:g}"
             f"_am{args.adjoint_mode}_ar{args.adjoint_rel_tol:g}_bp{args.block_precond}")
@@ -475,6 +516,8 @@ def main():
         if world == 1 and args.secondary and args.secondary.lower() not in ("none", "0", "off"):
             e.close()          # the headline's 40 GB of tape go back before the other configurations allocate theirs
             out["secondary_configs"] = [secondary_config(local_rank, k.strip()) for k in args.secondary.split(",") if k.strip()]
+            if args.cluster < 0 and args.total_batch == 256 and args.batch == 0:
+                out["secondary_configs"].append(c4_share_config(local_rank, args, V, F, V0, flap, center))
         line = json.dumps(out)
     else:
         line = None
