@@ -36,6 +36,7 @@ CFG
     fallb) TAILN=30 run fallb python -m pytest tests/test_gpu_fallbacks.py -q ;;
     parity) TAILN=40 run parity python -m pytest tests/test_gpu_bench_parity.py -q -s ;;
     all) TAILN=15 run all python -m pytest tests -m gpu -q -x ;;
+    final) bash tools/round_final.sh $TAG ;;      # the round's CLOSING record: whole suite + ledger + bench on the library as it is, its sha256 recorded (tools/check_round_final.py refuses a round whose record is not of the library in the tree)
     rest) TAILN=15 run rest python -m pytest tests -m gpu -q --deselect tests/test_gpu_bench_parity.py --deselect tests/test_gpu_cluster.py ;;
     bench) TAILN=3 run bench python bench.py --steps 20 --warmup 5 ;;
     bench32) TAILN=3 run bench32 python bench.py --steps 20 --warmup 5 --total-batch 32 --cpu-steps 0 --tshirt 0 ;;
