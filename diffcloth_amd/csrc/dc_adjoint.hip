@@ -921,7 +921,11 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step(const DevSystem *__res
     const bool cg_cycle = use_cg;
     Ret32 r32;
     if (cg_cycle) { r32 = cg32_solve<THREADS, WIN>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone); cg_total += r32.iters; r32.iters = iters; }
-    else r32 = bicgstab32_solve<THREADS, WIN, BLK, COARSE>(S, C, KV, in_stop, kcap, A.stall_window, red, kdone, iters);
+    // where the fp64 fall-back has the coarse level (ill-conditioned meshes: hat, dress-7742) an fp32 BiCGSTAB solve that has not found a new minimum of
+    // |r| for kCoarseStall iterations hands over AT ONCE instead of running to its 400-iteration hand-over: on the pressed-on hat the fp32 stage then
+    // ran 30 ... 185 instead of 400 iterations and the fp64 solve needed what it needed anyway (230 ... 430) — backward 59.7 -> 51.5 ms per batch step of
+    // 64 rollouts, gradients unchanged to three digits (round 6, gpurun_out/r06_17)
+    else r32 = bicgstab32_solve<THREADS, WIN, BLK, COARSE>(S, C, KV, in_stop, kcap, fb_coarse ? min(A.stall_window, kCoarseStall) : A.stall_window, red, kdone, iters);
     const int in_status = r32.status;
     kdone = r32.kdone; iters = r32.iters; rr = r32.rr;
     __syncthreads();

@@ -29,6 +29,8 @@ namespace dc {
 // The leash of the CG correction solves (dc_adjoint.hip: cg32_solve; the split kernel's CG branch): a solve ends unconverged after this many iterations
 // without a new minimum of |r|, or this many iterations in all — the rest of the step is then BiCGSTAB's.
 constexpr int kCgStall = 10, kCgCycleCap = 64;
+// fp32 BiCGSTAB solves of the instances whose fp64 fall-back has the coarse level: iterations without a new minimum of |r| before the hand-over
+constexpr int kCoarseStall = 30;
 
 struct d3 {
   double x, y, z;

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(THREADS) void k_adjoint_step_cl(const DevSystem *__
       rr = sums[1];
       if (rr <= in_stop) { in_status = 1; break; }
       if (rr < best_rr) { best_rr = rr; since_progress = 0; }
-      else if (++since_progress >= A.stall_window) { in_status = 2; break; }
+      else if (++since_progress >= (fb_coarse ? min(A.stall_window, kCoarseStall) : A.stall_window)) { in_status = 2; break; }      // (dc_adjoint.hip: early hand-over)
       if (!(fabs(rho_new) > 1e-300) || !(fabs(omega) > 0.f)) { in_status = 2; break; }
       const float beta = (float) ((rho_new / rho) * ((double) alpha / (double) omega));
       rho = rho_new;
